@@ -1,0 +1,28 @@
+"""emotiongestures_amd -- MI355X-native (gfx950) implementation of the EmotionGesture audio->gesture hot path.
+
+Layout:
+  csrc/ + libemogest_hip.so   hand-written HIP kernels behind the C ABI of include/emogest.h
+  _lib / packing / engine / ops  ctypes binding, weight-arena packing, per-batch engines, block operators
+  modules                     host mirror of the reference's nn.Module surface
+  Full_model/, CAVE/          the reference's import paths (thin re-exports of ``modules``)
+  synth                       platform-exact synthetic weights / inputs
+  dist                        clip sharding across ranks (one process per GPU)
+"""
+from . import synth  # noqa: F401  (pure numpy; safe without the HIP library)
+
+__version__ = "0.1.0"
+
+
+def install_aliases() -> None:
+    """Make the reference's own import lines resolve to this package, e.g.
+    ``from Full_model.Models_memory import Transformer`` and ``from CAVE.BEAT_CVAE import MLP_Reconstruct_v3``
+    (test_emotion_gesture_diversity_iterative.py:25-26)."""
+    import importlib
+    import sys
+
+    for top in ("Full_model", "CAVE"):
+        pkg = importlib.import_module(f"{__name__}.{top}")
+        sys.modules.setdefault(top, pkg)
+    for name in ("Full_model.Models_spatial_memory", "Full_model.Models_memory", "Full_model.Layers", "Full_model.SubLayers",
+                 "Full_model.Modules", "Full_model.tcn", "Full_model.ResNetSE34V2", "Full_model.ResNetBlocks", "CAVE.BEAT_CVAE"):
+        sys.modules.setdefault(name, importlib.import_module(f"{__name__}.{name}"))

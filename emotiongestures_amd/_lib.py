@@ -1,0 +1,127 @@
+"""ctypes binding of libemogest_hip.so (include/emogest.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback anywhere in this package.
+If the shared object is missing, importing any compute entry point raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemogest_hip.so")
+
+EG_PREC_F32, EG_PREC_BF16X3, EG_PREC_BF16 = 0, 1, 2
+PRECISIONS = {"f32": EG_PREC_F32, "fp32": EG_PREC_F32, "bf16x3": EG_PREC_BF16X3, "bf16": EG_PREC_BF16}
+
+(PACK_RAW, PACK_LINEAR, PACK_VEC_PAD, PACK_CONV3X3, PACK_BN_SCALE, PACK_BN_SHIFT, PACK_CONV1X1, PACK_STEM,
+ PACK_WN_TAP, PACK_CONV1D, PACK_POS_TABLE, PACK_LINEAR_T) = range(12)
+
+
+class EgError(RuntimeError):
+    pass
+
+
+class EgWeightEntry(C.Structure):
+    _fields_ = [("key", C.c_char * 192), ("kind", C.c_int32), ("dims", C.c_int32 * 4),
+                ("offset", C.c_int64), ("numel", C.c_int64)]
+
+
+class EgGeneratorConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "frames", "pose_dim", "prior_frames", "chunk", "d_model", "d_inner", "n_layers", "n_head", "d_k",
+        "n_mels", "spec_len", "text_len", "n_words", "embed_dim", "tcn_hidden", "tcn_layers", "variant",
+        "precision", "n_position")] + [("reserved", C.c_int32 * 5)]
+
+
+class EgCvaeConfig(C.Structure):
+    _fields_ = [("frames", C.c_int32), ("d_model", C.c_int32), ("latent", C.c_int32), ("n_classes", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+
+# name -> (restype, argtypes).  Must list every symbol include/emogest.h declares
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "eg_last_error": (C.c_char_p, []),
+    "eg_version": (C.c_char_p, []),
+    "eg_set_default_precision": (C.c_int, [C.c_int]),
+    "eg_get_default_precision": (C.c_int, []),
+    "eg_generator_default_config": (C.c_int, [C.POINTER(EgGeneratorConfig)]),
+    "eg_generator_create": (C.c_int, [C.POINTER(EgGeneratorConfig), C.POINTER(_P)]),
+    "eg_generator_destroy": (None, [_P]),
+    "eg_generator_arena_floats": (_L, [_P]),
+    "eg_generator_num_weights": (_I, [_P]),
+    "eg_generator_weight_entry": (C.c_int, [_P, _I, C.POINTER(EgWeightEntry)]),
+    "eg_generator_workspace_bytes": (_L, [_P, _I]),
+    "eg_generator_forward": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "eg_generator_forward_draws": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "eg_generator_draws_workspace_bytes": (_L, [_P, _I, _I]),
+    "eg_generator_tap": (C.c_int, [_P, _I, _P, C.c_char_p, C.POINTER(_P), C.POINTER(_L)]),
+    "eg_cvae_default_config": (C.c_int, [C.POINTER(EgCvaeConfig)]),
+    "eg_cvae_create": (C.c_int, [C.POINTER(EgCvaeConfig), C.POINTER(_P)]),
+    "eg_cvae_destroy": (None, [_P]),
+    "eg_cvae_arena_floats": (_L, [_P]),
+    "eg_cvae_num_weights": (_I, [_P]),
+    "eg_cvae_weight_entry": (C.c_int, [_P, _I, C.POINTER(EgWeightEntry)]),
+    "eg_cvae_workspace_bytes": (_L, [_P, _I]),
+    "eg_cvae_sample": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    "eg_cvae_forward": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "eg_mel_tables": (C.c_int, [_P, _P, _P]),
+    "eg_mel_workspace_bytes": (_L, [_I, _I]),
+    "eg_melspectrogram": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "eg_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_conv3x3_gap_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "eg_stem_conv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eg_se_gate": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "eg_se_residual_relu": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_linear": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_linear_splitk": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "eg_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
+    "eg_attention": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "eg_mha_workspace_bytes": (_L, [_I, _I, _I, _I]),
+    "eg_multi_head_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "eg_ffn_workspace_bytes": (_L, [_I, _I, _I]),
+    "eg_positionwise_ffn": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "eg_tcn_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "eg_reparameterize": (C.c_int, [_P, _P, _P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises EgError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EgError(
+            f"{LIB_PATH} not found: the HIP library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "emotiongestures_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().eg_last_error()
+        raise EgError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def precision_code(p) -> int:
+    if isinstance(p, int):
+        return p
+    try:
+        return PRECISIONS[str(p).lower()]
+    except KeyError:
+        raise ValueError(f"unknown precision {p!r}; choose from {sorted(PRECISIONS)}")

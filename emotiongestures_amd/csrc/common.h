@@ -1,0 +1,56 @@
+// Shared device/host helpers for libemogest_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "emogest.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef short bf8 __attribute__((ext_vector_type(8)));   // 8 bf16 (one 16x16x32 MFMA operand)
+
+#define EG_WAVE 64
+
+void eg_set_error(const char* fmt, ...);
+
+#define EG_REQUIRE(cond, code, ...)                      \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            eg_set_error(__VA_ARGS__);                   \
+            return (code);                               \
+        }                                                \
+    } while (0)
+
+// Launch check without synchronising (Guideline 9: nothing blocking in a launch function).
+static inline int eg_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        eg_set_error("%s: %s", what, hipGetErrorString(e));
+        return EG_ERR_HIP;
+    }
+    return EG_OK;
+}
+
+static inline bool eg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t eg_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int eg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// fp32 -> (hi, lo) bf16 split: hi = rne(x), lo = rne(x - hi).  x - hi is exact in fp32.
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }

@@ -1,0 +1,524 @@
+// Audio tower kernels: stem conv, 3x3 implicit-GEMM conv on MFMA, SE gate, SE tail (+1x1 downsample).
+// Reference semantics: Full_model/ResNetSE34V2.py:62-74, Full_model/ResNetBlocks.py:21-37,81-96.
+//
+// Data layout in HBM: activations NHWC fp32 (channel innermost, 128 B per pixel at C=32), so that
+// the implicit-GEMM K axis (tap, channel) is contiguous per pixel and every global access is a
+// 16-byte-per-lane coalesced load/store.
+//
+// conv3x3 kernel shape (one workgroup = 4 waves = TH x 32 output pixels x all output channels):
+//   D[co][pix] = sum_{tap,ci} Wt[tap][ci][co] * X[pix + tap][ci]            (swapped operands)
+//   A operand = weights  (lane: co = lane&15, k-quad = lane>>4), streamed from L2 (every workgroup
+//                          reads the same <= 590 KB, so they stay cache resident),
+//   B operand = pixels   (lane: pix = lane&15, k-quad = lane>>4), read from an LDS halo tile kept in a
+//                          channel-quad planar image [ci/4][pixel][4]: a ds_read_b128 per lane, bank-conflict
+//                          free for 16 consecutive pixels (plane stride = 0 mod 16 slots, stride 1; odd, stride 2),
+//   D: each lane owns 4 consecutive output channels of one pixel -> one 16-byte NHWC store per tile.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; const float* scale; const float* shift;
+    float* y; float* gap;
+    int H, W, Ho, Wo, cout, relu, nchw, tiles_x, tiles;
+};
+
+template <int S, int TH> struct ConvGeom {
+    static constexpr int IH = (TH - 1) * S + 3;
+    static constexpr int IW = 31 * S + 3;
+    static constexpr int NPIX = IH * IW;
+    static constexpr int PL = (S == 1) ? ((NPIX + 15) / 16 * 16) : (NPIX | 1);
+    static constexpr int MT = TH * 2 / 4;
+};
+
+// ---- fp32 MFMA path -------------------------------------------------------------------------
+template <int CIN, int NT, int S, int TH>
+__global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
+    using G = ConvGeom<S, TH>;
+    constexpr int COUTP = NT * 16, IW = G::IW, NPIX = G::NPIX, PL = G::PL, MT = G::MT;
+    __shared__ f4 tile[8 * PL];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int tile_id = blockIdx.x, b = blockIdx.y;
+    const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * 32;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+    int pbase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int id = wave * MT + t;
+        pbase[t] = ((id >> 1) * S) * IW + ((id & 1) * 16 + li) * S;
+    }
+    f4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const f4* __restrict__ w4 = reinterpret_cast<const f4*>(a.w);
+    const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
+
+    for (int chunk = 0; chunk < CIN / 32; ++chunk) {
+        if (chunk) __syncthreads();
+        // stage the (IH x IW) x 32-channel halo tile: 8 consecutive lanes = 8 consecutive pixels of one
+        // channel quad (conflict-free ds_write_b128); a wave still covers 8 pixels x 128 contiguous bytes.
+        for (int idx = tid; idx < ((NPIX + 7) / 8) * 64; idx += 256) {
+            const int p = (idx >> 6) * 8 + (idx & 7), cq = (idx >> 3) & 7;
+            if (p < NPIX) {
+                const int iy = p / IW, ix = p - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *reinterpret_cast<const f4*>(xb + ((size_t)gy * a.W + gx) * CIN + chunk * 32 + cq * 4);
+                tile[cq * PL + p] = v;
+            }
+        }
+        __syncthreads();
+        const f4* wp = w4 + (size_t)(chunk * 8 + kq) * COUTP + li;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = kh * 3 + kw, toff = kh * IW + kw;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f4 wv[NT], xv[MT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) wv[n] = wp[(size_t)(tap * (CIN / 4) + g * 4) * COUTP + n * 16];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) xv[t] = tile[(g * 4 + kq) * PL + pbase[t] + toff];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n][j], xv[t][j], acc[t][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: v = acc + bias; relu?; v*scale + shift; NHWC f4 store / NCHW scalar store; SE sums
+    f4 gsum[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + kq * 4;
+        const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
+        const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
+        const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int id = wave * MT + t;
+            const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
+            const bool valid = (oy < a.Ho) && (ox < a.Wo);
+            f4 v = acc[t][n] + bi;
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            v = v * sc + sh;
+            if (valid) {
+                if (!a.nchw) {
+                    if (co < a.cout)
+                        *reinterpret_cast<f4*>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.cout + co) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.cout)
+                            a.y[((size_t)b * a.cout + co + r) * a.Ho * a.Wo + (size_t)oy * a.Wo + ox] = v[r];
+                }
+                gsum[n] += v;
+            }
+        }
+    }
+    if (a.gap) {
+        float* sred = reinterpret_cast<float*>(tile);
+        __syncthreads();                                      // all waves are done reading the halo tile
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = gsum[n][r];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                if (li == 0) sred[wave * COUTP + n * 16 + kq * 4 + r] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < a.cout) {
+            const float s = (sred[tid] + sred[COUTP + tid]) + (sred[2 * COUTP + tid] + sred[3 * COUTP + tid]);
+            a.gap[((size_t)b * a.tiles + tile_id) * a.cout + tid] = s;
+        }
+    }
+}
+
+// ---- split-bf16 MFMA path (EG_PREC_BF16X3 / EG_PREC_BF16) --------------------------------------
+// Same tiling.  The halo tile is split while it is staged: hi = bf16(x), lo = bf16(x - hi), kept as
+// two channel-octet planar images [ci/8][pixel][8 bf16] (same 16-byte slot structure as the fp32
+// image, so the same conflict-free ds_read_b128).  Weights are pre-split on the host into the same
+// octet layout [tap][ci/8][co][8] (hi image, then lo image).  Per 32-channel k-step and tile pair:
+//   acc += Whi*Xhi + Whi*Xlo + Wlo*Xhi        (3 x v_mfma_f32_16x16x32_bf16; lo*lo ~ 2^-16 dropped)
+template <int CIN, int NT, int S, int TH, int TERMS>
+__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
+                                                           const bf8* __restrict__ wlo) {
+    using G = ConvGeom<S, TH>;
+    constexpr int COUTP = NT * 16, IW = G::IW, NPIX = G::NPIX, PL = G::PL, MT = G::MT;
+    __shared__ bf8 tile[(TERMS == 3 ? 2 : 1) * 4 * PL];      // [hi|lo][oct 0..3][pixel]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int tile_id = blockIdx.x, b = blockIdx.y;
+    const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * 32;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+    int pbase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int id = wave * MT + t;
+        pbase[t] = ((id >> 1) * S) * IW + ((id & 1) * 16 + li) * S;
+    }
+    f4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
+
+    for (int chunk = 0; chunk < CIN / 32; ++chunk) {
+        if (chunk) __syncthreads();
+        // one lane = one pixel x 8 channels (two 16-B global loads); 8 consecutive lanes = 8 pixels of one octet
+        for (int idx = tid; idx < ((NPIX + 7) / 8) * 32; idx += 256) {
+            const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
+            if (p < NPIX) {
+                const int iy = p / IW, ix = p - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                f4 v0 = (f4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    const float* src = xb + ((size_t)gy * a.W + gx) * CIN + chunk * 32 + oc * 8;
+                    v0 = *reinterpret_cast<const f4*>(src);
+                    v1 = *reinterpret_cast<const f4*>(src + 4);
+                }
+                bf8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = j < 4 ? v0[j & 3] : v1[j & 3];
+                    const unsigned short h = f32_to_bf16_rne(x);
+                    hi[j] = (short)h;
+                    lo[j] = (short)f32_to_bf16_rne(x - bf16_to_f32(h));
+                }
+                tile[oc * PL + p] = hi;
+                if (TERMS == 3) tile[(4 + oc) * PL + p] = lo;
+            }
+        }
+        __syncthreads();
+        const size_t wbase = (size_t)(chunk * 4 + kq) * COUTP + li;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = kh * 3 + kw, toff = kh * IW + kw;
+                bf8 wh[NT], wl[NT], xh[MT], xl[MT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const size_t wi = wbase + (size_t)tap * (CIN / 8) * COUTP + n * 16;
+                    wh[n] = whi[wi];
+                    if (TERMS == 3) wl[n] = wlo[wi];
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    xh[t] = tile[kq * PL + pbase[t] + toff];
+                    if (TERMS == 3) xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if (TERMS == 3) {
+                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
+                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
+                        }
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    f4 gsum[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + kq * 4;
+        const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
+        const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
+        const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int id = wave * MT + t;
+            const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
+            const bool valid = (oy < a.Ho) && (ox < a.Wo);
+            f4 v = acc[t][n] + bi;
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            v = v * sc + sh;
+            if (valid) {
+                if (!a.nchw) {
+                    if (co < a.cout)
+                        *reinterpret_cast<f4*>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.cout + co) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.cout)
+                            a.y[((size_t)b * a.cout + co + r) * a.Ho * a.Wo + (size_t)oy * a.Wo + ox] = v[r];
+                }
+                gsum[n] += v;
+            }
+        }
+    }
+    if (a.gap) {
+        float* sred = reinterpret_cast<float*>(tile);
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = gsum[n][r];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                if (li == 0) sred[wave * COUTP + n * 16 + kq * 4 + r] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < a.cout) {
+            const float s = (sred[tid] + sred[COUTP + tid]) + (sred[2 * COUTP + tid] + sred[3 * COUTP + tid]);
+            a.gap[((size_t)b * a.tiles + tile_id) * a.cout + tid] = s;
+        }
+    }
+}
+
+// ---- stem: Conv2d(1->C, 3x3, bias) -> ReLU -> BN, x [B,H,W] -> y NHWC ----------------------------
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ y,
+                                                        int B, int H, int W, int C) {
+    const int cq_n = C >> 2;
+    const size_t total = (size_t)B * H * W * cq_n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % cq_n);
+        const size_t p = i / cq_n;
+        const int ox = (int)(p % W);
+        const int oy = (int)((p / W) % H);
+        const size_t b = p / ((size_t)W * H);
+        const float* xb = x + b * H * W;
+        f4 acc = *reinterpret_cast<const f4*>(bias + cq * 4);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int gy = oy + kh - 1, gx = ox + kw - 1;
+                const float xv = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.f;
+                const f4 wv = *reinterpret_cast<const f4*>(w + (kh * 3 + kw) * C + cq * 4);
+                acc += wv * xv;
+            }
+        const f4 sc = *reinterpret_cast<const f4*>(scale + cq * 4), sh = *reinterpret_cast<const f4*>(shift + cq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        *reinterpret_cast<f4*>(y + p * C + cq * 4) = acc * sc + sh;
+    }
+}
+
+// ---- SE gate: GAP finish + FC -> ReLU -> FC -> sigmoid, one workgroup per clip ---------------------
+__global__ __launch_bounds__(128) void se_gate_kernel(const float* __restrict__ gap, int tiles, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ gate, int C, float inv_hw) {
+    __shared__ float m[128];
+    __shared__ float h[16];
+    const int b = blockIdx.x, t = threadIdx.x, R = C >> 3;
+    if (t < C) {
+        float s = 0.f;
+        for (int i = 0; i < tiles; ++i) s += gap[((size_t)b * tiles + i) * C + t];
+        m[t] = s * inv_hw;
+    }
+    __syncthreads();
+    if (t < R) {
+        float s = b1[t];
+        for (int c = 0; c < C; ++c) s += w1[t * C + c] * m[c];
+        h[t] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    if (t < C) {
+        float s = b2[t];
+        for (int j = 0; j < R; ++j) s += w2[t * R + j] * h[j];
+        gate[(size_t)b * C + t] = 1.f / (1.f + expf(-s));
+    }
+}
+
+// ---- SE tail: out = relu(y*gate + residual) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void se_tail_identity_kernel(const f4* __restrict__ y, const float* __restrict__ gate,
+                                                               const f4* __restrict__ res, f4* __restrict__ out,
+                                                               size_t n4, int hw_cq, int cq_n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % cq_n);
+        const size_t b = i / hw_cq;
+        const f4 g = *reinterpret_cast<const f4*>(gate + b * cq_n * 4 + cq * 4);
+        f4 v = y[i] * g + res[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        out[i] = v;
+    }
+}
+
+// residual = BN(conv1x1 stride s (x_in)); weights [CIN][COUT] staged in LDS; one thread = 1 pixel x 4 couts
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void se_tail_downsample_kernel(const float* __restrict__ y, const float* __restrict__ gate,
+                                                                 const float* __restrict__ xin, const float* __restrict__ dsw,
+                                                                 const float* __restrict__ dss, const float* __restrict__ dsh,
+                                                                 float* __restrict__ out, int B, int Ho, int Wo, int Hin, int Win, int S) {
+    __shared__ f4 wl[CIN * COUT / 4];
+    for (int i = threadIdx.x; i < CIN * COUT / 4; i += 256) wl[i] = reinterpret_cast<const f4*>(dsw)[i];
+    __syncthreads();
+    constexpr int CQ = COUT / 4;
+    const size_t total = (size_t)B * Ho * Wo * CQ;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cq = (int)(i % CQ);
+        const size_t p = i / CQ;
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+        const size_t b = p / ((size_t)Wo * Ho);
+        const float* xp = xin + ((b * Hin + (size_t)oy * S) * Win + (size_t)ox * S) * CIN;
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int ci = 0; ci < CIN; ci += 4) {
+            const f4 xv = *reinterpret_cast<const f4*>(xp + ci);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += wl[(ci + j) * CQ + cq] * xv[j];
+        }
+        const f4 res = acc * *reinterpret_cast<const f4*>(dss + cq * 4) + *reinterpret_cast<const f4*>(dsh + cq * 4);
+        const f4 g = *reinterpret_cast<const f4*>(gate + b * COUT + cq * 4);
+        f4 v = *reinterpret_cast<const f4*>(y + p * COUT + cq * 4) * g + res;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        *reinterpret_cast<f4*>(out + p * COUT + cq * 4) = v;
+    }
+}
+
+template <int CIN, int NT, int S, int TH>
+int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
+    dim3 grid(a.tiles, batch), block(256);
+    if (precision == EG_PREC_F32) {
+        hipLaunchKernelGGL((conv3x3_f32_kernel<CIN, NT, S, TH>), grid, block, 0, st, a);
+    } else {
+        // packed bf16 weights follow the fp32 image in the arena: [hi image][lo image], each 9*CIN*COUTP bf16
+        const size_t f32_floats = (size_t)9 * CIN * NT * 16;
+        const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
+        const bf8* wlo = whi + (size_t)9 * (CIN / 8) * NT * 16;
+        if (precision == EG_PREC_BF16X3)
+            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, 3>), grid, block, 0, st, a, whi, wlo);
+        else
+            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, 1>), grid, block, 0, st, a, whi, wlo);
+    }
+    return eg_check_launch("conv3x3");
+}
+
+int conv_tile_rows(int cin, int cout, int stride) {
+    if (stride == 2) return 2;
+    return (cout >= 128 || cin >= 128) ? 4 : 8;
+}
+
+}  // namespace
+
+extern "C" int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride) {
+    const int ho = (h + 2 - 3) / stride + 1, wo = (wdt + 2 - 3) / stride + 1;
+    const int th = conv_tile_rows(cin, cout, stride);
+    return eg_cdiv(ho, th) * eg_cdiv(wo, 32);
+}
+
+// Packed weight size in floats for one 3x3 conv: fp32 image + (hi, lo) bf16 images.
+extern "C" int64_t eg_conv3x3_packed_floats(int32_t cin, int32_t cout_pad) {
+    return (int64_t)9 * cin * cout_pad * 2;     // 9*cin*coutp fp32 + 2 * 9*cin*coutp bf16 (= same bytes again)
+}
+
+extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                          float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
+                          int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
+    EG_REQUIRE(x && w && y && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3: null pointer or empty shape");
+    EG_REQUIRE(eg_aligned16(x) && eg_aligned16(w) && eg_aligned16(y), EG_ERR_ALIGN, "eg_conv3x3: pointers must be 16-byte aligned");
+    EG_REQUIRE(stride == 1 || stride == 2, EG_ERR_UNSUPPORTED, "eg_conv3x3: stride %d", stride);
+    EG_REQUIRE(precision >= 0 && precision <= 2, EG_ERR_BAD_ARG, "eg_conv3x3: precision %d", precision);
+    EG_REQUIRE(nchw_out || (cout % 4 == 0), EG_ERR_UNSUPPORTED, "eg_conv3x3: NHWC output needs cout %% 4 == 0");
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.gap = gap_partial;
+    a.H = h; a.W = wdt; a.Ho = (h + 2 - 3) / stride + 1; a.Wo = (wdt + 2 - 3) / stride + 1;
+    a.cout = cout; a.relu = relu; a.nchw = nchw_out;
+    const int th = conv_tile_rows(cin, cout, stride);
+    a.tiles_x = eg_cdiv(a.Wo, 32);
+    a.tiles = a.tiles_x * eg_cdiv(a.Ho, th);
+    hipStream_t st = (hipStream_t)stream;
+    const int coutp = (int)eg_round_up(cout, 16);
+    if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8>(a, batch, precision, st);
+    if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2>(a, batch, precision, st);
+    if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8>(a, batch, precision, st);
+    if (cin == 64 && coutp == 128 && stride == 2) return launch_conv<64, 8, 2, 2>(a, batch, precision, st);
+    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4>(a, batch, precision, st);
+    if (cin == 128 && coutp <= 64 && stride == 1) {       // final_conv1: 128 -> frames (34 -> 48, 60 -> 64)
+        if (coutp <= 48) return launch_conv<128, 3, 1, 4>(a, batch, precision, st);
+        return launch_conv<128, 4, 1, 4>(a, batch, precision, st);
+    }
+    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4>(a, batch, precision, st);
+    eg_set_error("eg_conv3x3: unsupported channels cin=%d cout=%d stride=%d", cin, cout, stride);
+    return EG_ERR_UNSUPPORTED;
+}
+
+extern "C" int eg_stem_conv(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift,
+                            float* y, int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream) {
+    EG_REQUIRE(x && w9xc && bias && scale && shift && y && batch > 0, EG_ERR_BAD_ARG, "eg_stem_conv: null pointer");
+    EG_REQUIRE(c % 4 == 0 && c <= 128, EG_ERR_UNSUPPORTED, "eg_stem_conv: C=%d", c);
+    const size_t total = (size_t)batch * h * wdt * (c / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w9xc, bias, scale, shift, y,
+                       batch, h, wdt, c);
+    return eg_check_launch("stem_conv");
+}
+
+extern "C" int eg_se_gate(const float* gap_partial, int32_t tiles, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* gate, int32_t batch, int32_t c, int32_t hw, void* stream) {
+    EG_REQUIRE(gap_partial && w1 && b1 && w2 && b2 && gate && batch > 0, EG_ERR_BAD_ARG, "eg_se_gate: null pointer");
+    EG_REQUIRE(c % 8 == 0 && c <= 128, EG_ERR_UNSUPPORTED, "eg_se_gate: C=%d", c);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(128), 0, (hipStream_t)stream, gap_partial, tiles, w1, b1, w2, b2,
+                       gate, c, 1.0f / (float)hw);
+    return eg_check_launch("se_gate");
+}
+
+extern "C" int eg_se_residual_relu(const float* y, const float* gate, const float* x_in, const float* ds_w,
+                                   const float* ds_scale, const float* ds_shift, float* out, int32_t batch, int32_t ho,
+                                   int32_t wo, int32_t c, int32_t h_in, int32_t w_in, int32_t cin, int32_t stride, void* stream) {
+    EG_REQUIRE(y && gate && x_in && out && batch > 0, EG_ERR_BAD_ARG, "eg_se_residual_relu: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (!ds_w) {
+        EG_REQUIRE(cin == c && h_in == ho && w_in == wo, EG_ERR_BAD_ARG, "eg_se_residual_relu: identity shortcut shape mismatch");
+        const size_t n4 = (size_t)batch * ho * wo * c / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+        hipLaunchKernelGGL(se_tail_identity_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f4*>(y), gate,
+                           reinterpret_cast<const f4*>(x_in), reinterpret_cast<f4*>(out), n4, ho * wo * (c / 4), c / 4);
+        return eg_check_launch("se_tail");
+    }
+    EG_REQUIRE(ds_scale && ds_shift, EG_ERR_BAD_ARG, "eg_se_residual_relu: downsample BN missing");
+    const size_t total = (size_t)batch * ho * wo * (c / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (cin == 32 && c == 64)
+        hipLaunchKernelGGL((se_tail_downsample_kernel<32, 64>), dim3(blocks), dim3(256), 0, st, y, gate, x_in, ds_w, ds_scale,
+                           ds_shift, out, batch, ho, wo, h_in, w_in, stride);
+    else if (cin == 64 && c == 128)
+        hipLaunchKernelGGL((se_tail_downsample_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, y, gate, x_in, ds_w, ds_scale,
+                           ds_shift, out, batch, ho, wo, h_in, w_in, stride);
+    else {
+        eg_set_error("eg_se_residual_relu: unsupported downsample %d->%d", cin, c);
+        return EG_ERR_UNSUPPORTED;
+    }
+    return eg_check_launch("se_tail_downsample");
+}

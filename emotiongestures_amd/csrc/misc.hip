@@ -1,0 +1,528 @@
+// Small kernels of the generator: LayerNorm, single-tile attention, embedding gather, row-periodic add,
+// TCN time-axis Linear, prior/memory encoder, CVAE conv1d / convT1d, reparameterise.
+#include "common.h"
+
+namespace {
+
+// ---- LayerNorm (Full_model/SubLayers.py:55-57,80-82): one wave per row, two-pass in registers ----------
+template <int NV>   // NV f4 per lane (D <= NV*256)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y, int rows, int D,
+                                                        float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * D);
+    const int nq = D >> 2;
+    f4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + i * 64;
+        v[i] = q < nq ? xr[q] : (f4){0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nq) {
+            const f4 d = v[i] - mean;
+            ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    f4* yr = reinterpret_cast<f4*>(y + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nq) yr[q] = (v[i] - mean) * rstd * reinterpret_cast<const f4*>(g)[q] + reinterpret_cast<const f4*>(b)[q];
+    }
+}
+
+// ---- attention (Full_model/Modules.py:13-23), one workgroup per (q-chunk, head, clip) --------------------
+constexpr int ATT_QC = 32;      // query rows per workgroup
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                        const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
+                                                        float* __restrict__ attn, int H, int Lq, int Lk, float inv_temp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int qc = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int q0 = qc * ATT_QC, nq = min(ATT_QC, Lq - q0);
+    float* Qs = sm;                         // [ATT_QC][65]
+    float* Ks = Qs + ATT_QC * 65;           // [Lk][65]
+    float* Vs = Ks + Lk * 65;               // [Lk][64]
+    float* Ss = Vs + Lk * 64;               // [ATT_QC][Lk]
+    for (int i = tid; i < nq * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        const f4 t = *reinterpret_cast<const f4*>(q + ((size_t)b * Lq + q0 + r) * ldq + h * 64 + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Qs[r * 65 + c + j] = t[j] * inv_temp;      // q / temperature first (Modules.py:15)
+    }
+    for (int i = tid; i < Lk * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        const f4 tk = *reinterpret_cast<const f4*>(k + ((size_t)b * Lk + r) * ldk + h * 64 + c);
+        const f4 tv = *reinterpret_cast<const f4*>(v + ((size_t)b * Lk + r) * ldv + h * 64 + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ks[r * 65 + c + j] = tk[j];
+        *reinterpret_cast<f4*>(Vs + r * 64 + c) = tv;
+    }
+    __syncthreads();
+    for (int i = tid; i < nq * Lk; i += 256) {
+        const int r = i / Lk, c = i - r * Lk;
+        float s = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < 64; ++d) s += Qs[r * 65 + d] * Ks[c * 65 + d];
+        Ss[r * Lk + c] = s;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < nq; r += 4) {
+        float m = -3.0e38f;
+        for (int c = lane; c < Lk; c += 64) m = fmaxf(m, Ss[r * Lk + c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < Lk; c += 64) {
+            const float e = expf(Ss[r * Lk + c] - m);
+            Ss[r * Lk + c] = e;
+            s += e;
+        }
+        const float inv = 1.0f / wave_sum(s);
+        for (int c = lane; c < Lk; c += 64) {
+            const float p = Ss[r * Lk + c] * inv;
+            Ss[r * Lk + c] = p;
+            if (attn) attn[(((size_t)b * H + h) * Lq + q0 + r) * Lk + c] = p;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nq * 64; i += 256) {
+        const int r = i >> 6, d = i & 63;
+        float s = 0.f;
+        for (int c = 0; c < Lk; ++c) s += Ss[r * Lk + c] * Vs[c * 64 + d];
+        out[((size_t)b * Lq + q0 + r) * ldo + h * 64 + d] = s;
+    }
+}
+
+// ---- elementwise helpers -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
+                                                        float* __restrict__ out, int rows, int dim, int ld, int n_words) {
+    const int dq = dim >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * dq; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / dq), c = (int)(i % dq);
+        int64_t w = idx[r];
+        w = w < 0 ? 0 : (w >= n_words ? n_words - 1 : w);
+        *reinterpret_cast<f4*>(out + (size_t)r * ld + c * 4) = *reinterpret_cast<const f4*>(table + (size_t)w * dim + c * 4);
+    }
+}
+
+// out = a + b ;  b optionally row-periodic (row % period) -- positional table add (Models_spatial_memory.py:46-48)
+__global__ __launch_bounds__(256) void add_kernel(const f4* __restrict__ a, const f4* __restrict__ b, f4* __restrict__ out,
+                                                  size_t n4, int row_q, int period) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        size_t j = i;
+        if (period) {
+            const size_t row = i / row_q;
+            j = (row % period) * row_q + (i - row * row_q);
+        }
+        out[i] = a[i] + b[j];
+    }
+}
+
+// ---- TextEncoderTCN.fc1: Linear over the time axis (Models_spatial_memory.py:164-166,176) -----------------
+// x, y [B, L, C] channels-last:  y[b,t',c] = bias[t'] + sum_t W[t',t] x[b,t,c]
+__global__ __launch_bounds__(256) void time_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int L, int C, int ld) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ws = sm;             // [L][L]
+    float* Xs = sm + L * L;     // [L][64]
+    const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int i = tid; i < L * L; i += 256) Ws[i] = w[i];
+    for (int i = tid; i < L * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        Xs[i] = (c0 + c < C) ? x[((size_t)b * L + t) * ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int c = tid & 63;
+    if (c0 + c >= C) return;
+    for (int tp = tid >> 6; tp < L; tp += 4) {
+        float s = bias[tp];
+        for (int t = 0; t < L; ++t) s += Ws[tp * L + t] * Xs[t * 64 + c];
+        y[((size_t)b * L + tp) * ld + c0 + c] = s;
+    }
+}
+
+// ---- Prior_MemoryEncoder front half (Models_spatial_memory.py:366-390; Models_memory.py:233-251,282-287) ---
+struct PriorArgs {
+    const float* prior;         // [B,P,D]
+    const float *w1, *b1, *s1, *t1;     // Conv1d(P->PL,k3) raw [PL][P][3], bias, BN scale/shift
+    const float *w2, *b2, *s2, *t2;     // Conv1d(PL->PL,k3)
+    // memory variant (NULL for spatial): SP_v1 chunk encoder and TM encoders, raw nn.Linear layouts
+    const float *sp_w0, *sp_b0, *sp_w1, *sp_b1;         // [D, chunk*D], [D], [D,D], [D]
+    const float *tc_w0, *tc_b0, *tc_w1, *tc_b1;         // temporal_chunk_encoder
+    const float *tm_w0, *tm_b0, *tm_w1, *tm_b1;         // temporal_memory_encoder [chunk, chunk*D], [chunk], [chunk,chunk], [chunk]
+    float* cat;                 // [B,F,Dpad] = cat(prior, pred), zero padded
+    float* tm_mem;              // [B,D]
+    float* tm_pe;               // [B,chunk]
+    int P, PL, D, Dpad, chunk, variant;
+};
+
+__device__ __forceinline__ float block_dot(const float* __restrict__ wrow, const float* __restrict__ xs, int n, int lane) {
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += wrow[i] * xs[i];
+    return wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int P = a.P, PL = a.PL, D = a.D, DW = D + 2;
+    float* xs = sm;                     // [P][D+2]  (zero halo)
+    float* h1 = xs + P * DW;            // [PL][D+2]
+    float* h2 = h1 + PL * DW;           // [PL][D]
+    float* v0 = h2 + PL * D;            // [chunk*D] flat chunk / scratch
+    float* v1 = v0 + a.chunk * D;       // [D]
+    float* v2 = v1 + D;                 // [D]
+    for (int i = tid; i < P * DW; i += 256) {
+        const int f = i / DW, d = i - f * DW - 1;
+        xs[i] = (d >= 0 && d < D) ? a.prior[((size_t)b * P + f) * D + d] : 0.f;
+    }
+    for (int i = tid; i < PL * DW; i += 256) h1[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < PL * D; i += 256) {
+        const int co = i / D, d = i - co * D;
+        float s = a.b1[co];
+        for (int ci = 0; ci < P; ++ci) {
+            const float* wp = a.w1 + (co * P + ci) * 3;
+            const float* xp = xs + ci * DW + d;
+            s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
+        }
+        h1[co * DW + d + 1] = fmaxf(s, 0.f) * a.s1[co] + a.t1[co];
+    }
+    __syncthreads();
+    for (int i = tid; i < PL * D; i += 256) {
+        const int co = i / D, d = i - co * D;
+        float s = a.b2[co];
+        for (int ci = 0; ci < PL; ++ci) {
+            const float* wp = a.w2 + (co * PL + ci) * 3;
+            const float* xp = h1 + ci * DW + d;
+            s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
+        }
+        h2[i] = fmaxf(s, 0.f) * a.s2[co] + a.t2[co];
+    }
+    __syncthreads();
+    if (a.variant == 1) {
+        const int CD = a.chunk * D;
+        // flat last-chunk prior frames (Models_memory.py:237)
+        for (int i = tid; i < CD; i += 256) {
+            const int f = i / D, d = i - f * D;
+            v0[i] = xs[(P - a.chunk + f) * DW + d + 1];
+        }
+        __syncthreads();
+        // SP_v1: mem = L1(L0(flat)) ; s = sigmoid(<mem, pred_c>) ; pred_c = s*pred_c + (1-s)*mem
+        for (int n = wave; n < D; n += 4) {
+            const float s = block_dot(a.sp_w0 + (size_t)n * CD, v0, CD, lane);
+            if (lane == 0) v1[n] = s + a.sp_b0[n];
+        }
+        __syncthreads();
+        for (int n = wave; n < D; n += 4) {
+            const float s = block_dot(a.sp_w1 + (size_t)n * D, v1, D, lane);
+            if (lane == 0) v2[n] = s + a.sp_b1[n];
+        }
+        __syncthreads();
+        // TM memory encoding uses the same flat chunk (Models_memory.py:285): compute before v0 is reused
+        for (int n = wave; n < D; n += 4) {
+            const float s = block_dot(a.tc_w0 + (size_t)n * CD, v0, CD, lane);
+            if (lane == 0) v1[n] = s + a.tc_b0[n];
+        }
+        __syncthreads();
+        for (int n = wave; n < D; n += 4) {
+            const float s = block_dot(a.tc_w1 + (size_t)n * D, v1, D, lane);
+            if (lane == 0) a.tm_mem[(size_t)b * D + n] = s + a.tc_b1[n];
+        }
+        for (int c = wave; c < a.chunk; c += 4) {           // gate each of the first `chunk` predicted frames
+            const float dot = block_dot(v2, h2 + c * D, D, lane);
+            const float sg = 1.f / (1.f + expf(-dot));
+            for (int d = lane; d < D; d += 64) h2[c * D + d] = sg * h2[c * D + d] + (1.f - sg) * v2[d];
+        }
+        __syncthreads();
+        // TM pred encoding on the gated frames: pe = M1(M0(flat(pred[:chunk])))  (Models_memory.py:286)
+        for (int n = wave; n < a.chunk; n += 4) {
+            const float s = block_dot(a.tm_w0 + (size_t)n * CD, h2, CD, lane);
+            if (lane == 0) v1[n] = s + a.tm_b0[n];
+        }
+        __syncthreads();
+        if (tid < a.chunk) {
+            float s = a.tm_b1[tid];
+            for (int j = 0; j < a.chunk; ++j) s += a.tm_w1[tid * a.chunk + j] * v1[j];
+            a.tm_pe[(size_t)b * a.chunk + tid] = s;
+        }
+    }
+    const int F = P + PL;
+    for (int i = tid; i < F * a.Dpad; i += 256) {
+        const int f = i / a.Dpad, d = i - f * a.Dpad;
+        float v = 0.f;
+        if (d < D) v = f < P ? xs[f * DW + d + 1] : h2[(f - P) * D + d];
+        a.cat[((size_t)b * F + f) * a.Dpad + d] = v;
+    }
+}
+
+// TM_Memory_Net cross-batch step (Models_memory.py:288-292):  G = mem^T @ pe  [D,chunk]  (sum over the batch)
+__global__ __launch_bounds__(256) void tm_gram_kernel(const float* __restrict__ mem, const float* __restrict__ pe,
+                                                      float* __restrict__ G, int B, int D, int chunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D * chunk) return;
+    const int d = i / chunk, c = i - d * chunk;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += mem[(size_t)b * D + d] * pe[(size_t)b * chunk + c];
+    G[i] = s;
+}
+// score = mem[b] @ G ; w = softmax(score) ; cat[b, P+c, :] *= (1 + w[c])
+__global__ __launch_bounds__(64) void tm_apply_kernel(const float* __restrict__ mem, const float* __restrict__ G,
+                                                      float* __restrict__ cat, int D, int Dpad, int chunk, int P, int F) {
+    __shared__ float sc[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int c = 0; c < chunk; ++c) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += mem[(size_t)b * D + d] * G[d * chunk + c];
+        s = wave_sum(s);
+        if (lane == 0) sc[c] = s;
+        mx = fmaxf(mx, s);
+    }
+    __syncthreads();
+    float den = 0.f;
+    for (int c = 0; c < chunk; ++c) den += expf(sc[c] - mx);
+    for (int c = 0; c < chunk; ++c) {
+        const float w = expf(sc[c] - mx) / den;
+        float* row = cat + ((size_t)b * F + P + c) * Dpad;
+        for (int d = lane; d < D; d += 64) row[d] = row[d] + row[d] * w;
+    }
+}
+
+// ---- CVAE 1-D convolutions (CAVE/BEAT_CVAE.py:318-332,355-369), layout [n][C][L] ----------------------------
+// y[n,co,l] = post( bias[co] + sum_{ci,k} w[co,ci,k] x[n,ci,l*stride + k - pad] );  post = LeakyReLU(0.2) then BN affine
+// One workgroup = (sample, 128-wide l tile); the input tile lives in LDS; every thread of the workgroup works on
+// the same co at a time so the weight reads are wave-uniform (scalar loads).
+__global__ __launch_bounds__(128) void conv1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout,
+                                                     int Lin, int Lout, int K, int stride, int pad, int act) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int n = blockIdx.y, l0 = blockIdx.x * 128, tid = threadIdx.x;
+    const int span = 127 * stride + K;              // input columns needed by this tile
+    const int in0 = l0 * stride - pad;
+    for (int i = tid; i < Cin * span; i += 128) {
+        const int ci = i / span, j = i - ci * span, gl = in0 + j;
+        sm[i] = (gl >= 0 && gl < Lin) ? x[((size_t)n * Cin + ci) * Lin + gl] : 0.f;
+    }
+    __syncthreads();
+    const int l = l0 + tid;
+    if (l >= Lout) return;
+    for (int co = 0; co < Cout; ++co) {
+        float s = bias[co];
+        const float* wr = w + (size_t)co * Cin * K;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xp = sm + ci * span + tid * stride;
+            for (int k = 0; k < K; ++k) s += wr[ci * K + k] * xp[k];
+        }
+        if (act) {
+            s = s > 0.f ? s : 0.2f * s;
+            s = s * scale[co] + shift[co];
+        }
+        y[((size_t)n * Cout + co) * Lout + l] = s;
+    }
+}
+
+// ConvTranspose1d(k=3, stride=2, padding=1, output_padding=1): Lout = 2*Lin; weight [Cin][Cout][3]
+// y[co, lo] = bias + sum_ci sum_k [ (lo + 1 - k) even, li = (lo+1-k)/2 in range ] x[ci, li] w[ci, co, k]
+__global__ __launch_bounds__(128) void convt1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout,
+                                                      int Lin) {
+    const int n = blockIdx.y, lo = blockIdx.x * 128 + threadIdx.x, Lout = 2 * Lin;
+    if (lo >= Lout) return;
+    for (int co = 0; co < Cout; ++co) {
+        float s = bias[co];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xr = x + ((size_t)n * Cin + ci) * Lin;
+            const float* wr = w + ((size_t)ci * Cout + co) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int t = lo + 1 - k;
+                if (t >= 0 && !(t & 1) && (t >> 1) < Lin) s += xr[t >> 1] * wr[k];
+            }
+        }
+        s = s > 0.f ? s : 0.2f * s;
+        s = s * scale[co] + shift[co];
+        y[((size_t)n * Cout + co) * Lout + lo] = s;
+    }
+}
+
+// tiny dense layer for the CVAE MLPs (<= 512 wide): y[n, o] = bias[o] + sum_i w[o,i] x[n,i]; one wave per output
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int ldy,
+                                                           int In, int Out) {
+    const int n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int o = blockIdx.x * 4 + wave; o < Out; o += gridDim.x * 4) {
+        float s = 0.f;
+        for (int i = lane; i < In; i += 64) s += w[(size_t)o * In + i] * x[(size_t)n * ldx + i];
+        s = wave_sum(s);
+        if (lane == 0) y[(size_t)n * ldy + o] = s + bias[o];
+    }
+}
+
+__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                      const float* __restrict__ eps, float* __restrict__ z, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) z[i] = eps[i] * expf(0.5f * logvar[i]) + mu[i];
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd,
+                                                     int rows, int cols) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * cols; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
+    }
+}
+
+// out[row] = (a ? a[row] : 0) + b[(row / (rep*period)) * period + row % period]   (per-clip rows broadcast over `rep` draws)
+__global__ __launch_bounds__(256) void add_bcast_kernel(const f4* __restrict__ a, const f4* __restrict__ b, f4* __restrict__ out,
+                                                        size_t n4, int row_q, int period, int rep) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / row_q;
+        const size_t brow = (row / ((size_t)rep * period)) * period + row % period;
+        const f4 bv = b[brow * row_q + (i - row * row_q)];
+        out[i] = a ? a[i] + bv : bv;
+    }
+}
+
+inline int grid_for(size_t n, int cap = 4096) {
+    const size_t g = (n + 255) / 256;
+    return (int)(g < (size_t)cap ? (g ? g : 1) : cap);
+}
+
+}  // namespace
+
+// ================================ C ABI + internal launchers =============================================
+
+extern "C" int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
+                            float eps, void* stream) {
+    EG_REQUIRE(x && gamma && beta && y && rows > 0, EG_ERR_BAD_ARG, "eg_layernorm: null pointer");
+    EG_REQUIRE((d & 3) == 0 && d <= 2048, EG_ERR_UNSUPPORTED, "eg_layernorm: D=%d", d);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(eg_cdiv(rows, 4)), block(256);
+    if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
+    else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
+    else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
+    return eg_check_launch("layernorm");
+}
+
+extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
+                            float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
+                            int32_t dk, void* stream) {
+    EG_REQUIRE(q && k && v && out && batch > 0 && heads > 0 && lq > 0 && lk > 0, EG_ERR_BAD_ARG, "eg_attention: null pointer or empty shape");
+    EG_REQUIRE(dk == 64, EG_ERR_UNSUPPORTED, "eg_attention: d_k=%d (64 supported)", dk);
+    EG_REQUIRE(lk <= 256, EG_ERR_UNSUPPORTED, "eg_attention: Lk=%d > 256", lk);
+    EG_REQUIRE(((ldq | ldk | ldv) & 3) == 0, EG_ERR_ALIGN, "eg_attention: row strides must be multiples of 4");
+    const size_t smem = sizeof(float) * ((size_t)ATT_QC * 65 + (size_t)lk * 65 + (size_t)lk * 64 + (size_t)ATT_QC * lk);
+    dim3 grid(eg_cdiv(lq, ATT_QC), heads, batch);
+    if (smem > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, attn, heads,
+                       lq, lk, 1.0f / sqrtf((float)dk));
+    return eg_check_launch("attention");
+}
+
+extern "C" int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream) {
+    EG_REQUIRE(mu && logvar && eps && z && n > 0, EG_ERR_BAD_ARG, "eg_reparameterize: null pointer");
+    hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n);
+    return eg_check_launch("reparameterize");
+}
+
+// ---- internal (C++ linkage) launchers used by generator.hip ------------------------------------------------
+int egi_embedding(const int64_t* idx, const float* table, float* out, int rows, int dim, int ld, int n_words, hipStream_t st) {
+    hipLaunchKernelGGL(embedding_kernel, dim3(grid_for((size_t)rows * dim / 4)), dim3(256), 0, st, idx, table, out, rows, dim, ld, n_words);
+    return eg_check_launch("embedding");
+}
+int egi_add(const float* a, const float* b, float* out, size_t n, int row_len, int period, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f4*>(a),
+                       reinterpret_cast<const f4*>(b), reinterpret_cast<f4*>(out), n / 4, row_len / 4, period);
+    return eg_check_launch("add");
+}
+int egi_add_bcast(const float* a, const float* b, float* out, size_t rows, int row_len, int period, int rep, hipStream_t st) {
+    const size_t n4 = rows * (size_t)(row_len / 4);
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(n4)), dim3(256), 0, st, reinterpret_cast<const f4*>(a),
+                       reinterpret_cast<const f4*>(b), reinterpret_cast<f4*>(out), n4, row_len / 4, period, rep);
+    return eg_check_launch("add_bcast");
+}
+int egi_time_linear(const float* x, const float* w, const float* bias, float* y, int batch, int L, int C, int ld, hipStream_t st) {
+    const size_t smem = sizeof(float) * ((size_t)L * L + (size_t)L * 64);
+    hipLaunchKernelGGL(time_linear_kernel, dim3(eg_cdiv(C, 64), batch), dim3(256), smem, st, x, w, bias, y, L, C, ld);
+    return eg_check_launch("time_linear");
+}
+int egi_copy2d(const float* src, int lds_, float* dst, int ldd, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+    return eg_check_launch("copy2d");
+}
+
+struct EgiPriorW {
+    const float *w1, *b1, *s1, *t1, *w2, *b2, *s2, *t2;
+    const float *sp_w0, *sp_b0, *sp_w1, *sp_b1, *tc_w0, *tc_b0, *tc_w1, *tc_b1, *tm_w0, *tm_b0, *tm_w1, *tm_b1;
+};
+int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float* tm_mem, float* tm_pe, float* tm_gram,
+                      int batch, int P, int F, int D, int Dpad, int chunk, int variant, hipStream_t st) {
+    PriorArgs a;
+    a.prior = prior; a.w1 = w.w1; a.b1 = w.b1; a.s1 = w.s1; a.t1 = w.t1; a.w2 = w.w2; a.b2 = w.b2; a.s2 = w.s2; a.t2 = w.t2;
+    a.sp_w0 = w.sp_w0; a.sp_b0 = w.sp_b0; a.sp_w1 = w.sp_w1; a.sp_b1 = w.sp_b1;
+    a.tc_w0 = w.tc_w0; a.tc_b0 = w.tc_b0; a.tc_w1 = w.tc_w1; a.tc_b1 = w.tc_b1;
+    a.tm_w0 = w.tm_w0; a.tm_b0 = w.tm_b0; a.tm_w1 = w.tm_w1; a.tm_b1 = w.tm_b1;
+    a.cat = cat; a.tm_mem = tm_mem; a.tm_pe = tm_pe;
+    a.P = P; a.PL = F - P; a.D = D; a.Dpad = Dpad; a.chunk = chunk; a.variant = variant;
+    const int PL = F - P;
+    const size_t smem = sizeof(float) * ((size_t)P * (D + 2) + (size_t)PL * (D + 2) + (size_t)PL * D + (size_t)chunk * D + 2 * (size_t)D);
+    if (smem > 160 * 1024) { eg_set_error("prior encoder: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(prior_pred_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(prior_pred_kernel, dim3(batch), dim3(256), smem, st, a);
+    int rc = eg_check_launch("prior_pred");
+    if (rc || variant != 1) return rc;
+    hipLaunchKernelGGL(tm_gram_kernel, dim3(eg_cdiv(D * chunk, 256)), dim3(256), 0, st, tm_mem, tm_pe, tm_gram, batch, D, chunk);
+    if ((rc = eg_check_launch("tm_gram"))) return rc;
+    hipLaunchKernelGGL(tm_apply_kernel, dim3(batch), dim3(64), 0, st, tm_mem, tm_gram, cat, D, Dpad, chunk, P, F);
+    return eg_check_launch("tm_apply");
+}
+
+int egi_conv1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int n, int cin,
+               int cout, int lin, int k, int stride, int pad, int act, hipStream_t st) {
+    const int lout = (lin + 2 * pad - k) / stride + 1;
+    const size_t smem = sizeof(float) * (size_t)cin * (127 * stride + k);
+    if (smem > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(conv1d_kernel, dim3(eg_cdiv(lout, 128), n), dim3(128), smem, st, x, w, bias, scale, shift, y, cin, cout, lin,
+                       lout, k, stride, pad, act);
+    return eg_check_launch("conv1d");
+}
+int egi_convt1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int n, int cin,
+                int cout, int lin, hipStream_t st) {
+    hipLaunchKernelGGL(convt1d_kernel, dim3(eg_cdiv(2 * lin, 128), n), dim3(128), 0, st, x, w, bias, scale, shift, y, cin, cout, lin);
+    return eg_check_launch("convt1d");
+}
+int egi_small_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int n, int in, int out,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(small_linear_kernel, dim3(eg_cdiv(out, 4) < 64 ? eg_cdiv(out, 4) : 64, n), dim3(256), 0, st, x, ldx, w, bias, y,
+                       ldy, in, out);
+    return eg_check_launch("small_linear");
+}

@@ -1,0 +1,234 @@
+"""Tensor-level wrappers of the block operators in include/emogest.h.
+
+Used by the module-level host mirrors and by the per-kernel parity tests.  They take GPU torch
+tensors, pack weights into the library's layouts where needed, call the C ABI on the current HIP
+stream and return GPU tensors.  No arithmetic of the path is done in torch here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import packing
+from .engine import _need_cuda, _ptr, _stream
+
+
+def _dev(t):
+    return t.device
+
+
+def pack_linear_weight(w: torch.Tensor, device) -> torch.Tensor:
+    """nn.Linear weight [N,K] -> EG_PACK_LINEAR image on `device` (rows padded to 16, K to 8)."""
+    n, k = w.shape
+    npad, kpad = (n + 15) // 16 * 16, (k + 7) // 8 * 8
+    return torch.from_numpy(packing._pack_linear(w.detach().cpu().float(), npad, kpad)).to(device), npad, kpad
+
+
+def pack_conv3x3_weight(w: torch.Tensor, device):
+    opad = (w.shape[0] + 15) // 16 * 16
+    return torch.from_numpy(packing._pack_conv3x3(w.detach().cpu().float(), opad)).to(device), opad
+
+
+def _padvec(v: Optional[torch.Tensor], npad: int, device, fill=0.0):
+    if v is None:
+        return None
+    out = torch.full((npad,), fill, dtype=torch.float32, device=device)
+    out[: v.numel()] = v.detach().to(device, torch.float32).reshape(-1)
+    return out
+
+
+def conv3x3(x_nhwc, weight_oihw, bias=None, scale=None, shift=None, stride=1, relu=False, nchw_out=False, want_gap=False,
+            precision="f32"):
+    """Conv2d 3x3 pad 1 + fused epilogue (Full_model/ResNetBlocks.py:12,14).  x NHWC [B,H,W,Cin]."""
+    lib = L.load()
+    x = _need_cuda(x_nhwc, "x")
+    dev = x.device
+    B, H, W, Cin = x.shape
+    Cout = weight_oihw.shape[0]
+    wp, opad = pack_conv3x3_weight(weight_oihw, dev)
+    bias_p, scale_p, shift_p = _padvec(bias, opad, dev), _padvec(scale, opad, dev), _padvec(shift, opad, dev)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cout, Ho * Wo) if nchw_out else (B, Ho, Wo, Cout), device=dev)
+    gap = None
+    tiles = lib.eg_conv3x3_gap_tiles(H, W, Cin, Cout, stride)
+    if want_gap:
+        gap = torch.empty(B, tiles, Cout, device=dev)
+    L.check(lib.eg_conv3x3(_ptr(x), _ptr(wp), _ptr(bias_p), _ptr(scale_p), _ptr(shift_p), _ptr(y), _ptr(gap), B, H, W, Cin, Cout,
+                           stride, int(relu), int(nchw_out), L.precision_code(precision), _stream(dev)), "eg_conv3x3")
+    return (y, gap) if want_gap else y
+
+
+def stem_conv(x, weight, bias, scale, shift):
+    lib = L.load()
+    x = _need_cuda(x, "x")
+    dev = x.device
+    B, H, W = x.shape
+    Cc = weight.shape[0]
+    w9 = weight.detach().reshape(Cc, 9).t().contiguous().to(dev, torch.float32)
+    y = torch.empty(B, H, W, Cc, device=dev)
+    L.check(lib.eg_stem_conv(_ptr(x), _ptr(w9), _ptr(_need_cuda(bias, "bias")), _ptr(_need_cuda(scale, "scale")),
+                             _ptr(_need_cuda(shift, "shift")), _ptr(y), B, H, W, Cc, _stream(dev)), "eg_stem_conv")
+    return y
+
+
+def se_gate(gap_partial, w1, b1, w2, b2, hw: int):
+    lib = L.load()
+    g = _need_cuda(gap_partial, "gap")
+    dev = g.device
+    B, tiles, Cc = g.shape
+    gate = torch.empty(B, Cc, device=dev)
+    L.check(lib.eg_se_gate(_ptr(g), tiles, _ptr(_need_cuda(w1, "w1")), _ptr(_need_cuda(b1, "b1")), _ptr(_need_cuda(w2, "w2")),
+                           _ptr(_need_cuda(b2, "b2")), _ptr(gate), B, Cc, hw, _stream(dev)), "eg_se_gate")
+    return gate
+
+
+def se_residual_relu(y, gate, x_in, ds_weight=None, ds_scale=None, ds_shift=None, stride=1):
+    lib = L.load()
+    y, gate, x_in = _need_cuda(y, "y"), _need_cuda(gate, "gate"), _need_cuda(x_in, "x_in")
+    dev = y.device
+    B, Ho, Wo, Cc = y.shape
+    _, Hi, Wi, Cin = x_in.shape
+    dsw = None
+    if ds_weight is not None:
+        dsw = ds_weight.detach().reshape(Cc, Cin).t().contiguous().to(dev, torch.float32)
+        ds_scale, ds_shift = _need_cuda(ds_scale, "ds_scale"), _need_cuda(ds_shift, "ds_shift")
+    out = torch.empty_like(y)
+    L.check(lib.eg_se_residual_relu(_ptr(y), _ptr(gate), _ptr(x_in), _ptr(dsw), _ptr(ds_scale), _ptr(ds_shift), _ptr(out), B, Ho, Wo,
+                                    Cc, Hi, Wi, Cin, stride, _stream(dev)), "eg_se_residual_relu")
+    return out
+
+
+def linear(x, weight, bias=None, res1=None, res2=None, relu=False, a_shift=0, a_seq=0, precision="f32", packed=None):
+    """y = epi(x @ weight.T): x [M,K] (row-major, K%4==0), weight nn.Linear [N,K]."""
+    lib = L.load()
+    x = _need_cuda(x, "x")
+    dev = x.device
+    M, K = x.shape
+    N = weight.shape[0]
+    wp, npad, kpad = packed if packed is not None else pack_linear_weight(weight, dev)
+    bias_p = _padvec(bias, npad, dev)
+    y = torch.empty(M, N, device=dev)
+    r1 = _need_cuda(res1, "res1") if res1 is not None else None
+    r2 = _need_cuda(res2, "res2") if res2 is not None else None
+    L.check(lib.eg_linear(_ptr(x), K, _ptr(wp), kpad, _ptr(bias_p), _ptr(r1), _ptr(r2), N, _ptr(y), N, M, N, K, int(relu), a_shift,
+                          a_seq, L.precision_code(precision), _stream(dev)), "eg_linear")
+    return y
+
+
+def linear_splitk(x, weight, bias=None, relu=False, splits=8, precision="f32"):
+    lib = L.load()
+    x = _need_cuda(x, "x")
+    dev = x.device
+    M, K = x.shape
+    N = weight.shape[0]
+    wp, npad, kpad = pack_linear_weight(weight, dev)
+    bias_p = _padvec(bias, npad, dev)
+    y = torch.empty(M, N, device=dev)
+    part = torch.empty(splits + 1, M, N, device=dev)
+    L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(wp), kpad, _ptr(bias_p), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part),
+                                 L.precision_code(precision), _stream(dev)), "eg_linear_splitk")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-6):
+    lib = L.load()
+    x = _need_cuda(x, "x")
+    dev = x.device
+    rows, d = x.reshape(-1, x.shape[-1]).shape
+    y = torch.empty_like(x)
+    L.check(lib.eg_layernorm(_ptr(x), _ptr(_need_cuda(gamma, "gamma")), _ptr(_need_cuda(beta, "beta")), _ptr(y), rows, d, eps,
+                             _stream(dev)), "eg_layernorm")
+    return y
+
+
+def attention(q, k, v, heads: int, want_attn=False):
+    """q [B,Lq,H*64], k/v [B,Lk,H*64] -> out [B,Lq,H*64] (Full_model/Modules.py:13-23)."""
+    lib = L.load()
+    q, k, v = _need_cuda(q, "q"), _need_cuda(k, "k"), _need_cuda(v, "v")
+    dev = q.device
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    out = torch.empty_like(q)
+    attn = torch.empty(B, heads, Lq, Lk, device=dev) if want_attn else None
+    L.check(lib.eg_attention(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk, D // heads,
+                             _stream(dev)), "eg_attention")
+    return (out, attn) if want_attn else out
+
+
+def multi_head_attention(xq, xkv, wq, wk, wv, wo, ln_g, ln_b, heads: int, precision="f32", want_attn=True):
+    lib = L.load()
+    xq, xkv = _need_cuda(xq, "q"), _need_cuda(xkv, "kv")
+    dev = xq.device
+    B, Lq, D = xq.shape
+    Lk = xkv.shape[1]
+    packs = [pack_linear_weight(w, dev)[0] for w in (wq, wk, wv, wo)]
+    nbytes = lib.eg_mha_workspace_bytes(B, Lq, Lk, D)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(xq)
+    attn = torch.empty(B, heads, Lq, Lk, device=dev) if want_attn else None
+    L.check(lib.eg_multi_head_attention(_ptr(xq), _ptr(xkv), *[_ptr(p) for p in packs], _ptr(_need_cuda(ln_g, "g")),
+                                        _ptr(_need_cuda(ln_b, "b")), _ptr(out), _ptr(attn), B, Lq, Lk, D, heads,
+                                        L.precision_code(precision), _ptr(ws), nbytes, _stream(dev)), "eg_multi_head_attention")
+    return out, attn
+
+
+def positionwise_ffn(x, w1, b1, w2, b2, ln_g, ln_b, precision="f32"):
+    lib = L.load()
+    x = _need_cuda(x, "x")
+    dev = x.device
+    d = x.shape[-1]
+    rows = x.numel() // d
+    di = w1.shape[0]
+    p1, p2 = pack_linear_weight(w1, dev)[0], pack_linear_weight(w2, dev)[0]
+    nbytes = lib.eg_ffn_workspace_bytes(rows, d, di)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(x)
+    L.check(lib.eg_positionwise_ffn(_ptr(x), _ptr(p1), _ptr(_need_cuda(b1, "b1")), _ptr(p2), _ptr(_need_cuda(b2, "b2")),
+                                    _ptr(_need_cuda(ln_g, "g")), _ptr(_need_cuda(ln_b, "b")), _ptr(out), rows, d, di,
+                                    L.precision_code(precision), _ptr(ws), nbytes, _stream(dev)), "eg_positionwise_ffn")
+    return out
+
+
+def pack_tcn_weights(levels, device):
+    """levels: list of (v1, g1, b1, v2, g2, b2) weight-norm tensors per TemporalBlock (tcn.py:18-24)."""
+    chunks = []
+    for (v1, g1, b1, v2, g2, b2) in levels:
+        for v, g, b in ((v1, g1, b1), (v2, g2, b2)):
+            v, g = v.detach().cpu().float(), g.detach().cpu().float()
+            w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+            c = w.shape[0]
+            npad, cpad = (c + 15) // 16 * 16, (c + 7) // 8 * 8
+            for tap in range(2):
+                chunks.append(packing._pack_linear(w[:, :, tap].contiguous(), npad, cpad))
+            bb = np.zeros(npad, np.float32)
+            bb[:c] = b.detach().cpu().float().numpy()
+            chunks.append(bb)
+    return torch.from_numpy(np.concatenate(chunks)).to(device)
+
+
+def tcn_forward(x_blc, packed_w, levels: int, precision="f32"):
+    """x [B, L, C] channels-last -> [B, L, C] (Full_model/tcn.py:63)."""
+    lib = L.load()
+    x = _need_cuda(x_blc, "x")
+    dev = x.device
+    B, Ln, Cc = x.shape
+    cpad = (Cc + 7) // 8 * 8
+    xp = torch.zeros(B, Ln, cpad, device=dev)
+    xp[:, :, :Cc] = x
+    y = torch.zeros(B, Ln, cpad, device=dev)
+    ws = torch.empty(4 * B * Ln * cpad, dtype=torch.float32, device=dev)
+    L.check(lib.eg_tcn_forward(_ptr(xp), _ptr(packed_w), _ptr(y), B, Ln, Cc, levels, L.precision_code(precision), _ptr(ws),
+                               ws.numel() * 4, _stream(dev)), "eg_tcn_forward")
+    return y[:, :, :Cc].contiguous()
+
+
+def reparameterize(mu, logvar, eps):
+    lib = L.load()
+    mu, logvar, eps = _need_cuda(mu, "mu"), _need_cuda(logvar, "logvar"), _need_cuda(eps, "eps")
+    z = torch.empty_like(mu)
+    L.check(lib.eg_reparameterize(_ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream(mu.device)), "eg_reparameterize")
+    return z

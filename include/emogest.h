@@ -1,0 +1,283 @@
+/*
+ * emogest.h -- C ABI of libemogest_hip.so: the MI355X (gfx950) implementation of the
+ * EmotionGesture audio->gesture hot path.
+ *
+ * The reference (XingqunQi-lab/EmotionGestures) is pure Python/PyTorch and has no FFI; the
+ * boundary it exposes for this path is the nn.Module surface used by
+ * test_emotion_gesture_diversity_iterative.py:25-30,135-174,203-205.  Each entry point below
+ * names the reference function it replaces (paths relative to the upstream repo).  The Python
+ * host mirror (emotiongestures_amd.Full_model.*, emotiongestures_amd.CAVE.*) binds these with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Contract (all entry points):
+ *   - plain C types only; every pointer named "d_*"/"arena"/"workspace" or documented as
+ *     device memory is a HIP device pointer owned by the CALLER (PyTorch's caching allocator
+ *     in the host mirror).  The library never allocates, frees or copies device memory behind
+ *     the caller's back and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing touches
+ *     the default stream.
+ *   - return value: EG_OK (0) or a negative EgStatus; HIP launch errors are surfaced as
+ *     EG_ERR_HIP.  No exceptions cross the ABI.  eg_last_error() gives a thread-local message.
+ *   - stateless and re-entrant: EgGenerator / EgCvae handles are immutable host-side plans
+ *     (offset tables); they hold no device memory and may be shared by threads.
+ *   - activations are fp32 in HBM.  Convolution activations are NHWC inside the library; every
+ *     tensor crossing this ABI uses the reference's own layout (stated per function).
+ */
+#ifndef EMOGEST_H
+#define EMOGEST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum EgStatus {
+    EG_OK = 0,
+    EG_ERR_BAD_ARG = -1,        /* null pointer, negative size, inconsistent shape */
+    EG_ERR_UNSUPPORTED = -2,    /* shape / channel count the kernels are not built for */
+    EG_ERR_WORKSPACE = -3,      /* workspace too small (see *_workspace_bytes) */
+    EG_ERR_HIP = -4,            /* hipGetLastError() != hipSuccess after a launch */
+    EG_ERR_ALIGN = -5           /* pointer or leading dimension not 16-byte aligned */
+} EgStatus;
+
+/* Arithmetic mode of the contraction kernels (conv / GEMM).  Storage is fp32 in both. */
+typedef enum EgPrecision {
+    EG_PREC_F32 = 0,            /* v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate */
+    EG_PREC_BF16X3 = 1,         /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 */
+    EG_PREC_BF16 = 2            /* single bf16 product (fast mode; not parity-grade) */
+} EgPrecision;
+
+const char* eg_last_error(void);
+const char* eg_version(void);
+/* Process-wide default for the contraction kernels (EgPrecision).  Per-call structs below
+ * carry their own field; this only seeds eg_*_default_config. */
+int eg_set_default_precision(int precision);
+int eg_get_default_precision(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight arena.  A model's parameters live in ONE caller-owned fp32 device buffer ("arena")
+ * in kernel-ready layouts.  The library is authoritative for the layout: it publishes a
+ * manifest (one entry per packed tensor) naming the reference state_dict key(s) each entry is
+ * built from and the packing rule; the host packs on the CPU once per load_state_dict and
+ * uploads.  Offsets and sizes are in floats.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum EgPackKind {
+    EG_PACK_RAW = 0,            /* tensor copied as is (row-major) */
+    EG_PACK_LINEAR = 1,         /* nn.Linear weight [N,K] -> [Npad,Kpad] zero padded (dims = N,K,Npad,Kpad) */
+    EG_PACK_VEC_PAD = 2,        /* 1-D tensor zero padded to dims[1] (dims = n, npad) */
+    EG_PACK_CONV3X3 = 3,        /* Conv2d OIHW [O,I,3,3] -> [tap][I/4][Opad][4] (dims = O,I,Opad) */
+    EG_PACK_BN_SCALE = 4,       /* key = BN prefix: weight/sqrt(running_var+eps), padded to dims[1] with 0 */
+    EG_PACK_BN_SHIFT = 5,       /* key = BN prefix: bias - running_mean*scale, padded to dims[1] with 0 */
+    EG_PACK_CONV1X1 = 6,        /* Conv2d [O,I,1,1] -> [I][O] */
+    EG_PACK_STEM = 7,           /* Conv2d [O,1,3,3] -> [9][O] */
+    EG_PACK_WN_TAP = 8,         /* key = weight-norm conv prefix (weight_g, weight_v [O,I,k]); tap dims[2] of
+                                   g*v/||v|| as [O,Ipad] (dims = O,I,tap,Ipad) */
+    EG_PACK_CONV1D = 9,         /* Conv1d [O,I,k] -> [O][I][k] raw (alias of RAW, kept for readability) */
+    EG_PACK_POS_TABLE = 10,     /* buffer [1,n_position,D] -> first dims[0] rows [frames,D] */
+    EG_PACK_LINEAR_T = 11       /* nn.Linear weight [N,K] -> transposed [K,N] */
+} EgPackKind;
+
+typedef struct EgWeightEntry {
+    char key[192];              /* reference state_dict key (or module prefix for BN / weight-norm kinds) */
+    int32_t kind;               /* EgPackKind */
+    int32_t dims[4];
+    int64_t offset;             /* floats from arena base; 64-byte aligned */
+    int64_t numel;              /* packed size in floats */
+} EgWeightEntry;
+
+/* ------------------------------------------------------------------------------------------
+ * Generator = Transformer (Full_model/Models_spatial_memory.py:471-616, Full_model/Models_memory.py:426-565)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct EgGeneratorConfig {
+    int32_t frames;             /* Transformer(frames=...)       :475 */
+    int32_t pose_dim;           /* pose_dim                       :475 */
+    int32_t prior_frames;       /* prior_frames                   :475 */
+    int32_t chunk;              /* args.chunk                     :263 */
+    int32_t d_model;            /* must be 512-class: multiple of 64 */
+    int32_t d_inner;
+    int32_t n_layers;
+    int32_t n_head;
+    int32_t d_k;                /* == d_v */
+    int32_t n_mels;             /* spectrogram rows (128) */
+    int32_t spec_len;           /* spectrogram columns (124 for 4 s) */
+    int32_t text_len;           /* 60 (Linear(60,60), :164-166) */
+    int32_t n_words;            /* lang_model.n_words */
+    int32_t embed_dim;          /* args.wordembed_dim (300) */
+    int32_t tcn_hidden;         /* args.hidden_size (300) */
+    int32_t tcn_layers;         /* args.n_layers (3) */
+    int32_t variant;            /* 0 = Models_spatial_memory (SP_v2 no-op), 1 = Models_memory (SP_v1 + TM) */
+    int32_t precision;          /* EgPrecision */
+    int32_t n_position;         /* rows of the positional table held in the checkpoint (>= frames) */
+    int32_t reserved[5];
+} EgGeneratorConfig;
+
+typedef struct EgGenerator EgGenerator;
+
+int eg_generator_default_config(EgGeneratorConfig* cfg);          /* TED: 34/126/4, spec 128x124 */
+int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** out);
+void eg_generator_destroy(EgGenerator* g);
+int64_t eg_generator_arena_floats(const EgGenerator* g);
+int32_t eg_generator_num_weights(const EgGenerator* g);
+int eg_generator_weight_entry(const EgGenerator* g, int32_t index, EgWeightEntry* out);
+int64_t eg_generator_workspace_bytes(const EgGenerator* g, int32_t batch);
+
+/* Transformer.forward (Models_spatial_memory.py:566-616 / Models_memory.py:521-565), eval mode.
+ *   spec      [B, n_mels, spec_len] fp32 (dB)           text  [B, text_len] int64
+ *   prior     [B, prior_frames, pose_dim]               sampled [B, frames, d_model] or NULL
+ * outputs (any may be NULL to skip the copy-out; the computation is still performed):
+ *   pose [B, frames, pose_dim]   emotion_feature, semantic_feature [B, frames, d_model]
+ *   emotion_prediction [B, 8]    text_embedding [B, text_len, 512]                      */
+int eg_generator_forward(const EgGenerator* g, const float* arena, int32_t batch,
+                         const float* spec, const int64_t* text, const float* prior, const float* sampled,
+                         float* pose, float* emotion_feature, float* semantic_feature,
+                         float* emotion_prediction, float* text_embedding,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Diversity sampling (BASELINE config 5): the audio/semantic tower is run once per clip, then
+ * fusion -> encoder -> decoder -> post_projector for `draws` sampled emotion maps per clip.
+ *   sampled [B, draws, frames, d_model]    pose [B, draws, frames, pose_dim]               */
+int eg_generator_forward_draws(const EgGenerator* g, const float* arena, int32_t batch, int32_t draws,
+                               const float* spec, const float* prior, const float* sampled, float* pose,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+int64_t eg_generator_draws_workspace_bytes(const EgGenerator* g, int32_t batch, int32_t draws);
+
+/* Intermediate taps of the most recent eg_generator_forward on this workspace (for parity tests):
+ * returns the device pointer inside `workspace` and the element count; names: "stem", "layer1",
+ * "layer2", "layer3" (NHWC), "audio_feat", "prior_enc", "fusion", "enc_out", "dec_out". */
+int eg_generator_tap(const EgGenerator* g, int32_t batch, void* workspace, const char* name,
+                     float** d_ptr, int64_t* numel);
+
+/* ------------------------------------------------------------------------------------------
+ * Emotion CVAE = MLP_Reconstruct_v3 (CAVE/BEAT_CVAE.py:312-460)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct EgCvaeConfig {
+    int32_t frames;             /* decoder output channels; 60 hard-coded upstream (:365-368) */
+    int32_t d_model;            /* 512 = 4 * latent map width 128 (:445) */
+    int32_t latent;             /* 32 */
+    int32_t n_classes;          /* 8 */
+    int32_t reserved[4];
+} EgCvaeConfig;
+typedef struct EgCvae EgCvae;
+
+int eg_cvae_default_config(EgCvaeConfig* cfg);
+int eg_cvae_create(const EgCvaeConfig* cfg, EgCvae** out);
+void eg_cvae_destroy(EgCvae* c);
+int64_t eg_cvae_arena_floats(const EgCvae* c);
+int32_t eg_cvae_num_weights(const EgCvae* c);
+int eg_cvae_weight_entry(const EgCvae* c, int32_t index, EgWeightEntry* out);
+int64_t eg_cvae_workspace_bytes(const EgCvae* c, int32_t n);
+
+/* MLP_Reconstruct_v3.sample (:427-447).  y [n, 8] one-hot, z [n, 32] latent draw (the host draws it
+ * with torch.randn on the CPU generator exactly as :441 does) -> out [n, frames, d_model]. */
+int eg_cvae_sample(const EgCvae* c, const float* arena, int32_t n, const float* y, const float* z,
+                   float* out, void* workspace, int64_t workspace_bytes, void* stream);
+/* MLP_Reconstruct_v3.forward (:403-424), eval-mode BN.  x [n, frames, d_model], y [n,8], eps [n,32]
+ * (reparameterize :389-399: z = eps*exp(0.5*logvar)+mu) -> recon [n, frames, d_model], mu, logvar [n,32]. */
+int eg_cvae_forward(const EgCvae* c, const float* arena, int32_t n, const float* x, const float* y,
+                    const float* eps, float* recon, float* mu, float* logvar,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Mel front-end = extract_melspectrogram (utils/train_utils_BEAT.py:186-190) + the loader's
+ * column slice (data_loader/lmdb_loader_BEAT_full.py:229)
+ * ------------------------------------------------------------------------------------------ */
+/* audio [B, n_samples] fp32 16 kHz -> spec [B, 128, out_frames] fp32 holding fp16-rounded dB.
+ * n_fft 1024, hop 512, centred (zero pad), periodic Hann, 128 Slaney mels, power_to_db(ref=max, top_db=80).
+ * d_melfb [128, 513] and d_window [1024] are caller-provided tables (eg_mel_tables fills host copies).
+ * workspace >= eg_mel_workspace_bytes. */
+int eg_mel_tables(float* h_melfb /*128*513*/, float* h_window /*1024*/, float* h_twiddle /*2*512*/);
+int64_t eg_mel_workspace_bytes(int32_t batch, int32_t n_samples);
+int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_samples, const float* d_melfb,
+                      const float* d_window, const float* d_twiddle, float* spec, int32_t out_frames,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Block-level operators (the reference's L2 blocks), used by the module-level mirrors and by the
+ * per-kernel parity tests.  Weights here are passed as individual device pointers in the PACKED
+ * layouts named above.
+ * ------------------------------------------------------------------------------------------ */
+
+/* nn.Conv2d 3x3 pad 1 (Full_model/ResNetBlocks.py:12,14; ResNetSE34V2.py:21) on NHWC fp32 with the
+ * fused epilogue  v = acc + bias[c]; if relu: v = max(v,0); v = v*scale[c] + shift[c].
+ *   x [B,H,W,Cin]   w EG_PACK_CONV3X3   bias/scale/shift [Cout_pad] (NULL = 0/1/0)
+ *   y NHWC [B,Ho,Wo,Cout] or, if nchw_out, [B,Cout,Ho*Wo]
+ *   gap_partial (optional) [B, eg_conv3x3_gap_tiles(...), Cout]: per-tile channel sums of y (for SE). */
+int eg_conv3x3(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+               float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
+               int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
+int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride);
+
+/* Stem: Conv2d(1->C,3x3,bias) -> ReLU -> BN (ResNetSE34V2.py:64-66).  x [B,H,W], y NHWC [B,H,W,C]. */
+int eg_stem_conv(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift,
+                 float* y, int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream);
+
+/* SELayer gate (ResNetBlocks.py:92-96): s[b,c] = sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2) from the
+ * per-tile sums written by eg_conv3x3.  w1 [C/8,C], w2 [C,C/8] raw nn.Linear layouts. */
+int eg_se_gate(const float* gap_partial, int32_t tiles, const float* w1, const float* b1, const float* w2,
+               const float* b2, float* gate, int32_t batch, int32_t c, int32_t hw, void* stream);
+
+/* SEBasicBlock tail (ResNetBlocks.py:28-36): out = relu(y*gate[b,c] + residual), residual = x_in or,
+ * for the first block of a stage, BN(conv1x1_stride(x_in)) (ResNetSE34V2.py:43-47).
+ *   y,out [B,Ho,Wo,C]; x_in [B,H,W,Cin]; ds_w EG_PACK_CONV1X1 or NULL. */
+int eg_se_residual_relu(const float* y, const float* gate, const float* x_in, const float* ds_w,
+                        const float* ds_scale, const float* ds_shift, float* out, int32_t batch, int32_t ho,
+                        int32_t wo, int32_t c, int32_t h_in, int32_t w_in, int32_t cin, int32_t stride, void* stream);
+
+/* nn.Linear family: Y[M,N] = epi(X[M,K] . W[N,K]^T).
+ *   v = acc + bias[n] + res1[m,n];  if relu: v = max(v,0);  if res2: v = max(v + res2[m,n], 0)
+ * lda/ldw/ldc/ldr in floats; K, lda, ldw multiples of 4 and X, W 16-byte aligned.
+ * a_shift/a_seq implement the causal dilated tap of Full_model/tcn.py:18-24: source row of output row m is
+ * m - a_shift, taken as zero when (m % a_seq) < a_shift (a_shift = 0 disables). */
+int eg_linear(const float* x, int32_t lda, const float* w, int32_t ldw, const float* bias,
+              const float* res1, const float* res2, int32_t ldr, float* y, int32_t ldc,
+              int32_t m, int32_t n, int32_t k, int32_t relu, int32_t a_shift, int32_t a_seq,
+              int32_t precision, void* stream);
+/* Split-K variant for tall-K, short-M products (emotion_classifer_header.0: K = frames*d_model,
+ * Models_spatial_memory.py:500).  partial >= splits*M*N floats. */
+int eg_linear_splitk(const float* x, int32_t lda, const float* w, int32_t ldw, const float* bias, float* y,
+                     int32_t ldc, int32_t m, int32_t n, int32_t k, int32_t relu, int32_t splits,
+                     float* partial, int32_t precision, void* stream);
+
+/* nn.LayerNorm(D, eps) over the last axis (Full_model/SubLayers.py:55-57,80-82).  rows x D, D%4==0, D<=2048. */
+int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
+                 float eps, void* stream);
+
+/* ScaledDotProductAttention (Full_model/Modules.py:13-23) for all heads, mask=None, eval mode:
+ * out[b,i,h*dv:(h+1)*dv] = softmax_j((q[b,i,h]/sqrt(dk)) . k[b,j,h]) v[b,j,h].
+ * q [B,Lq,H*dk] (row stride ldq), k/v [B,Lk,H*dk] (ldk/ldv), out [B,Lq,H*dk] (ldo).  dk == 64.
+ * attn (optional) [B,H,Lq,Lk] receives the probabilities (the reference returns them). */
+int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
+                 float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
+                 int32_t dk, void* stream);
+
+/* MultiHeadAttention.forward (Full_model/SubLayers.py:30-59): LN(fc(attn(q Wq, k Wk, v Wv)) + q).
+ * xq [B*Lq, D], xkv [B*Lk, D]; wq/wk/wv/wo raw nn.Linear [D,D]; out [B*Lq, D].
+ * workspace >= eg_mha_workspace_bytes. */
+int64_t eg_mha_workspace_bytes(int32_t batch, int32_t lq, int32_t lk, int32_t d_model);
+int eg_multi_head_attention(const float* xq, const float* xkv, const float* wq, const float* wk, const float* wv,
+                            const float* wo, const float* ln_g, const float* ln_b, float* out, float* attn,
+                            int32_t batch, int32_t lq, int32_t lk, int32_t d_model, int32_t heads,
+                            int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* PositionwiseFeedForward.forward (Full_model/SubLayers.py:74-84): LN(w2 relu(w1 x + b1) + b2 + x). */
+int64_t eg_ffn_workspace_bytes(int32_t rows, int32_t d_model, int32_t d_inner);
+int eg_positionwise_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* ln_g, const float* ln_b, float* out, int32_t rows, int32_t d_model,
+                        int32_t d_inner, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* TemporalConvNet.forward (Full_model/tcn.py:63; TemporalBlock :43-47), channels-last:
+ * x, y [B, L, C]; per level i (dilation 2^i) two weight-normed causal convs k=2 + ReLU, residual, ReLU.
+ * w points at levels*2 convs, each {tap0 [C,Cpad], tap1 [C,Cpad], bias [C]} packed back to back
+ * (EG_PACK_WN_TAP x2 + RAW); Cpad = C rounded up to 4.  workspace >= 4*B*L*Cpad floats. */
+int eg_tcn_forward(const float* x, const float* w, float* y, int32_t batch, int32_t len, int32_t c,
+                   int32_t levels, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* VAE reparameterisation (CAVE/BEAT_CVAE.py:397-399): z = eps*exp(0.5*logvar) + mu, n elements. */
+int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMOGEST_H */

@@ -1,0 +1,418 @@
+"""CPU oracle for the EmotionGesture audio->gesture hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  The shipped path (``emotiongestures_amd``)
+never routes through it and fails loudly when the HIP library is missing.
+
+It is an independent, vectorised fp32 restatement (torch CPU functional ops + numpy) of the
+reference's eval-mode arithmetic.  Every function cites the reference file:line it follows
+(paths relative to the upstream repo).  It takes a flat ``state_dict``-style mapping with the
+reference's own key names, so the same synthetic weights drive the reference (when the golden
+vectors are generated, ``tests/golden/make_golden.py``), this oracle and the HIP path.
+
+Pinning: ``tests/test_oracle_golden.py`` checks this file against ``tests/golden/*.npz``, which
+were produced by importing and running the reference's own classes in the build container.
+Exception -- ``melspectrogram``: the reference delegates to librosa (utils/train_utils_BEAT.py:186-190),
+which is neither vendored, pinned nor installed here, and has no in-repo caller or test, so that
+one function is **parity unpinned**; it follows librosa's documented defaults (see its docstring).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Mapping[str, torch.Tensor]
+
+
+@dataclass
+class GenCfg:
+    """Constructor arguments of Transformer (Full_model/Models_spatial_memory.py:474-477) as
+    used by the eval script (test_emotion_gesture_diversity_iterative.py:135)."""
+    frames: int = 34
+    pose_dim: int = 126
+    prior_frames: int = 4
+    chunk: int = 4
+    d_model: int = 512
+    d_inner: int = 2048
+    n_layers: int = 3
+    n_head: int = 8
+    d_k: int = 64
+    d_v: int = 64
+    tcn_layers: int = 3          # args.n_layers
+    tcn_kernel: int = 2
+    variant: str = "spatial"     # "spatial" = Models_spatial_memory.py, "memory" = Models_memory.py
+
+
+# --------------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------------
+
+def _bn(sd: SD, p: str, x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """Eval-mode BatchNorm{1,2}d: running statistics, affine (torch default eps 1e-5)."""
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    inv = torch.rsqrt(sd[p + ".running_var"] + eps)
+    return (x - sd[p + ".running_mean"].view(shape)) * (inv * sd[p + ".weight"]).view(shape) \
+        + sd[p + ".bias"].view(shape)
+
+
+def _lin(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def _ln(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-6)
+
+
+# --------------------------------------------------------------------------------------------
+# a2-a4  audio tower
+# --------------------------------------------------------------------------------------------
+
+def se_basic_block(sd: SD, p: str, x: torch.Tensor, stride: int) -> torch.Tensor:
+    """SEBasicBlock.forward, Full_model/ResNetBlocks.py:21-37 (ReLU precedes bn1);
+    SELayer.forward :92-96."""
+    out = F.conv2d(x, sd[p + ".conv1.weight"], None, stride=stride, padding=1)
+    out = _bn(sd, p + ".bn1", F.relu(out))
+    out = _bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], None, padding=1))
+    y = out.mean(dim=(2, 3))
+    y = torch.sigmoid(_lin(sd, p + ".se.fc.2", F.relu(_lin(sd, p + ".se.fc.0", y))))
+    out = out * y[:, :, None, None]
+    if (p + ".downsample.0.weight") in sd:
+        res = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride=stride))
+    else:
+        res = x
+    return F.relu(out + res)
+
+
+def resnetse(sd: SD, p: str, x: torch.Tensor, layers=(3, 4, 6), taps: Optional[dict] = None) -> torch.Tensor:
+    """ResNetSE.forward, Full_model/ResNetSE34V2.py:62-74; _make_layer :40-55."""
+    x = _bn(sd, p + ".bn1", F.relu(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)))
+    if taps is not None:
+        taps["stem"] = x
+    for li, n in enumerate(layers):
+        for bi in range(n):
+            stride = 2 if (li > 0 and bi == 0) else 1
+            x = se_basic_block(sd, f"{p}.layer{li + 1}.{bi}", x, stride)
+        if taps is not None:
+            taps[f"layer{li + 1}"] = x
+    return x
+
+
+def audio_encoder(sd: SD, p: str, spec: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    """Audio_ResNetEncoder.forward, Full_model/Models_spatial_memory.py:118-133.
+    ``spec`` is [B,1,n_mels,T]; channel c of final_conv1 becomes time step c."""
+    x = resnetse(sd, p + ".feat_extractor", spec, taps=taps)
+    x = _bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".final_conv1.weight"], sd[p + ".final_conv1.bias"], padding=1))
+    b, f = x.shape[:2]
+    x = x.reshape(b, f, -1)
+    if taps is not None:
+        taps["audio_map"] = x
+    return _lin(sd, p + ".fc2", _lin(sd, p + ".fc1", x))
+
+
+# --------------------------------------------------------------------------------------------
+# a12  text branch
+# --------------------------------------------------------------------------------------------
+
+def weight_norm_weight(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||, norm over dims (1,2) per out channel
+    (Full_model/tcn.py:19-24)."""
+    return v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+
+
+def text_encoder_tcn(sd: SD, p: str, text: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
+    """TextEncoderTCN.forward, Full_model/Models_spatial_memory.py:171-179; TemporalBlock.forward
+    Full_model/tcn.py:43-47 (causal: pad d then chomp d from the right, :12,54-58)."""
+    x = F.embedding(text, sd[p + ".embedding.weight"]).transpose(1, 2)          # [B,300,L]
+    length = x.shape[-1]
+    for i in range(cfg.tcn_layers):
+        d = 2 ** i
+        pad = (cfg.tcn_kernel - 1) * d
+        q = f"{p}.tcn.network.{i}"
+        out = x
+        for c in ("conv1", "conv2"):
+            w = weight_norm_weight(sd[f"{q}.{c}.weight_v"], sd[f"{q}.{c}.weight_g"])
+            out = F.conv1d(out, w, sd[f"{q}.{c}.bias"], padding=pad, dilation=d)[:, :, :length]
+            out = F.relu(out)
+        if (q + ".downsample.weight") in sd:
+            res = F.conv1d(x, sd[q + ".downsample.weight"], sd[q + ".downsample.bias"])
+        else:
+            res = x
+        x = F.relu(out + res)
+    y = _lin(sd, p + ".fc1.0", x).transpose(1, 2)          # Linear over the time axis
+    return _lin(sd, p + ".decoder", y).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# a5  prior / memory encoder
+# --------------------------------------------------------------------------------------------
+
+def pred_conv(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """Prior_MemoryEncoder.pred_conv, Full_model/Models_spatial_memory.py:366-373: the prior frames
+    are the conv *channels*, the pose_dim axis is the conv length."""
+    y = _bn(sd, p + ".2", F.relu(F.conv1d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], padding=1)))
+    return _bn(sd, p + ".5", F.relu(F.conv1d(y, sd[p + ".3.weight"], sd[p + ".3.bias"], padding=1)))
+
+
+def sp_memory_v1(sd: SD, p: str, initial: torch.Tensor, pred: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
+    """SP_Memory_Net_v1.forward, Full_model/Models_memory.py:233-251, vectorised: the per-(b,c)
+    torch.mm of a [1,D] by a [D,1] is an inner product."""
+    b = initial.shape[0]
+    mem = initial[:, cfg.prior_frames - cfg.chunk:, :].reshape(b, -1)
+    mem = _lin(sd, p + ".spatial_chunk_encoder.2", _lin(sd, p + ".spatial_chunk_encoder.0", mem))   # [B,D]
+    head = pred[:, :cfg.chunk, :]
+    s = torch.sigmoid((head * mem[:, None, :]).sum(-1, keepdim=True))
+    out = pred.clone()
+    out[:, :cfg.chunk, :] = s * head + (1 - s) * mem[:, None, :]
+    return out
+
+
+def tm_memory(sd: SD, p: str, initial: torch.Tensor, pred: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
+    """TM_Memory_Net.forward, Full_model/Models_memory.py:282-293.  NB: the two torch.mm calls
+    contract over the *batch* axis (:288-289), so clips in one batch are coupled."""
+    b = initial.shape[0]
+    mem = initial[:, cfg.prior_frames - cfg.chunk:, :].reshape(b, -1)
+    mem = _lin(sd, p + ".temporal_chunk_encoder.2", _lin(sd, p + ".temporal_chunk_encoder.0", mem))     # [B,D]
+    pe = pred[:, :cfg.chunk, :].reshape(b, -1)
+    pe = _lin(sd, p + ".temporal_memory_encoder.2", _lin(sd, p + ".temporal_memory_encoder.0", pe))     # [B,chunk]
+    score = mem @ (mem.t() @ pe)
+    w = torch.softmax(score, dim=1)
+    out = pred.clone()
+    head = pred[:, :cfg.chunk, :]
+    out[:, :cfg.chunk, :] = head + head * w[:, :, None]
+    return out
+
+
+def prior_memory_encoder(sd: SD, p: str, prior: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
+    """Prior_MemoryEncoder.forward: Full_model/Models_spatial_memory.py:378-390 (SP_Memory_Net_v2
+    :276-295 returns its input unchanged -- its writes go to a clone) and
+    Full_model/Models_memory.py:336-346 (SP_v1 then TM)."""
+    pred = pred_conv(sd, p + ".pred_conv", prior)
+    if cfg.variant == "memory":
+        pred = sp_memory_v1(sd, p + ".spatial_memory", prior, pred, cfg)
+        pred = tm_memory(sd, p + ".temporal_memory", prior, pred, cfg)
+    out = torch.cat((prior, pred), 1)
+    return _lin(sd, p + ".post_header.2", _lin(sd, p + ".post_header.0", out))
+
+
+# --------------------------------------------------------------------------------------------
+# a7-a10  transformer
+# --------------------------------------------------------------------------------------------
+
+def multi_head_attention(sd: SD, p: str, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cfg: GenCfg):
+    """MultiHeadAttention.forward, Full_model/SubLayers.py:30-59; ScaledDotProductAttention.forward,
+    Full_model/Modules.py:13-23 (q is divided by sqrt(d_k) before the product; mask is None)."""
+    b, lq, lk = q.shape[0], q.shape[1], k.shape[1]
+    h, dk, dv = cfg.n_head, cfg.d_k, cfg.d_v
+    residual = q
+    qh = F.linear(q, sd[p + ".w_qs.weight"]).view(b, lq, h, dk).transpose(1, 2)
+    kh = F.linear(k, sd[p + ".w_ks.weight"]).view(b, lk, h, dk).transpose(1, 2)
+    vh = F.linear(v, sd[p + ".w_vs.weight"]).view(b, lk, h, dv).transpose(1, 2)
+    attn = torch.softmax(torch.matmul(qh / (dk ** 0.5), kh.transpose(2, 3)), dim=-1)
+    o = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(b, lq, -1)
+    o = F.linear(o, sd[p + ".fc.weight"]) + residual
+    return _ln(sd, p + ".layer_norm", o), attn
+
+
+def positionwise_ffn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """PositionwiseFeedForward.forward, Full_model/SubLayers.py:74-84."""
+    return _ln(sd, p + ".layer_norm", _lin(sd, p + ".w_2", F.relu(_lin(sd, p + ".w_1", x))) + x)
+
+
+def encoder(sd: SD, p: str, x: torch.Tensor, cfg: GenCfg, taps: Optional[dict] = None, tag: str = "enc") -> torch.Tensor:
+    """Encoder.forward, Full_model/Models_spatial_memory.py:413-436; PositionalEncoding.forward :46-48;
+    EncoderLayer.forward Full_model/Layers.py:18-22."""
+    x = x + sd[p + ".position_enc.pos_table"][:, :x.shape[1]]
+    for l in range(cfg.n_layers):
+        q = f"{p}.layer_stack.{l}"
+        x, _ = multi_head_attention(sd, q + ".slf_attn", x, x, x, cfg)
+        x = positionwise_ffn(sd, q + ".pos_ffn", x)
+        if taps is not None:
+            taps[f"{tag}{l}"] = x
+    return x
+
+
+def decoder(sd: SD, p: str, trg: torch.Tensor, enc_out: torch.Tensor, cfg: GenCfg, taps: Optional[dict] = None) -> torch.Tensor:
+    """Decoder.forward, Full_model/Models_spatial_memory.py:455-469; DecoderLayer.forward
+    Full_model/Layers.py:50-58 (cross-attention + FFN only; no positional encoding)."""
+    x = trg
+    for l in range(cfg.n_layers):
+        q = f"{p}.layer_stack.{l}"
+        x, _ = multi_head_attention(sd, q + ".enc_attn", x, enc_out, enc_out, cfg)
+        x = positionwise_ffn(sd, q + ".pos_ffn", x)
+        if taps is not None:
+            taps[f"dec{l}"] = x
+    return x
+
+
+# --------------------------------------------------------------------------------------------
+# a13  generator wiring
+# --------------------------------------------------------------------------------------------
+
+def generator_forward(sd: SD, cfg: GenCfg, spec: torch.Tensor, text: torch.Tensor, prior: torch.Tensor,
+                      sampled: Optional[torch.Tensor] = None, taps: Optional[dict] = None):
+    """Transformer.forward, Full_model/Models_spatial_memory.py:566-616 (Models_memory.py:521-565).
+    Returns (pose, emotion_feature, semantic_feature, emotion_prediction, text_embedding)."""
+    text_embedding = text_encoder_tcn(sd, "text_encoder", text, cfg)
+    feat = audio_encoder(sd, "audio_encoder", spec.unsqueeze(1), taps=taps)
+    pr = prior_memory_encoder(sd, "prior_seq_encoder", prior, cfg)
+    emo = _lin(sd, "emotion_proj.2", _lin(sd, "emotion_proj.0", feat))
+    sem = _lin(sd, "semantic_proj.2", _lin(sd, "semantic_proj.0", feat))
+    h = emo.reshape(emo.shape[0], -1)
+    for i in (0, 2, 4):
+        h = F.relu(_lin(sd, f"emotion_classifer_header.{i}", h))
+    emo_pred = _lin(sd, "emotion_classifer_header.6", h)
+    fusion = (sampled if sampled is not None else emo) + sem
+    fusion = _lin(sd, "fusion_proj.2", F.relu(_lin(sd, "fusion_proj.0", fusion)))
+    enc = encoder(sd, "encoder", fusion, cfg, taps=taps)
+    dec = decoder(sd, "decoder", pr, enc, cfg, taps=taps)
+    pose = dec
+    for i in (0, 2, 4, 6):
+        pose = _lin(sd, f"post_projector.{i}", pose)
+    if taps is not None:
+        taps.update(audio_feat=feat, prior_enc=pr, fusion=fusion)
+    return pose, emo, sem, emo_pred, text_embedding
+
+
+# --------------------------------------------------------------------------------------------
+# a14  emotion CVAE (v3)
+# --------------------------------------------------------------------------------------------
+
+def _lrelu_bn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return _bn(sd, p, F.leaky_relu(x, 0.2))
+
+
+def cvae_decode(sd: SD, zy: torch.Tensor) -> torch.Tensor:
+    """fusion_z_posterior + Decoder, CAVE/BEAT_CVAE.py:355-369,377-381,444-446."""
+    n = zy.shape[0]
+    z = _lin(sd, "fusion_z_posterior.2", _lin(sd, "fusion_z_posterior.0", zy)).reshape(n, 4, 128)
+    x = F.conv_transpose1d(z, sd["Decoder.0.weight"], sd["Decoder.0.bias"], stride=2, padding=1, output_padding=1)
+    x = _lrelu_bn(sd, "Decoder.2", x)
+    x = F.conv_transpose1d(x, sd["Decoder.3.weight"], sd["Decoder.3.bias"], stride=2, padding=1, output_padding=1)
+    x = _lrelu_bn(sd, "Decoder.5", x)
+    x = _lrelu_bn(sd, "Decoder.8", F.conv1d(x, sd["Decoder.6.weight"], sd["Decoder.6.bias"], padding=1))
+    x = _lrelu_bn(sd, "Decoder.11", F.conv1d(x, sd["Decoder.9.weight"], sd["Decoder.9.bias"], padding=1))
+    return F.conv1d(x, sd["Decoder.12.weight"], sd["Decoder.12.bias"], padding=1)
+
+
+def cvae_sample(sd: SD, y: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """MLP_Reconstruct_v3.sample, CAVE/BEAT_CVAE.py:427-447, with the latent draw ``z`` made an
+    explicit argument (the reference draws torch.randn(n,32) on the CPU generator, :441)."""
+    post_y = _lin(sd, "Posterior_Y_embedding.2", _lin(sd, "Posterior_Y_embedding.0", y))
+    return cvae_decode(sd, torch.cat([z, post_y], dim=1))
+
+
+def cvae_encode(sd: SD, x: torch.Tensor):
+    """Encoder + fc_mu / fc_var, CAVE/BEAT_CVAE.py:318-332,344-353,408-412."""
+    h = _lrelu_bn(sd, "Encoder.2", F.conv1d(x, sd["Encoder.0.weight"], sd["Encoder.0.bias"], padding=1))
+    h = _lrelu_bn(sd, "Encoder.5", F.conv1d(h, sd["Encoder.3.weight"], sd["Encoder.3.bias"], padding=1))
+    h = _lrelu_bn(sd, "Encoder.8", F.conv1d(h, sd["Encoder.6.weight"], sd["Encoder.6.bias"], stride=2, padding=2))
+    h = _lrelu_bn(sd, "Encoder.11", F.conv1d(h, sd["Encoder.9.weight"], sd["Encoder.9.bias"], stride=2, padding=2))
+    h = h.reshape(x.shape[0], -1)
+    mu = _lin(sd, "fc_mu.2", _lin(sd, "fc_mu.0", h))
+    logvar = _lin(sd, "fc_var.2", _lin(sd, "fc_var.0", h))
+    return mu, logvar
+
+
+def cvae_forward(sd: SD, x: torch.Tensor, y: torch.Tensor, eps: torch.Tensor):
+    """MLP_Reconstruct_v3.forward, CAVE/BEAT_CVAE.py:403-424; reparameterize :389-399 with the
+    noise ``eps`` explicit."""
+    mu, logvar = cvae_encode(sd, x)
+    z = eps * torch.exp(0.5 * logvar) + mu
+    post_y = _lin(sd, "Posterior_Y_embedding.2", _lin(sd, "Posterior_Y_embedding.0", y))
+    return cvae_decode(sd, torch.cat([z, post_y], dim=1)), mu, logvar
+
+
+# --------------------------------------------------------------------------------------------
+# a1  mel front-end  (PARITY UNPINNED: librosa is an un-vendored, un-pinned dependency)
+# --------------------------------------------------------------------------------------------
+
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log_t = min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, log_t, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr: int = 16000, n_fft: int = 1024, n_mels: int = 128) -> np.ndarray:
+    """librosa.filters.mel defaults: fmin 0, fmax sr/2, htk=False (Slaney scale), norm='slaney'.
+    Returns float32 [n_mels, 1 + n_fft//2] like librosa (dtype=np.float32)."""
+    n_bins = 1 + n_fft // 2
+    fftfreqs = np.linspace(0.0, sr / 2.0, n_bins)
+    mel_pts = np.linspace(_hz_to_mel_slaney(0.0), _hz_to_mel_slaney(sr / 2.0), n_mels + 2)
+    hz = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(hz)
+    ramps = hz[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, n_bins), dtype=np.float64)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0.0, np.minimum(lower, upper))
+    enorm = 2.0 / (hz[2:n_mels + 2] - hz[:n_mels])
+    w *= enorm[:, None]
+    return w.astype(np.float32)
+
+
+def hann_periodic(n: int = 1024) -> np.ndarray:
+    """scipy.signal.get_window('hann', n, fftbins=True), as librosa.stft uses."""
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)).astype(np.float32)
+
+
+def melspectrogram(audio: np.ndarray, sr: int = 16000, n_fft: int = 1024, hop: int = 512,
+                   n_mels: int = 128, top_db: float = 80.0, out_frames: Optional[int] = None) -> np.ndarray:
+    """extract_melspectrogram, utils/train_utils_BEAT.py:186-190 = librosa.feature.melspectrogram(
+    n_fft=1024, hop_length=512, power=2) -> librosa.power_to_db(ref=np.max) -> float16, followed by
+    the loader's slice [:, :expected_len] (data_loader/lmdb_loader_BEAT_full.py:229).
+
+    librosa defaults restated: centred STFT, zero ("constant") padding of n_fft//2 each side
+    (librosa >= 0.10), periodic Hann window, 1 + len//hop frames; Slaney mel basis;
+    power_to_db: 10*log10(max(amin=1e-10, S)) - 10*log10(max(amin, max S)), floored at max - top_db.
+    ``audio`` is [B, n]; returns float32 holding fp16-rounded dB, [B, n_mels, frames]."""
+    audio = np.asarray(audio, dtype=np.float32)
+    b, n = audio.shape
+    pad = n_fft // 2
+    x = np.pad(audio.astype(np.float64), ((0, 0), (pad, pad)))
+    n_frames = 1 + n // hop
+    win = hann_periodic(n_fft).astype(np.float64)
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = x[:, idx] * win                                     # [B, frames, n_fft]
+    power = np.abs(np.fft.rfft(frames, axis=-1)) ** 2            # [B, frames, 513]
+    mel = np.einsum("mk,bfk->bmf", mel_filterbank(sr, n_fft, n_mels).astype(np.float64), power)
+    db = 10.0 * np.log10(np.maximum(1e-10, mel))
+    ref = np.maximum(1e-10, mel.reshape(b, -1).max(axis=1))
+    db -= 10.0 * np.log10(ref)[:, None, None]
+    db = np.maximum(db, db.reshape(b, -1).max(axis=1)[:, None, None] - top_db)
+    if out_frames is not None:
+        db = db[:, :, :out_frames]
+    return db.astype(np.float16).astype(np.float32)
+
+
+def spectrogram_length(n_frames: int, fps: float) -> int:
+    """calc_spectrogram_length_from_motion_length, utils/train_utils_BEAT.py:193-195."""
+    return int(round((n_frames / fps * 16000 - 1024) / 512 + 1))
+
+
+# --------------------------------------------------------------------------------------------
+# convenience
+# --------------------------------------------------------------------------------------------
+
+def to_torch_sd(sd_np: Mapping[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes on CPU.
+
+Run in the build container only (it needs /root/reference, which never ships):
+
+    python tests/golden/make_golden.py
+
+The reference is imported in place from /root/reference with empty stand-in modules for
+imports it never uses on this path (torch_dct, torchvision, umap, fasttext: SURVEY.md §8c).
+Weights and inputs come from emotiongestures_amd.synth (integer-hash, platform exact), so the
+golden files hold only inputs that are not re-derivable (none) and expected OUTPUTS.
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from emotiongestures_amd.synth import digest, load_synth_weights, synth_inputs  # noqa: E402
+
+
+def _stub_unused_imports():
+    for name in ("torch_dct", "torchvision", "torchvision.utils", "torchvision.transforms", "umap", "fasttext"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision.utils"].save_image = None      # imported, never called (CAVE/BEAT_CVAE.py:17)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+
+
+def _ref_generator(variant, frames, pose_dim, prior, chunk, n_words, seed):
+    _stub_unused_imports()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    if variant == "spatial":
+        from Full_model.Models_spatial_memory import Transformer
+    else:
+        from Full_model.Models_memory import Transformer
+    args = SimpleNamespace(chunk=chunk, hidden_size=300, n_layers=3, freeze_wordembed=False,
+                           wordembed_dim=300, dropout_prob=0.1)
+    lang = SimpleNamespace(n_words=n_words, word_embedding_weights=None)
+    m = Transformer(args, lang, frames=frames, pose_dim=pose_dim, prior_frames=prior, d_word_vec=512,
+                    d_model=512, d_inner=2048, n_layers=3, n_head=8, d_k=64, d_v=64)
+    load_synth_weights(m, seed)
+    return m.eval()
+
+
+def _flat(prefix, dig):
+    return {f"{prefix}/{k}": v for k, v in dig.items()}
+
+
+def generator_case(name, variant, batch, frames, pose_dim, prior, chunk, spec_len=124, n_words=200,
+                   seed=0, use_sampled=False):
+    m = _ref_generator(variant, frames, pose_dim, prior, chunk, n_words, seed)
+    inp = synth_inputs(batch, frames, pose_dim, prior, spec_len=spec_len, n_words=n_words, seed=seed)
+    taps = {}
+
+    def hook(tag):
+        def fn(_mod, _inp, out):
+            taps[tag] = (out[0] if isinstance(out, tuple) else out).detach()
+        return fn
+
+    fe = m.audio_encoder.feat_extractor
+    hs = [fe.bn1.register_forward_hook(hook("stem")), fe.layer1.register_forward_hook(hook("layer1")),
+          fe.layer2.register_forward_hook(hook("layer2")), fe.layer3.register_forward_hook(hook("layer3")),
+          m.audio_encoder.register_forward_hook(hook("audio_feat")),
+          m.prior_seq_encoder.register_forward_hook(hook("prior_enc")),
+          m.fusion_proj.register_forward_hook(hook("fusion"))]
+    for l in range(3):
+        hs.append(m.encoder.layer_stack[l].register_forward_hook(hook(f"enc{l}")))
+        hs.append(m.decoder.layer_stack[l].register_forward_hook(hook(f"dec{l}")))
+    with torch.no_grad():
+        sampled = torch.from_numpy(inp["sampled"]) if use_sampled else None
+        pose, emo, sem, emo_pred, text = m(torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                           torch.from_numpy(inp["pre_pose"]), sampled)
+    for h in hs:
+        h.remove()
+    out = {"pose": pose.numpy(), "emotion_prediction": emo_pred.numpy(),
+           "meta": np.asarray([batch, frames, pose_dim, prior, chunk, spec_len, n_words, seed,
+                               int(use_sampled)], dtype=np.int64)}
+    out.update(_flat("emotion_feature", digest(emo.numpy(), 8192)))
+    out.update(_flat("semantic_feature", digest(sem.numpy(), 8192)))
+    out.update(_flat("text_embedding", digest(text.numpy(), 8192)))
+    for k, v in taps.items():
+        out.update(_flat("tap_" + k, digest(v.numpy())))
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "pose L2/clip", np.linalg.norm(pose.numpy().reshape(batch, -1), axis=1),
+          os.path.getsize(path) // 1024, "KiB")
+
+
+def cvae_case(seed=0):
+    _stub_unused_imports()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    m = load_synth_weights(MLP_Reconstruct_v3(), seed).eval()
+    inp = synth_inputs(3, frames=60, seed=seed)
+    y, z = torch.from_numpy(inp["label"]), torch.from_numpy(inp["z"])
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: z.clone()          # sample() draws torch.randn(n, 32) (BEAT_CVAE.py:441)
+    try:
+        with torch.no_grad():
+            s = m.sample(y)
+    finally:
+        torch.randn = real_randn
+    x = torch.from_numpy(inp["sampled"])             # [3,60,512] stand-in feature map
+    eps = torch.from_numpy(synth_inputs(3, seed=seed + 1)["z"])
+    real_rl = torch.randn_like
+    torch.randn_like = lambda t, **k: eps.clone()    # reparameterize() (BEAT_CVAE.py:398)
+    try:
+        with torch.no_grad():
+            rec, mu, logvar = m(x, y)
+    finally:
+        torch.randn_like = real_rl
+    out = {"mu": mu.numpy(), "logvar": logvar.numpy(), "meta": np.asarray([3, seed], dtype=np.int64)}
+    out.update(_flat("sample", digest(s.numpy(), 16384)))
+    out.update(_flat("recon", digest(rec.numpy(), 16384)))
+    path = os.path.join(ROOT, "tests", "golden", "cvae_v3.npz")
+    np.savez_compressed(path, **out)
+    print("cvae_v3", s.shape, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cvae":
+        cvae_case()
+        sys.exit(0)
+    generator_case("ted_spatial_b2", "spatial", 2, 34, 126, 4, 4)
+    generator_case("ted_spatial_b2_sampled", "spatial", 2, 34, 126, 4, 4, use_sampled=True, seed=1)
+    generator_case("ted_memory_b4", "memory", 4, 34, 126, 4, 4, seed=2)
+    generator_case("ted_spatial_b5", "spatial", 5, 34, 126, 4, 4, seed=3)
+    generator_case("beat_spatial_b1", "spatial", 1, 60, 282, 10, 10, use_sampled=True, seed=4)
+    generator_case("beat_memory_b2", "memory", 2, 60, 282, 10, 10, seed=5)
+    cvae_case()

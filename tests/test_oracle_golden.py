@@ -1,0 +1,120 @@
+"""Pin the CPU oracle (oracle/emogest_oracle.py) against golden vectors produced by the reference's own
+classes (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GENERATOR_CASES, GOLDEN, build_mirror, clip_rel_l2, golden_meta, rel_l2
+from emotiongestures_amd.synth import digest, load_synth_weights, synth_inputs
+from oracle import emogest_oracle as O
+
+TOL = 2e-5      # fp32 reassociation between ATen/mkldnn module code and the functional restatement
+
+
+def _run_oracle(name, variant):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = golden_meta(z)
+    model = build_mirror(variant, m["frames"], m["pose_dim"], m["prior"], m["chunk"], m["n_words"], m["seed"], m["spec_len"])
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    inp = synth_inputs(m["batch"], m["frames"], m["pose_dim"], m["prior"], spec_len=m["spec_len"], n_words=m["n_words"], seed=m["seed"])
+    cfg = O.GenCfg(frames=m["frames"], pose_dim=m["pose_dim"], prior_frames=m["prior"], chunk=m["chunk"], variant=variant)
+    taps = {}
+    with torch.no_grad():
+        out = O.generator_forward(sd, cfg, torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                  torch.from_numpy(inp["pre_pose"]),
+                                  torch.from_numpy(inp["sampled"]) if m["use_sampled"] else None, taps=taps)
+    return z, out, taps
+
+
+@pytest.mark.parametrize("name,variant", sorted(GENERATOR_CASES.items()))
+def test_generator_oracle_matches_reference_golden(name, variant):
+    z, (pose, emo, sem, pred, text), taps = _run_oracle(name, variant)
+    assert pose.shape == z["pose"].shape
+    assert clip_rel_l2(pose.numpy(), z["pose"]) < TOL
+    assert rel_l2(pred.numpy(), z["emotion_prediction"]) < TOL
+    for key, t in (("emotion_feature", emo), ("semantic_feature", sem), ("text_embedding", text)):
+        d = digest(t.numpy(), 8192)
+        assert tuple(d["shape"]) == tuple(z[key + "/shape"])
+        assert rel_l2(d["sample"], z[key + "/sample"]) < TOL, key
+        assert abs(d["absmean"] - z[key + "/absmean"]) < TOL * max(1.0, z[key + "/absmean"])
+    for tap in ("stem", "layer1", "layer2", "layer3", "audio_feat", "prior_enc", "fusion", "enc0", "enc1", "enc2", "dec0", "dec1", "dec2"):
+        d = digest(taps[tap].numpy())
+        assert rel_l2(d["sample"], z[f"tap_{tap}/sample"]) < TOL, tap
+
+
+def test_tm_memory_couples_clips_across_the_batch():
+    """Full_model/Models_memory.py:288-289 contracts over the batch axis: the oracle must reproduce that
+    (SURVEY.md §4 probe 3), so clip 0 of a batch of 4 differs from clip 0 run alone at module level."""
+    model = build_mirror("memory", 34, 126, 4, 4, seed=2)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    cfg = O.GenCfg(variant="memory")
+    inp = synth_inputs(4, seed=2)
+    prior = torch.from_numpy(inp["pre_pose"])
+    pred = O.pred_conv(sd, "prior_seq_encoder.pred_conv", prior)
+    a = O.tm_memory(sd, "prior_seq_encoder.temporal_memory", prior, pred, cfg)[0]
+    b = O.tm_memory(sd, "prior_seq_encoder.temporal_memory", prior[:1], pred[:1], cfg)[0]
+    assert (a - b).abs().max() > 1e-6
+
+
+def test_sp_memory_v2_is_identity_on_the_output():
+    """Full_model/Models_spatial_memory.py:276-295 writes into a clone and returns its input: the spatial variant's
+    prior encoding must equal post_header(cat(prior, pred_conv(prior)))."""
+    model = build_mirror("spatial", 34, 126, 4, 4)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    inp = synth_inputs(2)
+    prior = torch.from_numpy(inp["pre_pose"])
+    out = O.prior_memory_encoder(sd, "prior_seq_encoder", prior, O.GenCfg())
+    cat = torch.cat((prior, O.pred_conv(sd, "prior_seq_encoder.pred_conv", prior)), 1)
+    ref = torch.nn.functional.linear(torch.nn.functional.linear(cat, sd["prior_seq_encoder.post_header.0.weight"], sd["prior_seq_encoder.post_header.0.bias"]),
+                                     sd["prior_seq_encoder.post_header.2.weight"], sd["prior_seq_encoder.post_header.2.bias"])
+    assert torch.equal(out, ref)
+
+
+def test_cvae_oracle_matches_reference_golden():
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    z = np.load(os.path.join(GOLDEN, "cvae_v3.npz"))
+    n, seed = [int(v) for v in z["meta"]]
+    m = load_synth_weights(MLP_Reconstruct_v3(), seed).eval()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    inp = synth_inputs(n, frames=60, seed=seed)
+    with torch.no_grad():
+        s = O.cvae_sample(sd, torch.from_numpy(inp["label"]), torch.from_numpy(inp["z"]))
+        eps = torch.from_numpy(synth_inputs(n, seed=seed + 1)["z"])
+        rec, mu, logvar = O.cvae_forward(sd, torch.from_numpy(inp["sampled"]), torch.from_numpy(inp["label"]), eps)
+    assert tuple(s.shape) == (n, 60, 512)
+    assert rel_l2(digest(s.numpy(), 16384)["sample"], z["sample/sample"]) < TOL
+    assert rel_l2(digest(rec.numpy(), 16384)["sample"], z["recon/sample"]) < TOL
+    assert rel_l2(mu.numpy(), z["mu"]) < TOL and rel_l2(logvar.numpy(), z["logvar"]) < TOL
+
+
+def test_state_dict_schema_matches_reference():
+    """Keys, shapes and ORDER of our mirrors' state_dicts equal the reference's (tests/golden/state_dict_schema.json,
+    dumped from the reference classes), so its checkpoints load with strict=True."""
+    import json
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    schema = json.load(open(os.path.join(GOLDEN, "state_dict_schema.json")))
+    for name, model in (("ted_spatial", build_mirror("spatial", 34, 126, 4, 4)), ("ted_memory", build_mirror("memory", 34, 126, 4, 4)),
+                        ("cvae_v3", MLP_Reconstruct_v3())):
+        mine = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        assert mine == schema[name], name
+
+
+def test_mel_oracle_properties():
+    """Mel front-end restatement (parity unpinned: librosa absent): shape, dB range, fp16 grid, ref=max -> 0 dB peak,
+    the -80 dB floor and frame count 1 + n//hop (utils/train_utils_BEAT.py:186-195)."""
+    from emotiongestures_amd.synth import synth_audio
+    a = synth_audio(2, 64000, seed=0)
+    s = O.melspectrogram(a, out_frames=124)
+    assert s.shape == (2, 128, 124) and s.dtype == np.float32
+    full = O.melspectrogram(a)
+    assert full.shape == (2, 128, 126)
+    assert np.all(full <= 0) and np.all(full >= -80.0)
+    assert np.allclose(full.reshape(2, -1).max(axis=1), 0.0)
+    assert np.array_equal(s, s.astype(np.float16).astype(np.float32))
+    assert O.spectrogram_length(34, 15) == 70 and O.spectrogram_length(60, 15) == 124
+    fb = O.mel_filterbank()
+    assert fb.shape == (128, 513) and fb.min() >= 0 and np.all(fb.sum(axis=1) > 0)
+    silent = O.melspectrogram(np.zeros((1, 16000), np.float32))
+    assert np.all(silent == 0.0)          # all-amin input: db == ref everywhere
