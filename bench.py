@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- gesture clips/sec of the EmotionGesture hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of 64 synthetic TED-shaped clips per GPU, inputs already
+resident in HBM:   16 kHz audio [64, 64000] -> HIP mel front-end -> spec [64,128,124]
+                   one-hot label + latent z -> HIP CVAE sample -> emotion map [64,34,512]
+                   (spec, text, prior poses, emotion map) -> HIP generator -> pose [64,34,126] (+ the 4 auxiliary returns)
+This is BASELINE.json configs[1] ("Batch=64 synthetic 16 kHz audio -> gesture inference, 1xMI355X").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f32|bf16x3|bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, clips sharded across ranks (weak scaling: 64 clips per GPU), no collective on the data
+path (clips are independent); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
+time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+FLOP_PER_CLIP = 9.235e9        # 2 x MACs of the TED generator forward (reference FlopCounterMode probe)
+MEL_FLOP_PER_CLIP = 0.023e9
+CVAE_FLOP_PER_CLIP = 0.0189e9 * 34 / 60
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peak of the MFMA dtype
+
+
+def build_models(precision, dev, seed=0):
+    from conftest import build_mirror
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.engine import MelFrontEnd
+    from emotiongestures_amd.synth import load_synth_weights
+    gen = build_mirror("spatial", 34, 126, 4, 4, seed=seed, precision=precision)
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), seed).eval()
+    sd_g = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    sd_v = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    gen.to(dev)
+    vae.to(dev)
+    return gen, vae, MelFrontEnd(dev), sd_g, sd_v
+
+
+def make_inputs(batch, seed):
+    from emotiongestures_amd.synth import synth_audio, synth_inputs
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    inp["audio"] = synth_audio(batch, 64000, seed=seed)
+    return inp
+
+
+def cpu_baseline(sd_g, sd_v, inp, budget_s=20.0):
+    """The CPU oracle (port of the reference's CPU path: same torch fp32 CPU kernels) on the same workload, all host cores."""
+    from oracle import emogest_oracle as O
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(16, inp["audio"].shape[0])
+    t = {k: torch.from_numpy(v[:n]) for k, v in inp.items() if k != "audio"}
+    audio = inp["audio"][:n]
+
+    def step():
+        with torch.no_grad():
+            spec = torch.from_numpy(O.melspectrogram(audio, out_frames=124))
+            sampled = O.cvae_sample(sd_v, t["label"], t["z"])
+            return O.generator_forward(sd_g, O.GenCfg(), spec, t["text"], t["pre_pose"], sampled)[0]
+
+    # pick the thread count that is fastest for this workload (more threads than the small convs can use only adds
+    # synchronisation cost on many-core hosts); `cores` reports the threads actually used
+    best, cores = None, 1
+    for th in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
+        torch.set_num_threads(th)
+        step()
+        t0 = time.perf_counter()
+        step()
+        el = time.perf_counter() - t0
+        if best is None or el < best:
+            best, cores = el, th
+        if el > 8.0:
+            break
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        step()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 40:
+            break
+    return {"value": round(n * iters / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} x B={n} passes of oracle mel+cvae_sample+generator_forward (torch fp32 CPU, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--precision", default=os.environ.get("EG_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from emotiongestures_amd import _lib
+    lib = _lib.load()
+    gen, vae, mel, sd_g, sd_v = build_models(args.precision, dev)
+    B = args.batch
+    inp = make_inputs(B, seed=1000 + rank)          # every rank generates its own shard of clips
+    g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+
+    def step():
+        with torch.no_grad():
+            spec = mel(g["audio"], out_frames=124)
+            sampled = vae.sample(g["label"], z=g["z"])
+            return gen(spec, g["text"], g["pre_pose"], sampled)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_clips = B * world * args.steps
+    value = total_clips / elapsed
+
+    # ---- parity spot check on this very batch (first 2 clips) against the CPU oracle ----
+    parity = None
+    roof = None
+    cpu = None
+    if rank == 0:
+        from conftest import clip_rel_l2
+        from oracle import emogest_oracle as O
+        with torch.no_grad():
+            t2 = {k: torch.from_numpy(v[:2]) for k, v in inp.items() if k != "audio"}
+            spec_ref = torch.from_numpy(O.melspectrogram(inp["audio"][:2], out_frames=124))
+            s_ref = O.cvae_sample(sd_v, t2["label"], t2["z"])
+            pose_ref = O.generator_forward(sd_g, O.GenCfg(), spec_ref, t2["text"], t2["pre_pose"], s_ref)[0]
+        parity = clip_rel_l2(out[0][:2].cpu().numpy(), pose_ref.numpy())
+
+    # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
+    if rank == 0 and not args.no_roofline:
+        cap = 400 * max(args.steps, 1)
+        _lib.check(lib.eg_profile_enable(cap), "eg_profile_enable")
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        lib.eg_profile_disable()
+        tags = np.zeros(cap, np.int64); fl = np.zeros(cap, np.float64); ms = np.zeros(cap, np.float32)
+        n = lib.eg_profile_read(tags.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), cap)
+        tags, fl, ms = tags[:n], fl[:n], ms[:n]
+        groups = {}
+        for tg in np.unique(tags):
+            sel = tags == tg
+            groups[int(tg)] = (float(ms[sel].sum()), float(ms[sel].mean()), float(fl[sel].mean()), int(sel.sum()))
+        dom = max(groups, key=lambda k: groups[k][0])
+        tot_ms, avg_ms, flop, cnt = groups[dom]
+        name = "gemm(all eg_linear launches)" if dom == 2 else f"conv3x3<cin={dom // 1000000},cout={(dom // 1000) % 1000},stride={(dom // 100) % 10}>"
+        achieved = flop / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        step_ms = elapsed / args.steps * 1e3
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_step": cnt // max(args.steps, 1), "share_of_step": round(tot_ms / args.steps / step_ms, 3),
+                "flop_per_launch": flop,
+                "by_kernel_ms_per_step": {str(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sd_g, sd_v, inp)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {
+            "metric": "gesture clips/sec (34 frames, 43 joints)", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "TED clips: 4 s 16 kHz audio -> mel(128x124) -> CVAE sample -> generator -> 34x126 pose",
+                       "clips_per_gpu_per_step": B, "global_batch": B * world, "variant": "Models_spatial_memory",
+                       "parallelism": f"clip-sharded x{world}, no data-path collective",
+                       "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
+            "pose_rel_l2_vs_cpu_oracle": parity, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,11 @@ SIGNATURES = {
     "eg_ffn_workspace_bytes": (_L, [_I, _I, _I]),
     "eg_positionwise_ffn": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "eg_tcn_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "eg_add_rows": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
+    "eg_conv3x3_packed_floats": (_L, [_I, _I]),
+    "eg_profile_enable": (C.c_int, [_I]),
+    "eg_profile_disable": (C.c_int, []),
+    "eg_profile_read": (_I, [_P, _P, _P, _I]),
     "eg_reparameterize": (C.c_int, [_P, _P, _P, _P, _L, _P]),
 }
 
@@ -98,6 +103,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64; loading ours before it would pull a second HIP runtime copy
+    # from /opt/rocm into the process ("no ROCm-capable device" on the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EgError(
             f"{LIB_PATH} not found: the HIP library has not been built. Run "

@@ -54,3 +54,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// ---- optional launch profiler (generator.hip) ----------------------------------------------------------------
+struct EgProfScope {
+    int slot;
+    hipStream_t st;
+    EgProfScope(int64_t tag, double flops, hipStream_t s);
+    ~EgProfScope();
+};

@@ -460,6 +460,8 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
     a.tiles = a.tiles_x * eg_cdiv(a.Ho, th);
     hipStream_t st = (hipStream_t)stream;
     const int coutp = (int)eg_round_up(cout, 16);
+    EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + stride * 100 + 1,
+                     2.0 * 9 * cin * cout * (double)a.Ho * a.Wo * batch, st);
     if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8>(a, batch, precision, st);
     if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2>(a, batch, precision, st);
     if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8>(a, batch, precision, st);

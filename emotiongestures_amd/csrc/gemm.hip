@@ -226,6 +226,7 @@ extern "C" int eg_linear(const float* x, int32_t lda, const float* w, int32_t ld
     EG_REQUIRE(a_shift == 0 || a_seq > 0, EG_ERR_BAD_ARG, "eg_linear: a_seq must be positive when a_shift is set");
     a.bias = bias; a.res1 = res1; a.res2 = res2; a.ldr = ldr; a.y = y; a.ldc = ldc; a.relu = relu;
     a.a_shift = a_shift; a.a_seq = a_seq > 0 ? a_seq : 1; a.k_per_split = (int)eg_round_up(k, 32); a.partial = nullptr;
+    EgProfScope prof(2, 2.0 * m * (double)n * k, (hipStream_t)stream);
     return launch_gemm(a, 1, precision, (hipStream_t)stream);
 }
 

@@ -28,6 +28,48 @@ extern "C" int eg_set_default_precision(int p) {
 }
 extern "C" int eg_get_default_precision(void) { return g_default_precision; }
 
+// ---- launch profiler ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int64_t tag; double flops; };
+std::vector<ProfRec> g_prof;
+int g_prof_n = 0;
+bool g_prof_on = false;
+}  // namespace
+EgProfScope::EgProfScope(int64_t tag, double flops, hipStream_t s) : slot(-1), st(s) {
+    if (!g_prof_on || g_prof_n >= (int)g_prof.size()) return;
+    slot = g_prof_n++;
+    g_prof[slot].tag = tag;
+    g_prof[slot].flops = flops;
+    (void)hipEventRecord(g_prof[slot].a, st);
+}
+EgProfScope::~EgProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+extern "C" int eg_profile_enable(int32_t max_records) {
+    EG_REQUIRE(max_records > 0, EG_ERR_BAD_ARG, "eg_profile_enable: max_records=%d", max_records);
+    while ((int)g_prof.size() < max_records) {
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { eg_set_error("hipEventCreate failed"); return EG_ERR_HIP; }
+        r.tag = 0; r.flops = 0;
+        g_prof.push_back(r);
+    }
+    g_prof_n = 0;
+    g_prof_on = true;
+    return EG_OK;
+}
+extern "C" int eg_profile_disable(void) { g_prof_on = false; return EG_OK; }
+extern "C" int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacity) {
+    int n = g_prof_n < capacity ? g_prof_n : capacity;
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventSynchronize(g_prof[i].b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+        tags[i] = g_prof[i].tag; flops[i] = g_prof[i].flops; ms[i] = t;
+    }
+    g_prof_n = 0;
+    return n;
+}
+
 // ---- internal launchers implemented in misc.hip ---------------------------------------------------------------
 struct EgiPriorW {
     const float *w1, *b1, *s1, *t1, *w2, *b2, *s2, *t2;

@@ -78,11 +78,13 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ m
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float ref_db = 10.f * log10f(fmaxf(1e-10f, mx));
-    const float floor_db = (10.f * log10f(fmaxf(1e-10f, mx)) - ref_db) - 80.f;     // max(db) - top_db
+    // power_to_db(ref=np.max): 10*log10(max(amin,S)) - 10*log10(max(amin,max S)) = 10*log10(max(amin,S)/ref); the ratio
+    // form makes the peak (and an all-silent clip) exactly 0 dB, as in exact arithmetic.  max(db) = 0 => floor = -top_db.
+    const float inv_ref = 1.0f / fmaxf(1e-10f, mx);
+    const float floor_db = -80.f;
     for (int i = tid; i < 128 * out_frames; i += 256) {
         const int m = i / out_frames, f = i - m * out_frames;
-        float db = 10.f * log10f(fmaxf(1e-10f, p[m * n_frames + f])) - ref_db;
+        float db = 10.f * log10f(fmaxf(1e-10f, p[m * n_frames + f]) * inv_ref);
         db = fmaxf(db, floor_db);
         spec[((size_t)b * 128 + m) * out_frames + f] = __half2float(__float2half_rn(db));
     }

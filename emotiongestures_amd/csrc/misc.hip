@@ -444,6 +444,15 @@ extern "C" int eg_reparameterize(const float* mu, const float* logvar, const flo
     return eg_check_launch("reparameterize");
 }
 
+extern "C" int eg_add_rows(const float* a, const float* table, float* out, int64_t rows, int32_t d, int32_t period, void* stream) {
+    EG_REQUIRE(a && table && out && rows > 0 && d > 0, EG_ERR_BAD_ARG, "eg_add_rows: null pointer or empty shape");
+    EG_REQUIRE((d & 3) == 0, EG_ERR_ALIGN, "eg_add_rows: d %% 4 != 0");
+    const size_t n4 = (size_t)rows * (d / 4);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f4*>(a),
+                       reinterpret_cast<const f4*>(table), reinterpret_cast<f4*>(out), n4, d / 4, period);
+    return eg_check_launch("add_rows");
+}
+
 // ---- internal (C++ linkage) launchers used by generator.hip ------------------------------------------------
 int egi_embedding(const int64_t* idx, const float* table, float* out, int rows, int dim, int ld, int n_words, hipStream_t st) {
     hipLaunchKernelGGL(embedding_kernel, dim3(grid_for((size_t)rows * dim / 4)), dim3(256), 0, st, idx, table, out, rows, dim, ld, n_words);

@@ -350,7 +350,7 @@ class Encoder(nn.Module):
 
     def forward(self, src_seq, src_mask, return_attns=False, global_feature=False):
         _eval_only(self)
-        x = src_seq + self.position_enc.pos_table[:, :src_seq.size(1)]      # layout plumbing only (one add)
+        x = ops.add_rows(src_seq, self.position_enc.pos_table[0, :src_seq.size(1)].contiguous(), period=src_seq.size(1))
         attns = []
         for layer in self.layer_stack:
             x, a = layer(x, slf_attn_mask=src_mask)

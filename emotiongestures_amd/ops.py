@@ -232,3 +232,13 @@ def reparameterize(mu, logvar, eps):
     z = torch.empty_like(mu)
     L.check(lib.eg_reparameterize(_ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream(mu.device)), "eg_reparameterize")
     return z
+
+
+def add_rows(a, table, period=0):
+    """a [.., rows, d] + table[row % period] (period 0: plain add)."""
+    lib = L.load()
+    a, table = _need_cuda(a, "a"), _need_cuda(table, "table")
+    d = a.shape[-1]
+    out = torch.empty_like(a)
+    L.check(lib.eg_add_rows(_ptr(a), _ptr(table), _ptr(out), a.numel() // d, d, period, _stream(a.device)), "eg_add_rows")
+    return out

@@ -56,6 +56,14 @@ const char* eg_version(void);
 int eg_set_default_precision(int precision);
 int eg_get_default_precision(void);
 
+/* Optional per-launch timing of the contraction kernels (bench.py's roofline leg; a debugging facility, process
+ * global, not thread safe).  While enabled, every eg_conv3x3 / eg_linear launch is bracketed by a hipEvent pair on its
+ * own stream (no synchronisation).  eg_profile_read synchronises those events and returns, per record, a tag
+ * (conv: cin*1000000 + cout*1000 + stride*100 + 1; linear: 2) , its work in FLOP and its duration in ms. */
+int eg_profile_enable(int32_t max_records);
+int eg_profile_disable(void);
+int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacity);
+
 /* ------------------------------------------------------------------------------------------
  * Weight arena.  A model's parameters live in ONE caller-owned fp32 device buffer ("arena")
  * in kernel-ready layouts.  The library is authoritative for the layout: it publishes a
@@ -208,6 +216,8 @@ int eg_conv3x3(const float* x, const float* w, const float* bias, const float* s
                float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
                int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
 int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride);
+/* size in floats of one EG_PACK_CONV3X3 image (fp32 image + bf16 hi/lo images) */
+int64_t eg_conv3x3_packed_floats(int32_t cin, int32_t cout_pad);
 
 /* Stem: Conv2d(1->C,3x3,bias) -> ReLU -> BN (ResNetSE34V2.py:64-66).  x [B,H,W], y NHWC [B,H,W,C]. */
 int eg_stem_conv(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift,
@@ -273,6 +283,10 @@ int eg_positionwise_ffn(const float* x, const float* w1, const float* b1, const 
  * (EG_PACK_WN_TAP x2 + RAW); Cpad = C rounded up to 4.  workspace >= 4*B*L*Cpad floats. */
 int eg_tcn_forward(const float* x, const float* w, float* y, int32_t batch, int32_t len, int32_t c,
                    int32_t levels, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out[r,:] = a[r,:] + table[r % period,:]  (PositionalEncoding.forward, Full_model/Models_spatial_memory.py:46-48);
+ * period == 0: plain elementwise add of two [rows, d] tensors (fusion add, :601-605).  d % 4 == 0. */
+int eg_add_rows(const float* a, const float* table, float* out, int64_t rows, int32_t d, int32_t period, void* stream);
 
 /* VAE reparameterisation (CAVE/BEAT_CVAE.py:397-399): z = eps*exp(0.5*logvar) + mu, n elements. */
 int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);

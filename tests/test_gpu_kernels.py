@@ -1,0 +1,209 @@
+"""Per-kernel parity: every block operator of include/emogest.h, called through the C ABI on the GPU, against
+the CPU oracle / plain fp32 torch reference of the same op on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import build_mirror, rel_l2
+from emotiongestures_amd.synth import hash_uniform
+
+pytestmark = pytest.mark.gpu
+
+# tolerance per arithmetic mode (relative L2 of the whole tensor)
+TOL = {"f32": 2e-6, "bf16x3": 3e-5, "bf16": 2e-2}
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(key, shape, lo=-1.0, hi=1.0, seed=0):
+    return torch.from_numpy(hash_uniform(key, shape, lo, hi, seed))
+
+
+CONV_CASES = [   # cin, cout, stride, H, W, nchw
+    (32, 32, 1, 24, 40, False), (32, 64, 2, 24, 44, False), (64, 64, 1, 16, 62, False), (64, 128, 2, 18, 62, False),
+    (128, 128, 1, 12, 31, False), (128, 34, 1, 8, 31, True), (128, 60, 1, 8, 20, True), (32, 32, 1, 128, 124, False),
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("cin,cout,stride,H,W,nchw", CONV_CASES)
+def test_conv3x3_epilogues(cin, cout, stride, H, W, nchw, prec):
+    from emotiongestures_amd import ops
+    B = 2
+    x = T(f"x{cin}", (B, cin, H, W), -1, 1)
+    w = T(f"w{cin}{cout}", (cout, cin, 3, 3), -0.1, 0.1)
+    bias, scale, shift = T("b", (cout,), -0.2, 0.2), T("s", (cout,), 0.5, 1.5), T("t", (cout,), -0.3, 0.3)
+    for relu in (True, False):
+        ref = F.conv2d(x, w, bias, stride=stride, padding=1)
+        if relu:
+            ref = F.relu(ref)
+        ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+        y, gap = ops.conv3x3(xg, w, bias, scale, shift, stride=stride, relu=relu, nchw_out=nchw, want_gap=True, precision=prec)
+        got = y.cpu().view(ref.shape) if nchw else y.cpu().permute(0, 3, 1, 2)
+        assert rel_l2(got.numpy(), ref.numpy()) < TOL[prec]
+        # SE partial sums: sum over tiles == sum over pixels of the epilogue output
+        assert rel_l2(gap.sum(1).cpu().numpy(), ref.sum((2, 3)).numpy()) < max(TOL[prec], 1e-5)
+
+
+def test_conv3x3_rejects_bad_arguments():
+    from emotiongestures_amd import ops
+    from emotiongestures_amd._lib import EgError
+    x = torch.zeros(1, 8, 8, 48, device=dev())
+    with pytest.raises(EgError):
+        ops.conv3x3(x, torch.zeros(48, 48, 3, 3))                # unsupported channel count
+    with pytest.raises(EgError):
+        ops.conv3x3(torch.zeros(1, 8, 8, 32), torch.zeros(32, 32, 3, 3))       # CPU tensor: no fallback
+    with pytest.raises(EgError):
+        ops.conv3x3(torch.zeros(1, 8, 8, 32, device=dev()), torch.zeros(32, 32, 3, 3), stride=3)
+
+
+def test_stem_conv():
+    from emotiongestures_amd import ops
+    x = T("spec", (2, 128, 124), -80, 0)
+    w, b = T("w", (32, 1, 3, 3), -0.3, 0.3), T("b", (32,), -0.1, 0.1)
+    s, t = T("s", (32,), 0.5, 1.5), T("t", (32,), -0.2, 0.2)
+    ref = F.relu(F.conv2d(x.unsqueeze(1), w, b, padding=1)) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+    y = ops.stem_conv(x.to(dev()), w, b.to(dev()), s.to(dev()), t.to(dev()))
+    assert rel_l2(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("layer,idx,H,W", [("layer1", 1, 32, 40), ("layer2", 0, 32, 44), ("layer2", 2, 16, 22), ("layer3", 0, 16, 22), ("layer3", 3, 8, 31)])
+def test_se_basic_block_module(layer, idx, H, W, prec):
+    """SEBasicBlock.forward (Full_model/ResNetBlocks.py:21-37) incl. the stride-2 downsample shortcut."""
+    from oracle import emogest_oracle as O
+    m = build_mirror("spatial", 34, 126, 4, 4)
+    blk = getattr(m.audio_encoder.feat_extractor, layer)[idx]
+    p = f"audio_encoder.feat_extractor.{layer}.{idx}"
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cin = blk.conv1.weight.shape[1]
+    x = T("blk", (2, cin, H, W), -1, 1)
+    ref = O.se_basic_block(sd, p, x, blk.stride)
+    blk.to(dev()).eval()
+    blk.precision = prec
+    got = blk(x.to(dev())).cpu()
+    assert got.shape == ref.shape
+    assert rel_l2(got.numpy(), ref.numpy()) < TOL[prec] * 3
+
+
+LIN_CASES = [(70, 512, 512), (68, 126, 128), (34, 2048, 512), (130, 300, 300), (5, 8, 64), (64, 512, 992)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", LIN_CASES)
+def test_linear_epilogues(M, N, K, prec):
+    from emotiongestures_amd import ops
+    x, w, b = T("x", (M, K)), T("w", (N, K), -0.05, 0.05), T("b", (N,), -0.1, 0.1)
+    r1, r2 = T("r1", (M, N)), T("r2", (M, N))
+    d = dev()
+    y = ops.linear(x.to(d), w, b, precision=prec).cpu()
+    assert rel_l2(y.numpy(), F.linear(x, w, b).numpy()) < TOL[prec]
+    y = ops.linear(x.to(d), w, b, res1=r1.to(d), relu=True, precision=prec).cpu()
+    assert rel_l2(y.numpy(), F.relu(F.linear(x, w, b) + r1).numpy()) < TOL[prec]
+    y = ops.linear(x.to(d), w, None, res1=r1.to(d), res2=r2.to(d), relu=True, precision=prec).cpu()
+    assert rel_l2(y.numpy(), F.relu(F.relu(F.linear(x, w) + r1) + r2).numpy()) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_linear_causal_shift_matches_dilated_conv_tap(prec):
+    """a_shift/a_seq: the x[t-d] tap of the causal dilated conv (Full_model/tcn.py:18-24)."""
+    from emotiongestures_amd import ops
+    B, Ln, Cc, dil = 3, 60, 300, 4
+    x, w = T("x", (B * Ln, Cc)), T("w", (Cc, Cc), -0.05, 0.05)
+    xs = torch.zeros(B, Ln, Cc)
+    xs[:, dil:] = x.view(B, Ln, Cc)[:, :-dil]
+    ref = F.linear(xs.view(B * Ln, Cc), w)
+    y = ops.linear(x.to(dev()), w, a_shift=dil, a_seq=Ln, precision=prec).cpu()
+    assert rel_l2(y.numpy(), ref.numpy()) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_linear_splitk(prec):
+    from emotiongestures_amd import ops
+    M, N, K = 6, 512, 34 * 512
+    x, w, b = T("x", (M, K)), T("w", (N, K), -0.01, 0.01), T("b", (N,))
+    y = ops.linear_splitk(x.to(dev()), w, b, relu=True, splits=34, precision=prec).cpu()
+    assert rel_l2(y.numpy(), F.relu(F.linear(x, w, b)).numpy()) < TOL[prec] * 2
+
+
+@pytest.mark.parametrize("rows,d", [(68, 512), (7, 128), (33, 2048), (1, 64)])
+def test_layernorm(rows, d):
+    from emotiongestures_amd import ops
+    x, g, b = T("x", (rows, d), -3, 3), T("g", (d,), 0.5, 1.5), T("b", (d,), -0.5, 0.5)
+    y = ops.layernorm(x.to(dev()), g.to(dev()), b.to(dev()), 1e-6).cpu()
+    assert rel_l2(y.numpy(), F.layer_norm(x, (d,), g, b, 1e-6).numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 8, 34, 34), (1, 8, 60, 60), (2, 2, 120, 120), (3, 8, 34, 60), (1, 1, 1, 1)])
+def test_attention(B, H, Lq, Lk):
+    """ScaledDotProductAttention (Full_model/Modules.py:13-23), ragged Lq != Lk and the 1x1 edge case."""
+    from emotiongestures_amd import ops
+    D = H * 64
+    q, k, v = T("q", (B, Lq, D), -2, 2), T("k", (B, Lk, D), -2, 2), T("v", (B, Lk, D))
+    split = lambda t, L: t.view(B, L, H, 64).transpose(1, 2)
+    attn = torch.softmax(torch.matmul(split(q, Lq) / 8.0, split(k, Lk).transpose(2, 3)), dim=-1)
+    ref = torch.matmul(attn, split(v, Lk)).transpose(1, 2).reshape(B, Lq, D)
+    out, a = ops.attention(q.to(dev()), k.to(dev()), v.to(dev()), H, want_attn=True)
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 3e-6
+    assert rel_l2(a.cpu().numpy(), attn.numpy()) < 3e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_mha_and_ffn_modules(prec):
+    """MultiHeadAttention / PositionwiseFeedForward forward (Full_model/SubLayers.py:30-59,74-84) and a whole
+    DecoderLayer (Full_model/Layers.py:50-58) at module level."""
+    from oracle import emogest_oracle as O
+    m = build_mirror("spatial", 34, 126, 4, 4)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cfg = O.GenCfg()
+    x, e = T("x", (2, 34, 512)), T("e", (2, 34, 512))
+    layer = m.decoder.layer_stack[1].to(dev()).eval()
+    layer.enc_attn.precision = layer.pos_ffn.precision = prec
+    ref_a, ref_attn = O.multi_head_attention(sd, "decoder.layer_stack.1.enc_attn", x, e, e, cfg)
+    ref = O.positionwise_ffn(sd, "decoder.layer_stack.1.pos_ffn", ref_a)
+    got_a, got_attn = layer.enc_attn(x.to(dev()), e.to(dev()), e.to(dev()))
+    assert rel_l2(got_a.cpu().numpy(), ref_a.numpy()) < TOL[prec] * 3
+    assert rel_l2(got_attn.cpu().numpy(), ref_attn.numpy()) < TOL[prec] * 3
+    out, _, _ = layer(x.to(dev()), e.to(dev()))
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < TOL[prec] * 3
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_tcn_module(prec):
+    """TemporalConvNet.forward (Full_model/tcn.py:63): 3 levels, dilation 1/2/4, causal."""
+    from oracle import emogest_oracle as O
+    m = build_mirror("spatial", 34, 126, 4, 4)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = T("tcn", (2, 300, 60))
+    ref = x
+    cfg = O.GenCfg()
+    for i in range(3):
+        d, q = 2 ** i, f"text_encoder.tcn.network.{i}"
+        out = ref
+        for c in ("conv1", "conv2"):
+            w = O.weight_norm_weight(sd[f"{q}.{c}.weight_v"], sd[f"{q}.{c}.weight_g"])
+            out = F.relu(F.conv1d(out, w, sd[f"{q}.{c}.bias"], padding=d, dilation=d)[:, :, :60])
+        ref = F.relu(out + ref)
+    tcn = m.text_encoder.tcn.to(dev()).eval()
+    tcn.precision = prec
+    got = tcn(x.to(dev())).cpu()
+    assert rel_l2(got.numpy(), ref.numpy()) < TOL[prec] * 3
+    # causality: changing the last time step must not change earlier outputs
+    x2 = x.clone()
+    x2[:, :, -1] += 1.0
+    got2 = tcn(x2.to(dev())).cpu()
+    assert torch.equal(got2[:, :, :-1], got[:, :, :-1])
+
+
+def test_reparameterize_and_add_rows():
+    from emotiongestures_amd import ops
+    mu, lv, eps = T("mu", (5, 32)), T("lv", (5, 32), -2, 2), T("eps", (5, 32), -3, 3)
+    z = ops.reparameterize(mu.to(dev()), lv.to(dev()), eps.to(dev())).cpu()
+    assert rel_l2(z.numpy(), (eps * torch.exp(0.5 * lv) + mu).numpy()) < 2e-6
+    a, tab = T("a", (3, 34, 512)), T("tab", (34, 512))
+    assert torch.equal(ops.add_rows(a.to(dev()), tab.to(dev()), period=34).cpu(), a + tab)
