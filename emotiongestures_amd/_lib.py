@@ -70,9 +70,9 @@ SIGNATURES = {
     "eg_cvae_workspace_bytes": (_L, [_P, _I]),
     "eg_cvae_sample": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _L, _P]),
     "eg_cvae_forward": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
-    "eg_mel_tables": (C.c_int, [_P, _P, _P]),
+    "eg_mel_tables": (C.c_int, [_P, _P, _P, _P]),
     "eg_mel_workspace_bytes": (_L, [_I, _I]),
-    "eg_melspectrogram": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "eg_melspectrogram": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "eg_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_conv3x3_gap_tiles": (_I, [_I, _I, _I, _I, _I]),
     "eg_stem_conv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

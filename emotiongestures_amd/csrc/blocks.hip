@@ -55,14 +55,14 @@ extern "C" int eg_positionwise_ffn(const float* x, const float* w1, const float*
     return eg_layernorm(pr, ln_g, ln_b, out, rows, d_model, 1e-6f, stream);
 }
 
-// TemporalConvNet (Full_model/tcn.py:49-64).  x, y [B, L, Cpad] channels-last with row stride Cpad = round_up(C, 8).
+// TemporalConvNet (Full_model/tcn.py:49-64).  x, y [B, L, Cpad] channels-last with row stride Cpad = round_up(C, 64).
 // w: per level two convs, each { tap0 image, tap1 image, bias[Npad] }, image = EG_PACK_WN_TAP ([Npad][Cpad] x2 floats),
-// Npad = round_up(C, 16).
+// Npad = round_up(C, 64).
 extern "C" int eg_tcn_forward(const float* x, const float* w, float* y, int32_t batch, int32_t len, int32_t c,
                               int32_t levels, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream) {
     EG_REQUIRE(x && w && y && workspace && batch > 0 && len > 0 && levels > 0, EG_ERR_BAD_ARG, "eg_tcn_forward: null pointer or empty shape");
     EG_REQUIRE(c % 4 == 0, EG_ERR_UNSUPPORTED, "eg_tcn_forward: C=%d must be a multiple of 4", c);
-    const int cpad = (int)eg_round_up(c, 8), npad = (int)eg_round_up(c, 16), rows = batch * len;
+    const int cpad = (int)eg_round_up(c, 64), npad = (int)eg_round_up(c, 64), rows = batch * len;
     const int64_t buf = (int64_t)rows * cpad;
     EG_REQUIRE(workspace_bytes >= (int64_t)sizeof(float) * buf * 4, EG_ERR_WORKSPACE, "eg_tcn_forward: workspace too small");
     const int64_t img = (int64_t)npad * cpad * 2, conv = 2 * img + npad;

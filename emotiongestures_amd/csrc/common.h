@@ -55,6 +55,28 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
+// split 8 consecutive fp32 into bf16 (hi, lo) octets with the hardware packed convert (v_cvt_pk_bf16_f32):
+// 2 cvt + shl + and + packed sub per pair of floats.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool WANT_LO>
+__device__ __forceinline__ void split_octet(const f4& v0, const f4& v1, bf8& hi, bf8& lo) {
+    u32x4_t h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t x = {p < 2 ? v0[2 * p] : v1[2 * p - 4], p < 2 ? v0[2 * p + 1] : v1[2 * p - 3]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+        h[p] = hu;
+        if (WANT_LO) {
+            const f32x2_t r = {x[0] - __uint_as_float(hu << 16), x[1] - __uint_as_float(hu & 0xffff0000u)};
+            l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+        }
+    }
+    hi = __builtin_bit_cast(bf8, h);
+    if (WANT_LO) lo = __builtin_bit_cast(bf8, l);
+}
+
 // ---- optional launch profiler (generator.hip) ----------------------------------------------------------------
 struct EgProfScope {
     int slot;

@@ -157,19 +157,34 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 }
 
 // ---- split-bf16 MFMA path (EG_PREC_BF16X3 / EG_PREC_BF16) --------------------------------------
-// Same tiling.  The halo tile is split while it is staged: hi = bf16(x), lo = bf16(x - hi), kept as
-// two channel-octet planar images [ci/8][pixel][8 bf16] (same 16-byte slot structure as the fp32
-// image, so the same conflict-free ds_read_b128).  Weights are pre-split on the host into the same
-// octet layout [tap][ci/8][co][8] (hi image, then lo image).  Per 32-channel k-step and tile pair:
-//   acc += Whi*Xhi + Whi*Xlo + Wlo*Xhi        (3 x v_mfma_f32_16x16x32_bf16; lo*lo ~ 2^-16 dropped)
-template <int CIN, int NT, int S, int TH, int TERMS>
+// Same tiling, but BOTH operands come from LDS and the weight stream is asynchronous:
+//  * halo tile: split while it is staged, hi = bf16(x), lo = bf16(x - hi), kept as two channel-octet planar images
+//    [ci/8][pixel][8 bf16] (same 16-byte slot structure as the fp32 image => conflict-free ds_read_b128);
+//  * weights: pre-split on the host into [tap][ci/8][co][8] (hi image, lo image).  The 4 octets of one (tap, 32-channel
+//    chunk) are one contiguous 64*COUTP-byte run, copied by global_load_lds (16 B/lane, no VGPR, no VALU) into a
+//    2-deep LDS ring: the copy of step s+1 is in flight while step s computes; one barrier per step retires it;
+//  * waves tile the workgroup's TH x 32 pixels x COUTP channels as WM (pixels) x WN (channels); per step and
+//    (pixel tile, channel tile) pair:  acc += Whi*Xhi + Whi*Xlo + Wlo*Xhi   (3 x v_mfma_f32_16x16x32_bf16).
+// Without the LDS weight ring every wave re-read all weights from L1/L2 (170 B/clk/CU demanded at C=128 vs 64 B/clk
+// of L1): the r01a profile's 115 us per 128->128 launch.
+template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
                                                            const bf8* __restrict__ wlo) {
     using G = ConvGeom<S, TH>;
-    constexpr int COUTP = NT * 16, IW = G::IW, NPIX = G::NPIX, PL = G::PL, MT = G::MT;
-    __shared__ bf8 tile[(TERMS == 3 ? 2 : 1) * 4 * PL];      // [hi|lo][oct 0..3][pixel]
+    constexpr int COUTP = NTT * 16, IW = G::IW, NPIX = G::NPIX, PL = G::PL;
+    constexpr int MT = TH * 2 / WM, NT = NTT / WN;
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr int TILE = NIMG * 4 * PL;             // bf8 slots of the halo tile
+    constexpr int WIMG = 4 * COUTP;                 // bf8 slots of one weight image of one step
+    constexpr int WBUF = NIMG * WIMG;
+    constexpr int NSTEP = (CIN / 32) * 9;
+    static_assert(WM * WN == 4 && MT * WM == TH * 2 && NT * WN == NTT, "wave tiling");
+    __shared__ bf8 lds[TILE + 2 * WBUF];
+    bf8* tile = lds;
+    bf8* wring = lds + TILE;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile_id = blockIdx.x, b = blockIdx.y;
     const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * 32;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
     int pbase[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const int id = wave * MT + t;
+        const int id = wm * MT + t;
         pbase[t] = ((id >> 1) * S) * IW + ((id & 1) * 16 + li) * S;
     }
     f4 acc[MT][NT];
@@ -188,9 +203,29 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
         for (int n = 0; n < NT; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
 
+    // one step's weights = NIMG runs of WIMG slots; 64-slot (1 KiB) pieces are dealt round-robin to the 4 waves
+    auto issue_weights = [&](int step, int buf) {
+        const int chunk = step / 9, tap = step - chunk * 9;
+        const size_t gbase = ((size_t)tap * (CIN / 8) + chunk * 4) * COUTP;
+        constexpr int PIECES = WIMG / 64;
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) {
+            const bf8* src = (img ? wlo : whi) + gbase;
+#pragma unroll
+            for (int p = 0; p < (PIECES + 3) / 4; ++p) {
+                const int piece = p * 4 + wave;
+                if (piece < PIECES)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                                     (__attribute__((address_space(3))) void*)(wring + buf * WBUF + img * WIMG + piece * 64),
+                                                     16, 0, 0);
+            }
+        }
+    };
+
+    issue_weights(0, 0);
+#pragma unroll 1
     for (int chunk = 0; chunk < CIN / 32; ++chunk) {
-        if (chunk) __syncthreads();
-        // one lane = one pixel x 8 channels (two 16-B global loads); 8 consecutive lanes = 8 pixels of one octet
+        // stage + split the (IH x IW) x 32-channel halo tile: one lane = one pixel x 8 channels
         for (int idx = tid; idx < ((NPIX + 7) / 8) * 32; idx += 256) {
             const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
             if (p < NPIX) {
@@ -203,47 +238,40 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
                     v1 = *reinterpret_cast<const f4*>(src + 4);
                 }
                 bf8 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = j < 4 ? v0[j & 3] : v1[j & 3];
-                    const unsigned short h = f32_to_bf16_rne(x);
-                    hi[j] = (short)h;
-                    lo[j] = (short)f32_to_bf16_rne(x - bf16_to_f32(h));
-                }
+                split_octet<TERMS == 3>(v0, v1, hi, lo);
                 tile[oc * PL + p] = hi;
                 if (TERMS == 3) tile[(4 + oc) * PL + p] = lo;
             }
         }
-        __syncthreads();
-        const size_t wbase = (size_t)(chunk * 4 + kq) * COUTP + li;
+        __syncthreads();                        // tile visible; also retires the weight copy of step chunk*9
 #pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
+        for (int tap = 0; tap < 9; ++tap) {
+            const int step = chunk * 9 + tap, buf = step & 1;
+            if (step + 1 < NSTEP) issue_weights(step + 1, buf ^ 1);
+            const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
+            const bf8* Wh = wring + buf * WBUF + kq * COUTP + wn * NT * 16 + li;
+            bf8 wh[NT], wl[NT], xh[MT], xl[MT];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tap = kh * 3 + kw, toff = kh * IW + kw;
-                bf8 wh[NT], wl[NT], xh[MT], xl[MT];
+            for (int n = 0; n < NT; ++n) {
+                wh[n] = Wh[n * 16];
+                if (TERMS == 3) wl[n] = Wh[WIMG + n * 16];
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                xh[t] = tile[kq * PL + pbase[t] + toff];
+                if (TERMS == 3) xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const size_t wi = wbase + (size_t)tap * (CIN / 8) * COUTP + n * 16;
-                    wh[n] = whi[wi];
-                    if (TERMS == 3) wl[n] = wlo[wi];
-                }
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    xh[t] = tile[kq * PL + pbase[t] + toff];
-                    if (TERMS == 3) xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
-                }
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        if (TERMS == 3) {
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
-                        }
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
                     }
-            }
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+                }
+            __syncthreads();                    // next step's weights landed; this step's buffers are free
         }
     }
 
@@ -252,13 +280,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
     for (int n = 0; n < NT; ++n) gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int co = n * 16 + kq * 4;
+        const int co = (wn * NT + n) * 16 + kq * 4;
         const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
         const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
         const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const int id = wave * MT + t;
+            const int id = wm * MT + t;
             const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
             const bool valid = (oy < a.Ho) && (ox < a.Wo);
             f4 v = acc[t][n] + bi;
@@ -281,9 +309,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
             }
         }
     }
-    if (a.gap) {
-        float* sred = reinterpret_cast<float*>(tile);
-        __syncthreads();
+    if (a.gap) {            // the last step's barrier already passed: the LDS is free for the reduction
+        float* sred = reinterpret_cast<float*>(lds);        // [WM][COUTP]
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -291,12 +318,14 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
                 float s = gsum[n][r];
                 s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
                 s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-                if (li == 0) sred[wave * COUTP + n * 16 + kq * 4 + r] = s;
+                if (li == 0) sred[wm * COUTP + (wn * NT + n) * 16 + kq * 4 + r] = s;
             }
         }
         __syncthreads();
         if (tid < a.cout) {
-            const float s = (sred[tid] + sred[COUTP + tid]) + (sred[2 * COUTP + tid] + sred[3 * COUTP + tid]);
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) s += sred[m * COUTP + tid];
             a.gap[((size_t)b * a.tiles + tile_id) * a.cout + tid] = s;
         }
     }
@@ -340,10 +369,17 @@ __global__ __launch_bounds__(128) void se_gate_kernel(const float* __restrict__ 
     __shared__ float m[128];
     __shared__ float h[16];
     const int b = blockIdx.x, t = threadIdx.x, R = C >> 3;
-    if (t < C) {
+    {   // fixed-order (deterministic) two-level sum of the per-tile partials: 128/C groups x C channels
+        const int c = t % C, g = t / C, G = 128 / C;
         float s = 0.f;
-        for (int i = 0; i < tiles; ++i) s += gap[((size_t)b * tiles + i) * C + t];
-        m[t] = s * inv_hw;
+        for (int i = g; i < tiles; i += G) s += gap[((size_t)b * tiles + i) * C + c];
+        m[t] = s;
+        __syncthreads();
+        float tot = 0.f;
+        if (t < C)
+            for (int j = 0; j < G; ++j) tot += m[j * C + t];
+        __syncthreads();
+        if (t < C) m[t] = tot * inv_hw;
     }
     __syncthreads();
     if (t < R) {
@@ -407,7 +443,7 @@ __global__ __launch_bounds__(256) void se_tail_downsample_kernel(const float* __
     }
 }
 
-template <int CIN, int NT, int S, int TH>
+template <int CIN, int NT, int S, int TH, int WM, int WN>
 int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
     dim3 grid(a.tiles, batch), block(256);
     if (precision == EG_PREC_F32) {
@@ -418,9 +454,9 @@ int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
         const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
         const bf8* wlo = whi + (size_t)9 * (CIN / 8) * NT * 16;
         if (precision == EG_PREC_BF16X3)
-            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, 3>), grid, block, 0, st, a, whi, wlo);
+            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, WM, WN, 3>), grid, block, 0, st, a, whi, wlo);
         else
-            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, 1>), grid, block, 0, st, a, whi, wlo);
+            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, WM, WN, 1>), grid, block, 0, st, a, whi, wlo);
     }
     return eg_check_launch("conv3x3");
 }
@@ -462,16 +498,16 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
     const int coutp = (int)eg_round_up(cout, 16);
     EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + stride * 100 + 1,
                      2.0 * 9 * cin * cout * (double)a.Ho * a.Wo * batch, st);
-    if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8>(a, batch, precision, st);
-    if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2>(a, batch, precision, st);
-    if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8>(a, batch, precision, st);
-    if (cin == 64 && coutp == 128 && stride == 2) return launch_conv<64, 8, 2, 2>(a, batch, precision, st);
-    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4>(a, batch, precision, st);
+    if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8, 4, 1>(a, batch, precision, st);
+    if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2, 2, 2>(a, batch, precision, st);
+    if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8, 4, 1>(a, batch, precision, st);
+    if (cin == 64 && coutp == 128 && stride == 2) return launch_conv<64, 8, 2, 2, 2, 2>(a, batch, precision, st);
+    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4, 2, 2>(a, batch, precision, st);
     if (cin == 128 && coutp <= 64 && stride == 1) {       // final_conv1: 128 -> frames (34 -> 48, 60 -> 64)
-        if (coutp <= 48) return launch_conv<128, 3, 1, 4>(a, batch, precision, st);
-        return launch_conv<128, 4, 1, 4>(a, batch, precision, st);
+        if (coutp <= 48) return launch_conv<128, 3, 1, 4, 4, 1>(a, batch, precision, st);
+        return launch_conv<128, 4, 1, 4, 4, 1>(a, batch, precision, st);
     }
-    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4>(a, batch, precision, st);
+    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4, 2, 2>(a, batch, precision, st);
     eg_set_error("eg_conv3x3: unsupported channels cin=%d cout=%d stride=%d", cin, cout, stride);
     return EG_ERR_UNSUPPORTED;
 }

@@ -32,6 +32,59 @@ __device__ __forceinline__ f4 load_x_quad(const GemmArgs& a, int m, int k, int k
     return v;
 }
 
+
+// v = acc + bias + res1; relu; (+res2, relu); lane owns 4 consecutive n of row m (+16 per t), n += 16 per tile
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[2][2], int mbase, int nbase) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = mbase + t * 16;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int nn = nbase + n * 16;
+            if (nn >= a.N) continue;
+            f4 v = acc[t][n];
+            if (a.partial) {            // split-K: raw partial sums [split][M][N]
+                float* p = a.partial + ((size_t)blockIdx.z * a.M + m) * a.N + nn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nn + r < a.N) p[r] = v[r];
+                continue;
+            }
+            const bool full = (nn + 3 < a.N);
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nn + r < a.N) v[r] += a.bias[nn + r];
+            }
+            if (a.res1) {
+                const float* rp = a.res1 + (size_t)m * a.ldr + nn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nn + r < a.N) v[r] += rp[r];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.res2) {
+                const float* rp = a.res2 + (size_t)m * a.ldr + nn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nn + r < a.N) v[r] = fmaxf(v[r] + rp[r], 0.f);
+            }
+            float* yp = a.y + (size_t)m * a.ldc + nn;
+            if (full && (a.ldc & 3) == 0) {
+                *reinterpret_cast<f4*>(yp) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nn + r < a.N) yp[r] = v[r];
+            }
+        }
+    }
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     __shared__ f4 lds[1024];            // fp32: Xs[8][64] | Ws[8][64];  bf16: Xh[4][64] Xl[4][64] Wh[4][64] Wl[4][64] (bf8 = 16 B)
@@ -125,55 +178,119 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    // epilogue
+    gemm_epilogue(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+}
+
+// ---- split-bf16 path: 64x64 tile, K-step 64, both operands double-buffered in LDS ------------------------------
+//  * W: pre-split on the host into tile-planar bf16 images [n/64][k/8][64 rows][8] (hi image, lo image): the 8 octets of
+//    one K-step are 8 contiguous 1-KiB pieces, copied by global_load_lds (no VGPR/VALU) into a 2-deep ring;
+//  * X (fp32 activations): next step's rows are loaded to registers before this step's MFMAs, split to (hi, lo) bf16 with
+//    v_cvt_pk_bf16_f32 and written to the other ring slot after them; one barrier per K-step.
+//  LDS image of both operands: [k/8][row] bf8 => the 16 rows of an MFMA tile are 16 consecutive 16-B slots (conflict free).
+template <int TERMS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr int IMG = 8 * 64;                     // bf8 slots of one operand image of one step (8 octets x 64 rows)
+    __shared__ bf8 lds[2 * 2 * NIMG * IMG];         // [buf][X|W][hi|lo][oct][row]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int kbeg = blockIdx.z * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nsteps = (kend - kbeg + 63) / 64;
+    const int KO = a.ldw >> 3;                      // octets per packed weight row
+
+    // X staging role: row = tid>>2, octets 2*(tid&3), 2*(tid&3)+1 (64 contiguous bytes per lane, 256 B per 4 lanes)
+    const int xr = tid >> 2, xo = (tid & 3) * 2;
+    const int xm = m0 + xr;
+    bool xok = xm < a.M;
+    int xsrc = xm;
+    if (a.a_shift) {
+        xok = xok && (xm % a.a_seq) >= a.a_shift;
+        xsrc = xm - a.a_shift;
+    }
+    const float* xrow = a.x + (size_t)(xok ? xsrc : 0) * a.lda;
+    f4 xv[4];
+    auto load_x = [&](int k0) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m0 + wm + t * 16 + li;
-        if (m >= a.M) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + xo * 8 + j * 4;
+            xv[j] = (xok && k < kend) ? *reinterpret_cast<const f4*>(xrow + k) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_x = [&](int buf) {
+        bf8* X = lds + buf * (2 * NIMG * IMG);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int nn = n0 + wn + n * 16 + kq * 4;
-            if (nn >= a.N) continue;
-            f4 v = acc[t][n];
-            if (a.partial) {            // split-K: raw partial sums [split][M][N]
-                float* p = a.partial + ((size_t)blockIdx.z * a.M + m) * a.N + nn;
+        for (int o = 0; o < 2; ++o) {
+            bf8 hi, lo;
+            split_octet<TERMS == 3>(xv[2 * o], xv[2 * o + 1], hi, lo);
+            X[(xo + o) * 64 + xr] = hi;
+            if (TERMS == 3) X[IMG + (xo + o) * 64 + xr] = lo;
+        }
+    };
+    auto issue_w = [&](int k0, int buf) {
+        bf8* W = lds + buf * (2 * NIMG * IMG) + NIMG * IMG;
+        const size_t gbase = ((size_t)blockIdx.y * KO + (k0 >> 3)) * 64;        // bf8 slots: [n/64][k/8][64]
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nn + r < a.N) p[r] = v[r];
-                continue;
-            }
-            const bool full = (nn + 3 < a.N);
-            if (a.bias) {
+        for (int img = 0; img < NIMG; ++img) {
+            const bf8* src = reinterpret_cast<const bf8*>(img ? a.wlo : a.whi) + gbase;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nn + r < a.N) v[r] += a.bias[nn + r];
-            }
-            if (a.res1) {
-                const float* rp = a.res1 + (size_t)m * a.ldr + nn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nn + r < a.N) v[r] += rp[r];
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (a.res2) {
-                const float* rp = a.res2 + (size_t)m * a.ldr + nn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nn + r < a.N) v[r] = fmaxf(v[r] + rp[r], 0.f);
-            }
-            float* yp = a.y + (size_t)m * a.ldc + nn;
-            if (full && (a.ldc & 3) == 0) {
-                *reinterpret_cast<f4*>(yp) = v;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nn + r < a.N) yp[r] = v[r];
+            for (int p = 0; p < 2; ++p) {
+                const int piece = p * 4 + wave;                                 // octet index 0..7
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(W + img * IMG + piece * 64), 16, 0, 0);
             }
         }
+    };
+
+    f4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    issue_w(kbeg, 0);
+    load_x(kbeg);
+    store_x(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) {
+            issue_w(kbeg + (s + 1) * 64, buf ^ 1);
+            load_x(kbeg + (s + 1) * 64);
+        }
+        const bf8* X = lds + buf * (2 * NIMG * IMG);
+        const bf8* W = X + NIMG * IMG;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xh[t] = X[(g * 4 + kq) * 64 + wm + t * 16 + li];
+                if (TERMS == 3) xl[t] = X[IMG + (g * 4 + kq) * 64 + wm + t * 16 + li];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                wh[n] = W[(g * 4 + kq) * 64 + wn + n * 16 + li];
+                if (TERMS == 3) wl[n] = W[IMG + (g * 4 + kq) * 64 + wn + n * 16 + li];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (TERMS == 3) {
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
+                    }
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+                }
+        }
+        if (more) store_x(buf ^ 1);
+        __syncthreads();
     }
+    gemm_epilogue(a, acc, m0 + wm + li, n0 + wn + kq * 4);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
@@ -190,8 +307,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int launch_gemm(GemmArgs& a, int splits, int precision, hipStream_t st) {
     dim3 grid(eg_cdiv(a.M, 64), eg_cdiv(a.N, 64), splits), block(256);
     if (precision == EG_PREC_F32) hipLaunchKernelGGL((gemm_kernel<EG_PREC_F32>), grid, block, 0, st, a);
-    else if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_kernel<EG_PREC_BF16X3>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<EG_PREC_BF16>), grid, block, 0, st, a);
+    else if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_bf16_kernel<3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<1>), grid, block, 0, st, a);
     return eg_check_launch("gemm");
 }
 
@@ -204,9 +321,10 @@ int fill_common(GemmArgs& a, const float* x, int lda, const float* w, int ldw, i
     a.x = x; a.w = w; a.lda = lda; a.ldw = ldw; a.M = m; a.N = n; a.K = k;
     a.whi = a.wlo = nullptr;
     if (precision != EG_PREC_F32) {
-        // packed weight = fp32 image [rows][ldw] followed by bf16 hi and lo images of the same shape; rows = N rounded to 16
-        EG_REQUIRE((ldw & 7) == 0, EG_ERR_ALIGN, "%s: split-bf16 modes need ldw %% 8 == 0 (packed weights)", who);
-        const size_t rows = (size_t)eg_round_up(n, 16);
+        // packed weight = fp32 image [rows][ldw] followed by tile-planar bf16 hi and lo images [rows/64][ldw/8][64][8];
+        // rows = N rounded up to 64, ldw = K rounded up to 64 (zero padded)
+        EG_REQUIRE((ldw & 63) == 0, EG_ERR_ALIGN, "%s: split-bf16 modes need ldw %% 64 == 0 (EG_PACK_LINEAR weights)", who);
+        const size_t rows = (size_t)eg_round_up(n, 64);
         a.whi = reinterpret_cast<const unsigned short*>(w + rows * ldw);
         a.wlo = a.whi + rows * ldw;
     }
@@ -225,7 +343,7 @@ extern "C" int eg_linear(const float* x, int32_t lda, const float* w, int32_t ld
     EG_REQUIRE(y, EG_ERR_BAD_ARG, "eg_linear: null output");
     EG_REQUIRE(a_shift == 0 || a_seq > 0, EG_ERR_BAD_ARG, "eg_linear: a_seq must be positive when a_shift is set");
     a.bias = bias; a.res1 = res1; a.res2 = res2; a.ldr = ldr; a.y = y; a.ldc = ldc; a.relu = relu;
-    a.a_shift = a_shift; a.a_seq = a_seq > 0 ? a_seq : 1; a.k_per_split = (int)eg_round_up(k, 32); a.partial = nullptr;
+    a.a_shift = a_shift; a.a_seq = a_seq > 0 ? a_seq : 1; a.k_per_split = (int)eg_round_up(k, 64); a.partial = nullptr;
     EgProfScope prof(2, 2.0 * m * (double)n * k, (hipStream_t)stream);
     return launch_gemm(a, 1, precision, (hipStream_t)stream);
 }
@@ -239,7 +357,7 @@ extern "C" int eg_linear_splitk(const float* x, int32_t lda, const float* w, int
     EG_REQUIRE(y && partial && splits > 0, EG_ERR_BAD_ARG, "eg_linear_splitk: null output/partial");
     a.bias = nullptr; a.res1 = a.res2 = nullptr; a.ldr = 0; a.y = y; a.ldc = ldc; a.relu = 0;
     a.a_shift = 0; a.a_seq = 1; a.partial = partial;
-    a.k_per_split = (int)eg_round_up(eg_cdiv(k, splits), 32);
+    a.k_per_split = (int)eg_round_up(eg_cdiv(k, splits), 64);
     const int nsplit = eg_cdiv(k, a.k_per_split);
     rc = launch_gemm(a, nsplit, precision, (hipStream_t)stream);
     if (rc) return rc;

@@ -131,8 +131,8 @@ struct FfnW { LinW w1, w2; int64_t ln_g, ln_b; };
 LinW add_linear(Layout& L, const std::string& prefix, int n, int k, bool bias, int kpad_force = 0, int npad_force = 0) {
     LinW w;
     w.n = n; w.k = k;
-    w.npad = npad_force ? npad_force : (int)eg_round_up(n, 16);
-    w.kpad = kpad_force ? kpad_force : (int)eg_round_up(k, 8);
+    w.npad = npad_force ? npad_force : (int)eg_round_up(n, 64);
+    w.kpad = kpad_force ? kpad_force : (int)eg_round_up(k, 64);
     w.w = L.add(prefix + ".weight", EG_PACK_LINEAR, n, k, w.npad, w.kpad, (int64_t)w.npad * w.kpad * 2);
     if (bias) w.b = L.vec(prefix + ".bias", n, w.npad);
     return w;
@@ -426,8 +426,8 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     g->H3 = (g->H2 - 1) / 2 + 1; g->W3 = (g->W2 - 1) / 2 + 1;
     g->HW3 = g->H3 * g->W3;
     if (g->HW3 % 8 != 0) { delete g; eg_set_error("config: final map %dx%d not a multiple of 8", g->H3, g->W3); return EG_ERR_UNSUPPORTED; }
-    g->Dpad = (int)eg_round_up(c.pose_dim, 16);
-    g->Cpad = (int)eg_round_up(c.tcn_hidden, 8);
+    g->Dpad = (int)eg_round_up(c.pose_dim, 64);
+    g->Cpad = (int)eg_round_up(c.tcn_hidden, 64);
     Layout& L = g->L;
     const int D = c.d_model, F = c.frames, P_ = c.prior_frames, PL = F - P_, PD = c.pose_dim;
     // --- audio tower (keys: audio_encoder.feat_extractor.*)
@@ -510,7 +510,7 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
         for (int j = 1; j <= 2; ++j) {
             EgGenerator::TcnConv tc;
             const std::string p = "text_encoder.tcn.network." + std::to_string(i) + ".conv" + std::to_string(j);
-            const int C = c.tcn_hidden, npad = (int)eg_round_up(C, 16);
+            const int C = c.tcn_hidden, npad = (int)eg_round_up(C, 64);
             for (int tap = 0; tap < 2; ++tap) {
                 LinW w;
                 w.n = C; w.k = C; w.npad = npad; w.kpad = g->Cpad;

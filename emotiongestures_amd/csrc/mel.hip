@@ -16,7 +16,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ audio, int n_samples, const float* __restrict__ melfb_t,
                                                         const float* __restrict__ window, const float* __restrict__ twiddle,
-                                                        float* __restrict__ melpow, int n_frames) {
+                                                        const int* __restrict__ band, float* __restrict__ melpow, int n_frames) {
     __shared__ float re[1024], im[1024], part[256];
     const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float* clip = audio + (size_t)b * n_samples;
@@ -57,9 +57,11 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
     re[tid] = p0; re[tid + 256] = p1;
     if (tid == 0) re[512] = p2;
     __syncthreads();
-    // mel projection: thread (m = tid&127, half = tid>>7) sums its half of the 513 bins
+    // mel projection: the Slaney filters are triangles, so mel m only touches bins [band[2m], band[2m+1]) (~2*513 non-zeros
+    // in total instead of 128*513); thread (m = tid&127, half = tid>>7) sums its half of that band
     const int m = tid & 127, hf = tid >> 7;
-    const int kb = hf ? 257 : 0, ke = hf ? 513 : 257;
+    const int b0 = band[2 * m], b1 = band[2 * m + 1], bm = (b0 + b1) >> 1;
+    const int kb = hf ? bm : b0, ke = hf ? b1 : bm;
     float s = 0.f;
     for (int k = kb; k < ke; ++k) s += melfb_t[k * 128 + m] * re[k];
     part[tid] = s;
@@ -101,9 +103,10 @@ double mel_to_hz(double m) {
 
 }  // namespace
 
-// Host tables: Slaney mel filterbank TRANSPOSED [513][128], periodic Hann [1024], twiddles (cos, -sin) [512][2].
-extern "C" int eg_mel_tables(float* h_melfb_t, float* h_window, float* h_twiddle) {
-    EG_REQUIRE(h_melfb_t && h_window && h_twiddle, EG_ERR_BAD_ARG, "eg_mel_tables: null pointer");
+// Host tables: Slaney mel filterbank TRANSPOSED [513][128], periodic Hann [1024], twiddles (cos, -sin) [512][2],
+// per-mel non-zero bin range [128][2] (begin, end).
+extern "C" int eg_mel_tables(float* h_melfb_t, float* h_window, float* h_twiddle, int32_t* h_band) {
+    EG_REQUIRE(h_melfb_t && h_window && h_twiddle && h_band, EG_ERR_BAD_ARG, "eg_mel_tables: null pointer");
     const int n_mels = 128, n_bins = 513;
     const double sr = 16000.0;
     double hz[130];
@@ -119,6 +122,11 @@ extern "C" int eg_mel_tables(float* h_melfb_t, float* h_window, float* h_twiddle
             if (w < 0) w = 0;
             h_melfb_t[k * 128 + m] = (float)(w * enorm);
         }
+        int lo = n_bins, hi = 0;
+        for (int k = 0; k < n_bins; ++k)
+            if (h_melfb_t[k * 128 + m] != 0.f) { if (k < lo) lo = k; hi = k + 1; }
+        if (lo > hi) lo = hi = 0;
+        h_band[2 * m] = lo; h_band[2 * m + 1] = hi;
     }
     const double pi = 3.14159265358979323846;
     for (int i = 0; i < 1024; ++i) h_window[i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / 1024.0));
@@ -135,9 +143,9 @@ extern "C" int64_t eg_mel_workspace_bytes(int32_t batch, int32_t n_samples) {
 }
 
 extern "C" int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_samples, const float* d_melfb_t,
-                                 const float* d_window, const float* d_twiddle, float* spec, int32_t out_frames,
+                                 const float* d_window, const float* d_twiddle, const int32_t* d_band, float* spec, int32_t out_frames,
                                  void* workspace, int64_t workspace_bytes, void* stream) {
-    EG_REQUIRE(audio && d_melfb_t && d_window && d_twiddle && spec && workspace, EG_ERR_BAD_ARG, "eg_melspectrogram: null pointer");
+    EG_REQUIRE(audio && d_melfb_t && d_window && d_twiddle && d_band && spec && workspace, EG_ERR_BAD_ARG, "eg_melspectrogram: null pointer");
     EG_REQUIRE(batch > 0 && n_samples >= 512, EG_ERR_BAD_ARG, "eg_melspectrogram: batch=%d n_samples=%d", batch, n_samples);
     const int n_frames = 1 + n_samples / 512;
     EG_REQUIRE(out_frames > 0 && out_frames <= n_frames, EG_ERR_BAD_ARG, "eg_melspectrogram: out_frames=%d of %d", out_frames, n_frames);
@@ -145,7 +153,7 @@ extern "C" int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_sa
     hipStream_t st = (hipStream_t)stream;
     float* melpow = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(mel_power_kernel, dim3(n_frames, batch), dim3(256), 0, st, audio, n_samples, d_melfb_t, d_window, d_twiddle,
-                       melpow, n_frames);
+                       d_band, melpow, n_frames);
     int rc = eg_check_launch("mel_power");
     if (rc) return rc;
     hipLaunchKernelGGL(mel_db_kernel, dim3(batch), dim3(256), 0, st, melpow, spec, n_frames, out_frames);

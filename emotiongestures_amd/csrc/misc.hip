@@ -300,35 +300,52 @@ __global__ __launch_bounds__(64) void tm_apply_kernel(const float* __restrict__ 
 
 // ---- CVAE 1-D convolutions (CAVE/BEAT_CVAE.py:318-332,355-369), layout [n][C][L] ----------------------------
 // y[n,co,l] = post( bias[co] + sum_{ci,k} w[co,ci,k] x[n,ci,l*stride + k - pad] );  post = LeakyReLU(0.2) then BN affine
-// One workgroup = (sample, 128-wide l tile); the input tile lives in LDS; every thread of the workgroup works on
-// the same co at a time so the weight reads are wave-uniform (scalar loads).
-__global__ __launch_bounds__(128) void conv1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// One workgroup = (sample, 64 output positions, 4*COG output channels): the input tile lives in LDS, each wave owns
+// COG output channels (wave-uniform => the weight reads are scalar loads) accumulated in registers, so every LDS read of
+// x is reused COG times.
+template <int COG>
+__global__ __launch_bounds__(256) void conv1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout,
                                                      int Lin, int Lout, int K, int stride, int pad, int act) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int n = blockIdx.y, l0 = blockIdx.x * 128, tid = threadIdx.x;
-    const int span = 127 * stride + K;              // input columns needed by this tile
+    const int n = blockIdx.y, l0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int span = 63 * stride + K;
     const int in0 = l0 * stride - pad;
-    for (int i = tid; i < Cin * span; i += 128) {
+    for (int i = tid; i < Cin * span; i += 256) {
         const int ci = i / span, j = i - ci * span, gl = in0 + j;
         sm[i] = (gl >= 0 && gl < Lin) ? x[((size_t)n * Cin + ci) * Lin + gl] : 0.f;
     }
     __syncthreads();
-    const int l = l0 + tid;
+    const int co0 = (blockIdx.z * 4 + wave) * COG;
+    const int l = l0 + lane;
+    float acc[COG];
+#pragma unroll
+    for (int j = 0; j < COG; ++j) acc[j] = (co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xp = sm + ci * span + lane * stride;
+        for (int k = 0; k < K; ++k) {
+            const float xv = xp[k];
+#pragma unroll
+            for (int j = 0; j < COG; ++j) {
+                const int co = co0 + j < Cout ? co0 + j : Cout - 1;
+                acc[j] += w[((size_t)co * Cin + ci) * K + k] * xv;
+            }
+        }
+    }
     if (l >= Lout) return;
-    for (int co = 0; co < Cout; ++co) {
-        float s = bias[co];
-        const float* wr = w + (size_t)co * Cin * K;
-        for (int ci = 0; ci < Cin; ++ci) {
-            const float* xp = sm + ci * span + tid * stride;
-            for (int k = 0; k < K; ++k) s += wr[ci * K + k] * xp[k];
+#pragma unroll
+    for (int j = 0; j < COG; ++j) {
+        const int co = co0 + j;
+        if (co < Cout) {
+            float s = acc[j];
+            if (act) {
+                s = s > 0.f ? s : 0.2f * s;
+                s = s * scale[co] + shift[co];
+            }
+            y[((size_t)n * Cout + co) * Lout + l] = s;
         }
-        if (act) {
-            s = s > 0.f ? s : 0.2f * s;
-            s = s * scale[co] + shift[co];
-        }
-        y[((size_t)n * Cout + co) * Lout + l] = s;
     }
 }
 
@@ -512,16 +529,17 @@ int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float*
 int egi_conv1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int n, int cin,
                int cout, int lin, int k, int stride, int pad, int act, hipStream_t st) {
     const int lout = (lin + 2 * pad - k) / stride + 1;
-    const size_t smem = sizeof(float) * (size_t)cin * (127 * stride + k);
-    if (smem > 64 * 1024) {
-        static bool once = false;
-        if (!once) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            once = true;
-        }
-    }
-    hipLaunchKernelGGL(conv1d_kernel, dim3(eg_cdiv(lout, 128), n), dim3(128), smem, st, x, w, bias, scale, shift, y, cin, cout, lin,
-                       lout, k, stride, pad, act);
+    const size_t smem = sizeof(float) * (size_t)cin * (63 * stride + k);
+    if (smem > 64 * 1024) { eg_set_error("conv1d: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
+    const int per_wave = eg_cdiv(cout, 4);
+    const int cog = per_wave <= 4 ? 4 : (per_wave <= 8 ? 8 : 16);
+    dim3 grid(eg_cdiv(lout, 64), n, eg_cdiv(cout, 4 * cog));
+    if (cog == 4)
+        hipLaunchKernelGGL((conv1d_kernel<4>), grid, dim3(256), smem, st, x, w, bias, scale, shift, y, cin, cout, lin, lout, k, stride, pad, act);
+    else if (cog == 8)
+        hipLaunchKernelGGL((conv1d_kernel<8>), grid, dim3(256), smem, st, x, w, bias, scale, shift, y, cin, cout, lin, lout, k, stride, pad, act);
+    else
+        hipLaunchKernelGGL((conv1d_kernel<16>), grid, dim3(256), smem, st, x, w, bias, scale, shift, y, cin, cout, lin, lout, k, stride, pad, act);
     return eg_check_launch("conv1d");
 }
 int egi_convt1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int n, int cin,

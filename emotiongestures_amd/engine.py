@@ -198,9 +198,10 @@ class MelFrontEnd:
         import numpy as np
         lib = L.load()
         fb, win, tw = np.zeros(513 * 128, np.float32), np.zeros(1024, np.float32), np.zeros(1024, np.float32)
-        L.check(lib.eg_mel_tables(fb.ctypes.data_as(C.c_void_p), win.ctypes.data_as(C.c_void_p), tw.ctypes.data_as(C.c_void_p)),
-                "eg_mel_tables")
-        self.fb, self.win, self.tw = (torch.from_numpy(a).to(device) for a in (fb, win, tw))
+        band = np.zeros(256, np.int32)
+        L.check(lib.eg_mel_tables(fb.ctypes.data_as(C.c_void_p), win.ctypes.data_as(C.c_void_p), tw.ctypes.data_as(C.c_void_p),
+                                  band.ctypes.data_as(C.c_void_p)), "eg_mel_tables")
+        self.fb, self.win, self.tw, self.band = (torch.from_numpy(a).to(device) for a in (fb, win, tw, band))
         self._lib, self.device, self._ws = lib, torch.device(device), {}
 
     def __call__(self, audio: torch.Tensor, out_frames: Optional[int] = None) -> torch.Tensor:
@@ -214,6 +215,6 @@ class MelFrontEnd:
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
             self._ws[(B, n)] = ws
         spec = torch.empty(B, 128, out_frames, device=self.device)
-        L.check(self._lib.eg_melspectrogram(_ptr(audio), B, n, _ptr(self.fb), _ptr(self.win), _ptr(self.tw), _ptr(spec), out_frames,
+        L.check(self._lib.eg_melspectrogram(_ptr(audio), B, n, _ptr(self.fb), _ptr(self.win), _ptr(self.tw), _ptr(self.band), _ptr(spec), out_frames,
                                             _ptr(ws), nbytes, _stream(self.device)), "eg_melspectrogram")
         return spec

@@ -22,9 +22,9 @@ def _dev(t):
 
 
 def pack_linear_weight(w: torch.Tensor, device) -> torch.Tensor:
-    """nn.Linear weight [N,K] -> EG_PACK_LINEAR image on `device` (rows padded to 16, K to 8)."""
+    """nn.Linear weight [N,K] -> EG_PACK_LINEAR image on `device` (rows and K padded to 64)."""
     n, k = w.shape
-    npad, kpad = (n + 15) // 16 * 16, (k + 7) // 8 * 8
+    npad, kpad = (n + 63) // 64 * 64, (k + 63) // 64 * 64
     return torch.from_numpy(packing._pack_linear(w.detach().cpu().float(), npad, kpad)).to(device), npad, kpad
 
 
@@ -201,7 +201,7 @@ def pack_tcn_weights(levels, device):
             v, g = v.detach().cpu().float(), g.detach().cpu().float()
             w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
             c = w.shape[0]
-            npad, cpad = (c + 15) // 16 * 16, (c + 7) // 8 * 8
+            npad, cpad = (c + 63) // 64 * 64, (c + 63) // 64 * 64
             for tap in range(2):
                 chunks.append(packing._pack_linear(w[:, :, tap].contiguous(), npad, cpad))
             bb = np.zeros(npad, np.float32)
@@ -216,7 +216,7 @@ def tcn_forward(x_blc, packed_w, levels: int, precision="f32"):
     x = _need_cuda(x_blc, "x")
     dev = x.device
     B, Ln, Cc = x.shape
-    cpad = (Cc + 7) // 8 * 8
+    cpad = (Cc + 63) // 64 * 64
     xp = torch.zeros(B, Ln, cpad, device=dev)
     xp[:, :, :Cc] = x
     y = torch.zeros(B, Ln, cpad, device=dev)

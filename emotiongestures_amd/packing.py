@@ -36,10 +36,14 @@ def _with_bf16_images(f32_img: np.ndarray, hi_bits: np.ndarray, lo_bits: np.ndar
 
 
 def _pack_linear(w: torch.Tensor, npad: int, kpad: int) -> np.ndarray:
+    """fp32 image [npad][kpad] row-major, then bf16 hi / lo images tile-planar [npad/64][kpad/8][64 rows][8]
+    (one K-step's 8 octets of a 64-row tile are 8 contiguous 1-KiB pieces for global_load_lds)."""
     n, k = w.shape
+    assert npad % 64 == 0 and kpad % 64 == 0
     p = torch.zeros(npad, kpad, dtype=torch.float32)
     p[:n, :k] = w
-    hi, lo = _bf16_split_bits(p)
+    t = p.reshape(npad // 64, 64, kpad // 8, 8).permute(0, 2, 1, 3).contiguous()
+    hi, lo = _bf16_split_bits(t)
     return _with_bf16_images(p.numpy(), hi, lo)
 
 
@@ -89,7 +93,7 @@ def pack_entry(sd: Mapping[str, torch.Tensor], e: L.EgWeightEntry) -> np.ndarray
     elif kind == L.PACK_WN_TAP:
         g, v = _t(sd, key + ".weight_g"), _t(sd, key + ".weight_v")
         w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))          # torch weight_norm, dim=0 (tcn.py:19)
-        npad = (d[0] + 15) // 16 * 16
+        npad = (d[0] + 63) // 64 * 64
         out = _pack_linear(w[:, :, d[2]].contiguous(), npad, d[3])
     elif kind == L.PACK_POS_TABLE:
         out = _t(sd, key)[0, : d[0], :].contiguous().reshape(-1).numpy()

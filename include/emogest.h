@@ -73,7 +73,8 @@ int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacit
  * ------------------------------------------------------------------------------------------ */
 typedef enum EgPackKind {
     EG_PACK_RAW = 0,            /* tensor copied as is (row-major) */
-    EG_PACK_LINEAR = 1,         /* nn.Linear weight [N,K] -> [Npad,Kpad] zero padded (dims = N,K,Npad,Kpad) */
+    EG_PACK_LINEAR = 1,         /* nn.Linear weight [N,K] -> fp32 [Npad,Kpad] + tile-planar bf16 hi/lo images; Npad,Kpad % 64 == 0
+                                   (dims = N,K,Npad,Kpad; numel = 2*Npad*Kpad floats) */
     EG_PACK_VEC_PAD = 2,        /* 1-D tensor zero padded to dims[1] (dims = n, npad) */
     EG_PACK_CONV3X3 = 3,        /* Conv2d OIHW [O,I,3,3] -> [tap][I/4][Opad][4] (dims = O,I,Opad) */
     EG_PACK_BN_SCALE = 4,       /* key = BN prefix: weight/sqrt(running_var+eps), padded to dims[1] with 0 */
@@ -193,12 +194,14 @@ int eg_cvae_forward(const EgCvae* c, const float* arena, int32_t n, const float*
  * ------------------------------------------------------------------------------------------ */
 /* audio [B, n_samples] fp32 16 kHz -> spec [B, 128, out_frames] fp32 holding fp16-rounded dB.
  * n_fft 1024, hop 512, centred (zero pad), periodic Hann, 128 Slaney mels, power_to_db(ref=max, top_db=80).
- * d_melfb [128, 513] and d_window [1024] are caller-provided tables (eg_mel_tables fills host copies).
+ * d_melfb_t [513,128] (transposed filterbank), d_window [1024], d_twiddle [512,2], d_band [128,2] are caller-provided
+ * device copies of the tables eg_mel_tables fills on the host.
  * workspace >= eg_mel_workspace_bytes. */
-int eg_mel_tables(float* h_melfb /*128*513*/, float* h_window /*1024*/, float* h_twiddle /*2*512*/);
+int eg_mel_tables(float* h_melfb_t /*513*128, transposed*/, float* h_window /*1024*/, float* h_twiddle /*2*512*/,
+                  int32_t* h_band /*128*2: non-zero bin range of each mel filter*/);
 int64_t eg_mel_workspace_bytes(int32_t batch, int32_t n_samples);
-int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_samples, const float* d_melfb,
-                      const float* d_window, const float* d_twiddle, float* spec, int32_t out_frames,
+int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_samples, const float* d_melfb_t,
+                      const float* d_window, const float* d_twiddle, const int32_t* d_band, float* spec, int32_t out_frames,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -280,7 +283,7 @@ int eg_positionwise_ffn(const float* x, const float* w1, const float* b1, const 
 /* TemporalConvNet.forward (Full_model/tcn.py:63; TemporalBlock :43-47), channels-last:
  * x, y [B, L, C]; per level i (dilation 2^i) two weight-normed causal convs k=2 + ReLU, residual, ReLU.
  * w points at levels*2 convs, each {tap0 [C,Cpad], tap1 [C,Cpad], bias [C]} packed back to back
- * (EG_PACK_WN_TAP x2 + RAW); Cpad = C rounded up to 4.  workspace >= 4*B*L*Cpad floats. */
+ * (EG_PACK_WN_TAP x2 + RAW); Cpad = C rounded up to 64.  workspace >= 4*B*L*Cpad floats. */
 int eg_tcn_forward(const float* x, const float* w, float* y, int32_t batch, int32_t len, int32_t c,
                    int32_t levels, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
 
