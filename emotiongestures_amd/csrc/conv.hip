@@ -15,6 +15,10 @@
 //   D: each lane owns 4 consecutive output channels of one pixel -> one 16-byte NHWC store per tile.
 #include "common.h"
 
+#ifndef EG_CONV_RING
+#define EG_CONV_RING 3
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -167,8 +171,20 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 //    (pixel tile, channel tile) pair:  acc += Whi*Xhi + Whi*Xlo + Wlo*Xhi   (3 x v_mfma_f32_16x16x32_bf16).
 // Without the LDS weight ring every wave re-read all weights from L1/L2 (170 B/clk/CU demanded at C=128 vs 64 B/clk
 // of L1): the r01a profile's 115 us per 128->128 launch.
-template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS>
-__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
+__device__ __forceinline__ void wait_vmcnt(int n) {      // counted wait: all but the n youngest VMEM ops of this wave are done
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS, int RING>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
                                                            const bf8* __restrict__ wlo) {
     using G = ConvGeom<S, TH>;
     constexpr int COUTP = NTT * 16, IW = G::IW, NPIX = G::NPIX, PL = G::PL;
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
     constexpr int WBUF = NIMG * WIMG;
     constexpr int NSTEP = (CIN / 32) * 9;
     static_assert(WM * WN == 4 && MT * WM == TH * 2 && NT * WN == NTT, "wave tiling");
-    __shared__ bf8 lds[TILE + 2 * WBUF];
+    extern __shared__ __attribute__((aligned(16))) bf8 lds[];      // TILE + RING * WBUF slots (dynamic: can exceed 64 KB)
     bf8* tile = lds;
     bf8* wring = lds + TILE;
 
@@ -204,76 +220,112 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a, const bf8
     const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
 
     // one step's weights = NIMG runs of WIMG slots; 64-slot (1 KiB) pieces are dealt round-robin to the 4 waves
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int PIECES = WIMG / 64;
     auto issue_weights = [&](int step, int buf) {
         const int chunk = step / 9, tap = step - chunk * 9;
         const size_t gbase = ((size_t)tap * (CIN / 8) + chunk * 4) * COUTP;
-        constexpr int PIECES = WIMG / 64;
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
             const bf8* src = (img ? wlo : whi) + gbase;
 #pragma unroll
             for (int p = 0; p < (PIECES + 3) / 4; ++p) {
-                const int piece = p * 4 + wave;
-                if (piece < PIECES)
+                const int piece = p * 4 + wave_u;
+                if (PIECES % 4 == 0 || piece < PIECES)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
                                                      (__attribute__((address_space(3))) void*)(wring + buf * WBUF + img * WIMG + piece * 64),
                                                      16, 0, 0);
             }
         }
     };
-
-    issue_weights(0, 0);
-#pragma unroll 1
-    for (int chunk = 0; chunk < CIN / 32; ++chunk) {
-        // stage + split the (IH x IW) x 32-channel halo tile: one lane = one pixel x 8 channels
-        for (int idx = tid; idx < ((NPIX + 7) / 8) * 32; idx += 256) {
+    // halo tile staging, split in two so the HBM latency of chunk c+1 hides under the 9 taps of chunk c:
+    //   load_tile: (IH x IW) pixels x 32 channels -> registers (one lane = one pixel x 8 channels per iteration)
+    //   store_tile: split to (hi, lo) bf16 and write the channel-octet planar LDS image
+    constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;
+    f4 pv[NIT][2];
+    auto load_tile = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
+            const int iy = p / IW, ix = p - iy * IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            pv[it][0] = pv[it][1] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (p < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const float* src = xb + ((size_t)gy * a.W + gx) * CIN + chunk * 32 + oc * 8;
+                pv[it][0] = *reinterpret_cast<const f4*>(src);
+                pv[it][1] = *reinterpret_cast<const f4*>(src + 4);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
             const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
             if (p < NPIX) {
-                const int iy = p / IW, ix = p - iy * IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                f4 v0 = (f4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    const float* src = xb + ((size_t)gy * a.W + gx) * CIN + chunk * 32 + oc * 8;
-                    v0 = *reinterpret_cast<const f4*>(src);
-                    v1 = *reinterpret_cast<const f4*>(src + 4);
-                }
                 bf8 hi, lo;
-                split_octet<TERMS == 3>(v0, v1, hi, lo);
+                split_octet<TERMS == 3>(pv[it][0], pv[it][1], hi, lo);
                 tile[oc * PL + p] = hi;
                 if (TERMS == 3) tile[(4 + oc) * PL + p] = lo;
             }
         }
-        __syncthreads();                        // tile visible; also retires the weight copy of step chunk*9
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int step = chunk * 9 + tap, buf = step & 1;
-            if (step + 1 < NSTEP) issue_weights(step + 1, buf ^ 1);
-            const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
-            const bf8* Wh = wring + buf * WBUF + kq * COUTP + wn * NT * 16 + li;
-            bf8 wh[NT], wl[NT], xh[MT], xl[MT];
+    };
+
+    // glds instructions this wave issues per step (pieces are dealt round-robin, so it can differ by wave)
+    // Schedule (3-slot weight ring, fragments double-buffered in registers, taps fully unrolled):
+    //   step s:  issue the weight copy of step s+2  ->  read step s+1's fragments from LDS (in flight during ...)
+    //            ... the MFMAs of step s  ->  vmcnt(0) + barrier (copies of s+1, s+2 landed; slot of s is free)
+    // so neither the LDS fragment reads nor the global->LDS weight copies sit on the MFMA critical path.
+    struct Frags { bf8 wh[NT], wl[NT], xh[MT], xl[MT]; };
+    auto read_frags = [&](Frags& f, int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
+        const bf8* Wh = wring + (tap % 3) * WBUF + kq * COUTP + wn * NT * 16 + li;      // step % 3 == tap % 3 (9 taps per chunk)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f.wh[n] = Wh[n * 16];
+            if (TERMS == 3) f.wl[n] = Wh[WIMG + n * 16];
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            f.xh[t] = tile[kq * PL + pbase[t] + toff];
+            if (TERMS == 3) f.xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
+        }
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                wh[n] = Wh[n * 16];
-                if (TERMS == 3) wl[n] = Wh[WIMG + n * 16];
-            }
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                xh[t] = tile[kq * PL + pbase[t] + toff];
-                if (TERMS == 3) xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
-            }
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    if (TERMS == 3) {
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
-                    }
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+                if (TERMS == 3) {
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[n], f.xh[t], acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[t][n], 0, 0, 0);
                 }
-            __syncthreads();                    // next step's weights landed; this step's buffers are free
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
+            }
+    };
+    static_assert(RING == 3, "schedule below assumes a 3-slot ring");
+    issue_weights(0, 0);
+    if (NSTEP > 1) issue_weights(1, 1);
+    load_tile(0);
+    Frags fr[2];
+#pragma unroll 1
+    for (int chunk = 0; chunk < CIN / 32; ++chunk) {
+        store_tile();
+        __syncthreads();                        // tile visible; every weight copy issued so far has landed
+        if (chunk + 1 < CIN / 32) load_tile(chunk + 1);
+        read_frags(fr[0], 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int step = chunk * 9 + tap;
+            if (step + 2 < NSTEP) issue_weights(step + 2, (tap + 2) % 3);
+            if (tap < 8) read_frags(fr[(tap + 1) & 1], tap + 1);
+            mfma_step(fr[tap & 1]);
+            __syncthreads();                    // vmcnt(0): copies of steps s+1, s+2 landed; slot s and (after tap 8) the tile are free
         }
     }
+
+
 
     f4 gsum[NT];
 #pragma unroll
@@ -443,22 +495,40 @@ __global__ __launch_bounds__(256) void se_tail_downsample_kernel(const float* __
     }
 }
 
+template <int CIN, int NT, int S, int TH, int WM, int WN, int TERMS>
+int launch_conv_bf16(const ConvArgs& a, const bf8* whi, const bf8* wlo, dim3 grid, hipStream_t st) {
+    // weight-ring depth: 3 where the K loop is long (C >= 64, stride 1); 2 for the HBM-bound C=32 layer and the
+    // stride-2 entries (smaller LDS footprint => one more workgroup per CU)
+    constexpr int RING = 3;
+    using G = ConvGeom<S, TH>;
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + RING * NIMG * 4 * NT * 16);
+    auto kern = conv3x3_bf16_kernel<CIN, NT, S, TH, WM, WN, TERMS, RING>;
+    static bool attr_done = false;
+    if (!attr_done && LDS_BYTES > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
+            eg_set_error("conv3x3: cannot reserve %zu B of LDS", LDS_BYTES);
+            return EG_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, whi, wlo);
+    return eg_check_launch("conv3x3");
+}
+
 template <int CIN, int NT, int S, int TH, int WM, int WN>
 int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
     dim3 grid(a.tiles, batch), block(256);
     if (precision == EG_PREC_F32) {
         hipLaunchKernelGGL((conv3x3_f32_kernel<CIN, NT, S, TH>), grid, block, 0, st, a);
-    } else {
-        // packed bf16 weights follow the fp32 image in the arena: [hi image][lo image], each 9*CIN*COUTP bf16
-        const size_t f32_floats = (size_t)9 * CIN * NT * 16;
-        const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
-        const bf8* wlo = whi + (size_t)9 * (CIN / 8) * NT * 16;
-        if (precision == EG_PREC_BF16X3)
-            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, WM, WN, 3>), grid, block, 0, st, a, whi, wlo);
-        else
-            hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, S, TH, WM, WN, 1>), grid, block, 0, st, a, whi, wlo);
+        return eg_check_launch("conv3x3");
     }
-    return eg_check_launch("conv3x3");
+    // packed bf16 weights follow the fp32 image in the arena: [hi image][lo image], each 9*CIN*COUTP bf16
+    const size_t f32_floats = (size_t)9 * CIN * NT * 16;
+    const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
+    const bf8* wlo = whi + (size_t)9 * (CIN / 8) * NT * 16;
+    if (precision == EG_PREC_BF16X3) return launch_conv_bf16<CIN, NT, S, TH, WM, WN, 3>(a, whi, wlo, grid, st);
+    return launch_conv_bf16<CIN, NT, S, TH, WM, WN, 1>(a, whi, wlo, grid, st);
 }
 
 int conv_tile_rows(int cin, int cout, int stride) {
