@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--precision", default=os.environ.get("EG_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-concurrent", action="store_true", help="keep the independent branches on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -122,15 +124,45 @@ def main():
     from emotiongestures_amd import _lib
     lib = _lib.load()
     gen, vae, mel, sd_g, sd_v = build_models(args.precision, dev)
+    gen.concurrent = not args.no_concurrent
     B = args.batch
     inp = make_inputs(B, seed=1000 + rank)          # every rank generates its own shard of clips
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
 
+    side = torch.cuda.Stream(dev) if gen.concurrent else None
+
     def step():
         with torch.no_grad():
-            spec = mel(g["audio"], out_frames=124)
-            sampled = vae.sample(g["label"], z=g["z"])
+            cur = torch.cuda.current_stream(dev)
+            if side is not None:            # the CVAE draw does not depend on the audio: fork it beside the mel front-end
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    sampled = vae.sample(g["label"], z=g["z"])
+                spec = mel(g["audio"], out_frames=124)
+                cur.wait_stream(side)
+            else:
+                spec = mel(g["audio"], out_frames=124)
+                sampled = vae.sample(g["label"], z=g["z"])
             return gen(spec, g["text"], g["pre_pose"], sampled)
+
+    eager_step = step
+    graph = None
+    if not args.no_graph:
+        # capture one step (all ~230 launches + the fork/join of the side streams) into a hipGraph and replay it
+        cap = torch.cuda.Stream(dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
+            for _ in range(2):
+                eager_step()              # allocate workspaces / set kernel attributes outside the capture
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = eager_step()
+
+        def step():                         # noqa: F811
+            graph.replay()
+            return graph_out
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -172,7 +204,7 @@ def main():
         cap = 400 * max(args.steps, 1)
         _lib.check(lib.eg_profile_enable(cap), "eg_profile_enable")
         for _ in range(args.steps):
-            step()
+            eager_step()                    # per-launch event timing runs eagerly (events are not part of the graph)
         torch.cuda.synchronize(dev)
         lib.eg_profile_disable()
         tags = np.zeros(cap, np.int64); fl = np.zeros(cap, np.float64); ms = np.zeros(cap, np.float32)
@@ -207,6 +239,8 @@ def main():
             "config": {"workload": "TED clips: 4 s 16 kHz audio -> mel(128x124) -> CVAE sample -> generator -> 34x126 pose",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "variant": "Models_spatial_memory",
                        "parallelism": f"clip-sharded x{world}, no data-path collective",
+                       "launch": "eager" if graph is None else "hipGraph replay",
+                       "branch_streams": bool(gen.concurrent),
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
             "pose_rel_l2_vs_cpu_oracle": parity, "roofline": roof, "cpu_baseline": cpu,
         }

@@ -125,7 +125,7 @@ struct BlockW {
     int64_t ds_w = -1, ds_scale = -1, ds_shift = -1;
     int cin, cout, stride;
 };
-struct MhaW { LinW q, k, v, o; int64_t ln_g, ln_b; };
+struct MhaW { LinW q, kv, qkv, o; int64_t ln_g, ln_b; };
 struct FfnW { LinW w1, w2; int64_t ln_g, ln_b; };
 
 LinW add_linear(Layout& L, const std::string& prefix, int n, int k, bool bias, int kpad_force = 0, int npad_force = 0) {
@@ -147,11 +147,30 @@ void add_bn(Layout& L, const std::string& prefix, int n, int npad, int64_t& scal
     scale = L.add(prefix, EG_PACK_BN_SCALE, n, npad, 0, 0, npad);
     shift = L.add(prefix, EG_PACK_BN_SHIFT, n, npad, 0, 0, npad);
 }
-MhaW add_mha(Layout& L, const std::string& p, int d) {
+// several nn.Linear weights sharing one input, concatenated along N into one packed image (keys joined by '|'):
+// one launch with `count` times the workgroups instead of `count` small launches
+LinW add_linear_cat(Layout& L, const std::vector<std::string>& prefixes, int n_each, int k, bool bias) {
+    LinW w;
+    const int n = n_each * (int)prefixes.size();
+    w.n = n; w.k = k; w.npad = (int)eg_round_up(n, 64); w.kpad = (int)eg_round_up(k, 64);
+    std::string wk, bk;
+    for (size_t i = 0; i < prefixes.size(); ++i) {
+        wk += (i ? "|" : "") + prefixes[i] + ".weight";
+        bk += (i ? "|" : "") + prefixes[i] + ".bias";
+    }
+    w.w = L.add(wk, EG_PACK_LINEAR, n, k, w.npad, w.kpad, (int64_t)w.npad * w.kpad * 2);
+    if (bias) w.b = L.vec(bk, n, w.npad);
+    return w;
+}
+// self_attn: fused Q|K|V projection of one input; cross attention: Q alone, K|V of the encoder output
+MhaW add_mha(Layout& L, const std::string& p, int d, bool self_attn) {
     MhaW m;
-    m.q = add_linear(L, p + ".w_qs", d, d, false);
-    m.k = add_linear(L, p + ".w_ks", d, d, false);
-    m.v = add_linear(L, p + ".w_vs", d, d, false);
+    if (self_attn) {
+        m.qkv = add_linear_cat(L, {p + ".w_qs", p + ".w_ks", p + ".w_vs"}, d, d, false);
+    } else {
+        m.q = add_linear(L, p + ".w_qs", d, d, false);
+        m.kv = add_linear_cat(L, {p + ".w_ks", p + ".w_vs"}, d, d, false);
+    }
     m.o = add_linear(L, p + ".fc", d, d, false);
     m.ln_g = L.raw(p + ".layer_norm.weight", d);
     m.ln_b = L.raw(p + ".layer_norm.bias", d);
@@ -187,7 +206,7 @@ struct EgGenerator {
     int64_t stem_w, stem_b, stem_scale, stem_shift;
     std::vector<BlockW> blocks;
     ConvW final_conv;
-    LinW a_fc1, a_fc2, emo0, emo2, sem0, sem2, fus0, fus2, cls[4], post[4], prior_h0, prior_h2, txt_dec;
+    LinW a_fc1, a_fc2, emosem0, emo2, sem2, fus0, fus2, cls[4], post[4], prior_h0, prior_h2, txt_dec;
     int64_t pos_table;
     std::vector<MhaW> enc_attn, dec_attn;
     std::vector<FfnW> enc_ffn, dec_ffn;
@@ -201,13 +220,38 @@ struct EgGenerator {
     int64_t txt_fc1_w, txt_fc1_b;
     int Cpad;   // padded TCN channel stride
     bool keep_taps = false;
+    // optional branch concurrency (cfg.reserved[1]): the text branch and the prior encoder are independent of the audio
+    // tower (Models_spatial_memory.py:577-585), so they are forked onto two library-owned side streams and joined back
+    // with events (capturable into a hipGraph as a fork/join).  Created lazily; no device memory involved.
+    bool concurrent = false;
+    mutable hipStream_t side[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int ensure_streams() const {
+        if (side[0]) return EG_OK;
+        for (int i = 0; i < 2; ++i) {
+            if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) {
+                eg_set_error("cannot create side stream/event");
+                return EG_ERR_HIP;
+            }
+        }
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { eg_set_error("cannot create event"); return EG_ERR_HIP; }
+        return EG_OK;
+    }
+    ~EgGenerator() {
+        for (int i = 0; i < 2; ++i) {
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+    }
 };
 
 namespace {
 
 struct GenWs {      // byte offsets into the workspace, for a given batch
     int64_t act[3], gap, gate, amap, afc1, afeat, emo_t, emo, sem_t, sem, cls_part, cls_h[3], cls_out;
-    int64_t fus_in, fus_h, fusion, xa, xb, q, k, v, ao, proj, ffn_h;
+    int64_t fus_in, fus_h, fusion, xa, xb, q, qkv, ao, proj, ffn_h;
     int64_t prior_cat, prior_h, prior_enc, prior_rep, tm_mem, tm_pe, tm_gram, post_a, post_b, post_c, pose;
     int64_t t_emb, t_a, t_b, t_c, t_out;
     int64_t tap_stem, tap_l[3];
@@ -226,13 +270,13 @@ GenWs carve(const EgGenerator* g, int B, int NB = 0) {
     w.gate = cv.take((int64_t)B * 128);
     w.amap = cv.take(BF * g->HW3);
     w.afc1 = cv.take(BF * D); w.afeat = cv.take(BF * D);
-    w.emo_t = cv.take(BF * D); w.emo = cv.take(BF * D); w.sem_t = cv.take(BF * D); w.sem = cv.take(BF * D);
+    w.emo_t = cv.take(BF * D * 2); w.emo = cv.take(BF * D); w.sem_t = cv.take(16); w.sem = cv.take(BF * D);
     w.cls_part = cv.take((int64_t)64 * B * D);
     w.cls_h[0] = cv.take((int64_t)B * D); w.cls_h[1] = cv.take((int64_t)B * 256); w.cls_h[2] = cv.take((int64_t)B * 64);
     w.cls_out = cv.take((int64_t)B * 16);
     w.fus_in = cv.take(NF * D); w.fus_h = cv.take(NF * D); w.fusion = cv.take(NF * D);
     w.xa = cv.take(NF * D); w.xb = cv.take(NF * D);
-    w.q = cv.take(NF * D); w.k = cv.take(NF * D); w.v = cv.take(NF * D); w.ao = cv.take(NF * D); w.proj = cv.take(NF * D);
+    w.q = cv.take(NF * D); w.qkv = cv.take(NF * D * 3); w.ao = cv.take(NF * D); w.proj = cv.take(NF * D);
     w.ffn_h = cv.take(NF * c.d_inner);
     w.prior_cat = cv.take(BF * g->Dpad); w.prior_h = cv.take(BF * D); w.prior_enc = cv.take(BF * D);
     w.prior_rep = cv.take(NB > B ? NF * D : 16);
@@ -266,14 +310,20 @@ int run_conv(const float* arena, const ConvW& c, const float* x, float* y, float
                       c.shift >= 0 ? arena + c.shift : nullptr, y, gap, B, h, w, c.cin, c.cout, c.stride, relu, nchw, prec, st);
 }
 
+// MultiHeadAttention.forward (SubLayers.py:30-59).  xkv == nullptr: self attention (fused Q|K|V projection of xq).
 int run_mha(const EgGenerator* g, const float* arena, const MhaW& m, const float* xq, const float* xkv, float* out, const GenWs& w,
             void* ws, int B, int Lq, int Lk, hipStream_t st) {
     const int D = g->cfg.d_model, prec = g->cfg.precision;
-    float *q = P(ws, w.q), *k = P(ws, w.k), *v = P(ws, w.v), *ao = P(ws, w.ao), *pr = P(ws, w.proj);
-    EG_TRY(run_linear(arena, m.q, xq, D, q, D, B * Lq, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, m.k, xkv, D, k, D, B * Lk, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, m.v, xkv, D, v, D, B * Lk, 0, nullptr, 0, prec, st));
-    EG_TRY(eg_attention(q, D, k, D, v, D, ao, D, nullptr, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
+    float *qkv = P(ws, w.qkv), *ao = P(ws, w.ao), *pr = P(ws, w.proj);
+    if (!xkv) {
+        EG_TRY(run_linear(arena, m.qkv, xq, D, qkv, 3 * D, B * Lq, 0, nullptr, 0, prec, st));
+        EG_TRY(eg_attention(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, ao, D, nullptr, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
+    } else {
+        float* q = P(ws, w.q);
+        EG_TRY(run_linear(arena, m.q, xq, D, q, D, B * Lq, 0, nullptr, 0, prec, st));
+        EG_TRY(run_linear(arena, m.kv, xkv, D, qkv, 2 * D, B * Lk, 0, nullptr, 0, prec, st));
+        EG_TRY(eg_attention(q, D, qkv, 2 * D, qkv + D, 2 * D, ao, D, nullptr, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
+    }
     EG_TRY(run_linear(arena, m.o, ao, D, pr, D, B * Lq, 0, xq, D, prec, st));
     return eg_layernorm(pr, arena + m.ln_g, arena + m.ln_b, out, B * Lq, D, 1e-6f, st);
 }
@@ -370,7 +420,7 @@ int run_transformer(const EgGenerator* g, const float* arena, const float* fusio
     float *xa = P(ws, w.xa), *xb = P(ws, w.xb);
     EG_TRY(egi_add(P(ws, w.fusion), arena + g->pos_table, xa, (size_t)rows * D, D, F, st));
     for (int l = 0; l < c.n_layers; ++l) {
-        EG_TRY(run_mha(g, arena, g->enc_attn[l], xa, xa, xb, w, ws, NB, F, F, st));
+        EG_TRY(run_mha(g, arena, g->enc_attn[l], xa, nullptr, xb, w, ws, NB, F, F, st));
         EG_TRY(run_ffn(g, arena, g->enc_ffn[l], xb, xa, w, ws, rows, st));
     }
     // encoder output now in xa; decoder stream starts from prior_enc
@@ -420,6 +470,7 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     EgGenerator* g = new EgGenerator();
     g->cfg = *cfg;
     g->keep_taps = cfg->reserved[0] != 0;
+    g->concurrent = cfg->reserved[1] != 0;
     const EgGeneratorConfig& c = g->cfg;
     g->H1 = c.n_mels; g->W1 = c.spec_len;
     g->H2 = (g->H1 - 1) / 2 + 1; g->W2 = (g->W1 - 1) / 2 + 1;
@@ -466,8 +517,9 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     g->a_fc1 = add_linear(L, "audio_encoder.fc1", D, g->HW3, true);
     g->a_fc2 = add_linear(L, "audio_encoder.fc2", D, D, true);
     // --- projections
-    g->emo0 = add_linear(L, "emotion_proj.0", D, D, true); g->emo2 = add_linear(L, "emotion_proj.2", D, D, true);
-    g->sem0 = add_linear(L, "semantic_proj.0", D, D, true); g->sem2 = add_linear(L, "semantic_proj.2", D, D, true);
+    g->emosem0 = add_linear_cat(L, {"emotion_proj.0", "semantic_proj.0"}, D, D, true);      // both read spectrum_feature (:588-589)
+    g->emo2 = add_linear(L, "emotion_proj.2", D, D, true);
+    g->sem2 = add_linear(L, "semantic_proj.2", D, D, true);
     g->fus0 = add_linear(L, "fusion_proj.0", D, D, true); g->fus2 = add_linear(L, "fusion_proj.2", D, D, true);
     g->cls[0] = add_linear(L, "emotion_classifer_header.0", D, F * D, true);
     g->cls[1] = add_linear(L, "emotion_classifer_header.2", 256, D, true);
@@ -499,9 +551,9 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     g->pos_table = L.add("encoder.position_enc.pos_table", EG_PACK_POS_TABLE, F, D, 0, 0, (int64_t)F * D);
     for (int l = 0; l < c.n_layers; ++l) {
         const std::string e = "encoder.layer_stack." + std::to_string(l), d = "decoder.layer_stack." + std::to_string(l);
-        g->enc_attn.push_back(add_mha(L, e + ".slf_attn", D));
+        g->enc_attn.push_back(add_mha(L, e + ".slf_attn", D, true));
         g->enc_ffn.push_back(add_ffn(L, e + ".pos_ffn", D, c.d_inner));
-        g->dec_attn.push_back(add_mha(L, d + ".enc_attn", D));     // slf_attn parameters exist but are unused (Layers.py:52-53)
+        g->dec_attn.push_back(add_mha(L, d + ".enc_attn", D, false));     // slf_attn parameters exist but are unused (Layers.py:52-53)
         g->dec_ffn.push_back(add_ffn(L, d + ".pos_ffn", D, c.d_inner));
     }
     // --- text branch
@@ -555,16 +607,28 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
     const int F = c.frames, D = c.d_model, rows = B * F, prec = c.precision;
 
     float* txt = text_embedding ? text_embedding : P(ws, w.t_out);
-    EG_TRY(run_text(g, arena, text, txt, w, ws, B, st));
+    hipStream_t s_text = st, s_prior = st;
+    if (g->concurrent) {
+        EG_TRY(g->ensure_streams());
+        s_text = g->side[0]; s_prior = g->side[1];
+        (void)hipEventRecord(g->ev_fork, st);
+        (void)hipStreamWaitEvent(s_text, g->ev_fork, 0);
+        (void)hipStreamWaitEvent(s_prior, g->ev_fork, 0);
+    }
+    EG_TRY(run_text(g, arena, text, txt, w, ws, B, s_text));
+    EG_TRY(run_prior(g, arena, prior, w, ws, B, s_prior));
+    if (g->concurrent) {
+        (void)hipEventRecord(g->ev_join[0], s_text);
+        (void)hipEventRecord(g->ev_join[1], s_prior);
+    }
     EG_TRY(run_audio_tower(g, arena, spec, w, ws, B, st));
-    EG_TRY(run_prior(g, arena, prior, w, ws, B, st));
     const float* feat = P(ws, w.afeat);
     float* emo = emotion_feature ? emotion_feature : P(ws, w.emo);
     float* sem = semantic_feature ? semantic_feature : P(ws, w.sem);
-    EG_TRY(run_linear(arena, g->emo0, feat, D, P(ws, w.emo_t), D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->emo2, P(ws, w.emo_t), D, emo, D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->sem0, feat, D, P(ws, w.sem_t), D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->sem2, P(ws, w.sem_t), D, sem, D, rows, 0, nullptr, 0, prec, st));
+    // emotion_proj.0 | semantic_proj.0 fused: [rows, 2D] = (emotion hidden | semantic hidden)
+    EG_TRY(run_linear(arena, g->emosem0, feat, D, P(ws, w.emo_t), 2 * D, rows, 0, nullptr, 0, prec, st));
+    EG_TRY(run_linear(arena, g->emo2, P(ws, w.emo_t), 2 * D, emo, D, rows, 0, nullptr, 0, prec, st));
+    EG_TRY(run_linear(arena, g->sem2, P(ws, w.emo_t) + D, 2 * D, sem, D, rows, 0, nullptr, 0, prec, st));
     // emotion classifier header on emotion_feature.reshape(B, F*D)  (:592)
     {
         const int K0 = F * D;
@@ -577,6 +641,10 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
     }
     EG_TRY(egi_add(sampled ? sampled : emo, sem, P(ws, w.fus_in), (size_t)rows * D, D, 0, st));
     float* pose_out = pose ? pose : P(ws, w.pose);
+    if (g->concurrent) {        // join: the decoder needs the prior encoding; the caller's stream must also cover the text branch
+        (void)hipStreamWaitEvent(st, g->ev_join[1], 0);
+        (void)hipStreamWaitEvent(st, g->ev_join[0], 0);
+    }
     return run_transformer(g, arena, P(ws, w.fus_in), P(ws, w.prior_enc), pose_out, w, ws, B, st);
 }
 
@@ -598,8 +666,8 @@ extern "C" int eg_generator_forward_draws(const EgGenerator* g, const float* are
     const int F = c.frames, D = c.d_model, rows = B * F, prec = c.precision;
     EG_TRY(run_audio_tower(g, arena, spec, w, ws, B, st));
     EG_TRY(run_prior(g, arena, prior, w, ws, B, st));
-    EG_TRY(run_linear(arena, g->sem0, P(ws, w.afeat), D, P(ws, w.sem_t), D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->sem2, P(ws, w.sem_t), D, P(ws, w.sem), D, rows, 0, nullptr, 0, prec, st));
+    EG_TRY(run_linear(arena, g->emosem0, P(ws, w.afeat), D, P(ws, w.emo_t), 2 * D, rows, 0, nullptr, 0, prec, st));
+    EG_TRY(run_linear(arena, g->sem2, P(ws, w.emo_t) + D, 2 * D, P(ws, w.sem), D, rows, 0, nullptr, 0, prec, st));
     // fusion_in[(b,r,f)] = sampled[(b,r,f)] + semantic[(b,f)];  decoder target stream = prior_enc[b] for every draw
     EG_TRY(egi_add_bcast(sampled, P(ws, w.sem), P(ws, w.fus_in), (size_t)B * R * F, D, F, R, st));
     EG_TRY(egi_add_bcast(nullptr, P(ws, w.prior_enc), P(ws, w.prior_rep), (size_t)B * R * F, D, F, R, st));

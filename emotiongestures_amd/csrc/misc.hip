@@ -313,40 +313,50 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const float* __restrict__ x
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int span = 63 * stride + K;
     const int in0 = l0 * stride - pad;
+    const int cblk = 4 * COG;                        // output channels of this workgroup
+    const int cbase = blockIdx.z * cblk;
+    float* xs = sm;                                 // [Cin][span]
+    float* ws = sm + ((Cin * span + 3) & ~3);       // [Cin*K][cblk]: the COG weights of a wave are COG/4 broadcast b128 reads
     for (int i = tid; i < Cin * span; i += 256) {
         const int ci = i / span, j = i - ci * span, gl = in0 + j;
-        sm[i] = (gl >= 0 && gl < Lin) ? x[((size_t)n * Cin + ci) * Lin + gl] : 0.f;
+        xs[i] = (gl >= 0 && gl < Lin) ? x[((size_t)n * Cin + ci) * Lin + gl] : 0.f;
+    }
+    for (int i = tid; i < Cin * K * cblk; i += 256) {
+        const int ck = i / cblk, c = i - ck * cblk, co = cbase + c;
+        ws[i] = co < Cout ? w[(size_t)co * Cin * K + ck] : 0.f;
     }
     __syncthreads();
-    const int co0 = (blockIdx.z * 4 + wave) * COG;
+    const int co0 = cbase + wave * COG;
     const int l = l0 + lane;
-    float acc[COG];
+    f4 acc[COG / 4];
 #pragma unroll
-    for (int j = 0; j < COG; ++j) acc[j] = (co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    for (int j = 0; j < COG / 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = (co0 + j * 4 + r < Cout) ? bias[co0 + j * 4 + r] : 0.f;
     for (int ci = 0; ci < Cin; ++ci) {
-        const float* xp = sm + ci * span + lane * stride;
+        const float* xp = xs + ci * span + lane * stride;
         for (int k = 0; k < K; ++k) {
             const float xv = xp[k];
+            const f4* wp = reinterpret_cast<const f4*>(ws + (ci * K + k) * cblk + wave * COG);
 #pragma unroll
-            for (int j = 0; j < COG; ++j) {
-                const int co = co0 + j < Cout ? co0 + j : Cout - 1;
-                acc[j] += w[((size_t)co * Cin + ci) * K + k] * xv;
-            }
+            for (int j = 0; j < COG / 4; ++j) acc[j] += wp[j] * xv;
         }
     }
     if (l >= Lout) return;
 #pragma unroll
-    for (int j = 0; j < COG; ++j) {
-        const int co = co0 + j;
-        if (co < Cout) {
-            float s = acc[j];
-            if (act) {
-                s = s > 0.f ? s : 0.2f * s;
-                s = s * scale[co] + shift[co];
+    for (int j = 0; j < COG / 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + j * 4 + r;
+            if (co < Cout) {
+                float s = acc[j][r];
+                if (act) {
+                    s = s > 0.f ? s : 0.2f * s;
+                    s = s * scale[co] + shift[co];
+                }
+                y[((size_t)n * Cout + co) * Lout + l] = s;
             }
-            y[((size_t)n * Cout + co) * Lout + l] = s;
         }
-    }
 }
 
 // ConvTranspose1d(k=3, stride=2, padding=1, output_padding=1): Lout = 2*Lin; weight [Cin][Cout][3]
@@ -529,10 +539,10 @@ int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float*
 int egi_conv1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int n, int cin,
                int cout, int lin, int k, int stride, int pad, int act, hipStream_t st) {
     const int lout = (lin + 2 * pad - k) / stride + 1;
-    const size_t smem = sizeof(float) * (size_t)cin * (63 * stride + k);
-    if (smem > 64 * 1024) { eg_set_error("conv1d: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
     const int per_wave = eg_cdiv(cout, 4);
     const int cog = per_wave <= 4 ? 4 : (per_wave <= 8 ? 8 : 16);
+    const size_t smem = sizeof(float) * ((((size_t)cin * (63 * stride + k) + 3) & ~(size_t)3) + (size_t)cin * k * 4 * cog);
+    if (smem > 64 * 1024) { eg_set_error("conv1d: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
     dim3 grid(eg_cdiv(lout, 64), n, eg_cdiv(cout, 4 * cog));
     if (cog == 4)
         hipLaunchKernelGGL((conv1d_kernel<4>), grid, dim3(256), smem, st, x, w, bias, scale, shift, y, cin, cout, lin, lout, k, stride, pad, act);

@@ -18,6 +18,8 @@ BN_EPS = 1e-5       # torch.nn.BatchNorm{1,2}d default, which the reference keep
 
 
 def _t(sd: Mapping[str, torch.Tensor], key: str) -> torch.Tensor:
+    if "|" in key:                      # several tensors concatenated along dim 0 (fused projections)
+        return torch.cat([_t(sd, k) for k in key.split("|")], 0)
     if key not in sd:
         raise KeyError(f"state_dict is missing '{key}' required by the HIP weight manifest")
     return sd[key].detach().to("cpu", torch.float32)
