@@ -79,6 +79,8 @@ SIGNATURES = {
     "eg_se_gate": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "eg_se_residual_relu": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_linear": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_split_tiles": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "eg_linear_presplit": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_linear_splitk": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "eg_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_attention": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

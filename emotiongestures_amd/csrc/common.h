@@ -84,3 +84,14 @@ struct EgProfScope {
     EgProfScope(int64_t tag, double flops, hipStream_t s);
     ~EgProfScope();
 };
+
+// ---- internal (C++ linkage) product descriptor shared by gemm.hip and generator.hip --------------------------------
+struct EgiLinear {
+    const float* x = nullptr; int lda = 0;                          // fp32 input, or ...
+    const void* ximg = nullptr; int xK = 0, xk0 = 0;                // ... pre-split images of width xK, this product's K range starts at xk0
+    const float* w = nullptr; int ldw = 0; const float* bias = nullptr;
+    const float* res1 = nullptr; const float* res2 = nullptr; int ldr = 0;
+    float* y = nullptr; int ldc = 0;
+    void* yimg = nullptr; int yK = 0, yk0 = 0;                      // optional pre-split output images of width yK at column offset yk0
+    int m = 0, n = 0, k = 0, relu = 0, a_shift = 0, a_seq = 1, precision = 0;
+};

@@ -16,6 +16,10 @@ struct GemmArgs {
     const unsigned short* whi; const unsigned short* wlo;     // bf16 images [Nrows][ldw] (split-bf16 modes)
     int lda, ldw, ldr, ldc, M, N, K, relu, a_shift, a_seq, k_per_split;
     float* partial;
+    // optional second output: Y split to bf16 (hi, lo) tile-planar images [ceil(M/64)][yKO][64][8] for a downstream product
+    unsigned short* yimg = nullptr;
+    int yKO = 0, yoct0 = 0;
+    int xoct0 = 0;              // pre-split X: first octet of this product's K range inside the X images
 };
 
 __device__ __forceinline__ f4 load_x_quad(const GemmArgs& a, int m, int k, int kend) {
@@ -34,13 +38,14 @@ __device__ __forceinline__ f4 load_x_quad(const GemmArgs& a, int m, int k, int k
 
 
 // v = acc + bias + res1; relu; (+res2, relu); lane owns 4 consecutive n of row m (+16 per t), n += 16 per tile
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[2][2], int mbase, int nbase) {
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[MT][NT], int mbase, int nbase) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < MT; ++t) {
         const int m = mbase + t * 16;
         if (m >= a.M) continue;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const int nn = nbase + n * 16;
             if (nn >= a.N) continue;
             f4 v = acc[t][n];
@@ -72,6 +77,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[2][2]
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (nn + r < a.N) v[r] = fmaxf(v[r] + rp[r], 0.f);
+            }
+            if (a.yimg) {           // 4 consecutive k of the downstream product = half an octet: two 8-byte stores
+                const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+                bf8 h8, l8;
+                split_octet<true>(v, z, h8, l8);
+                const size_t mt_total = (size_t)((a.M + 63) >> 6);
+                const size_t slot = (((size_t)(m >> 6) * a.yKO + a.yoct0 + (nn >> 3)) * 64 + (m & 63)) * 8 + (nn & 7);
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x4_t hh = __builtin_bit_cast(u32x4_t, h8), ll = __builtin_bit_cast(u32x4_t, l8);
+                *reinterpret_cast<u32x2*>(a.yimg + slot) = (u32x2){hh[0], hh[1]};
+                *reinterpret_cast<u32x2*>(a.yimg + mt_total * a.yKO * 512 + slot) = (u32x2){ll[0], ll[1]};
+                if (!a.y) continue;
             }
             float* yp = a.y + (size_t)m * a.ldc + nn;
             if (full && (a.ldc & 3) == 0) {
@@ -178,58 +195,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    gemm_epilogue(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+    gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
 }
 
-// ---- split-bf16 path: 64x64 tile, K-step 64, both operands double-buffered in LDS ------------------------------
+// ---- split-bf16 path: 64x64 tile, K-step 64 -----------------------------------------------------------------
 //  * W: pre-split on the host into tile-planar bf16 images [n/64][k/8][64 rows][8] (hi image, lo image): the 8 octets of
-//    one K-step are 8 contiguous 1-KiB pieces, copied by global_load_lds (no VGPR/VALU) into a 2-deep ring;
-//  * X (fp32 activations): next step's rows are loaded to registers before this step's MFMAs, split to (hi, lo) bf16 with
-//    v_cvt_pk_bf16_f32 and written to the other ring slot after them; one barrier per K-step.
-//  LDS image of both operands: [k/8][row] bf8 => the 16 rows of an MFMA tile are 16 consecutive 16-B slots (conflict free).
+//    one K-step are 8 contiguous 1-KiB pieces, copied by global_load_lds (no VGPR/VALU) into a 2-deep LDS ring; LDS image
+//    [k/8][row] bf8 => the 16 rows of an MFMA tile are 16 consecutive 16-B slots (conflict-free ds_read_b128);
+//  * X (fp32 activations) never touches LDS: each wave owns 16 rows, a lane loads its own MFMA B-operand octets
+//    (row = lane&15, k = 8*(lane>>4)..+7: 32 contiguous bytes) one K-step ahead, splits them to (hi, lo) bf16 in registers
+//    with v_cvt_pk_bf16_f32 and feeds the MFMAs directly.  (The r01b profile showed the LDS-staged X path LDS-bound:
+//    SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE from the ds_write_b128 of the split tile.)
+//  One barrier per K-step, for the weight ring only.
 template <int TERMS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr int IMG = 8 * 64;                     // bf8 slots of one operand image of one step (8 octets x 64 rows)
-    __shared__ bf8 lds[2 * 2 * NIMG * IMG];         // [buf][X|W][hi|lo][oct][row]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    constexpr int IMG = 8 * 64;                     // bf8 slots of one weight image of one step (8 octets x 64 rows)
+    __shared__ bf8 lds[2 * NIMG * IMG];             // [buf][hi|lo][oct][row]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nsteps = (kend - kbeg + 63) / 64;
     const int KO = a.ldw >> 3;                      // octets per packed weight row
 
-    // X staging role: row = tid>>2, octets 2*(tid&3), 2*(tid&3)+1 (64 contiguous bytes per lane, 256 B per 4 lanes)
-    const int xr = tid >> 2, xo = (tid & 3) * 2;
-    const int xm = m0 + xr;
+    const int xm = m0 + wave * 16 + li;
     bool xok = xm < a.M;
     int xsrc = xm;
     if (a.a_shift) {
         xok = xok && (xm % a.a_seq) >= a.a_shift;
         xsrc = xm - a.a_shift;
     }
-    const float* xrow = a.x + (size_t)(xok ? xsrc : 0) * a.lda;
-    f4 xv[4];
-    auto load_x = [&](int k0) {
+    const float* xrow = a.x + (size_t)(xok ? xsrc : 0) * a.lda + kq * 8;
+    f4 xv[2][2], xn[2][2];
+    auto load_x = [&](int k0, f4 (&v)[2][2]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + xo * 8 + j * 4;
-            xv[j] = (xok && k < kend) ? *reinterpret_cast<const f4*>(xrow + k) : (f4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto store_x = [&](int buf) {
-        bf8* X = lds + buf * (2 * NIMG * IMG);
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            bf8 hi, lo;
-            split_octet<TERMS == 3>(xv[2 * o], xv[2 * o + 1], hi, lo);
-            X[(xo + o) * 64 + xr] = hi;
-            if (TERMS == 3) X[IMG + (xo + o) * 64 + xr] = lo;
-        }
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + g * 32 + kq * 8 + h * 4;
+                v[g][h] = (xok && k < kend) ? *reinterpret_cast<const f4*>(xrow + (k0 + g * 32 + h * 4)) : (f4){0.f, 0.f, 0.f, 0.f};
+            }
     };
     auto issue_w = [&](int k0, int buf) {
-        bf8* W = lds + buf * (2 * NIMG * IMG) + NIMG * IMG;
+        bf8* W = lds + buf * (NIMG * IMG);
         const size_t gbase = ((size_t)blockIdx.y * KO + (k0 >> 3)) * 64;        // bf8 slots: [n/64][k/8][64]
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
@@ -243,15 +253,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         }
     };
 
-    f4 acc[2][2];
+    f4 acc[1][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n) acc[0][n] = (f4){0.f, 0.f, 0.f, 0.f};
 
     issue_w(kbeg, 0);
-    load_x(kbeg);
-    store_x(0);
+    load_x(kbeg, xv);
     __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
@@ -259,38 +266,262 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         const bool more = s + 1 < nsteps;
         if (more) {
             issue_w(kbeg + (s + 1) * 64, buf ^ 1);
-            load_x(kbeg + (s + 1) * 64);
+            load_x(kbeg + (s + 1) * 64, xn);
         }
-        const bf8* X = lds + buf * (2 * NIMG * IMG);
-        const bf8* W = X + NIMG * IMG;
+        const bf8* W = lds + buf * (NIMG * IMG);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            bf8 xh[2], xl[2], wh[2], wl[2];
+            bf8 xh, xl;
+            split_octet<TERMS == 3>(xv[g][0], xv[g][1], xh, xl);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                xh[t] = X[(g * 4 + kq) * 64 + wm + t * 16 + li];
-                if (TERMS == 3) xl[t] = X[IMG + (g * 4 + kq) * 64 + wm + t * 16 + li];
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                wh[n] = W[(g * 4 + kq) * 64 + wn + n * 16 + li];
-                if (TERMS == 3) wl[n] = W[IMG + (g * 4 + kq) * 64 + wn + n * 16 + li];
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    if (TERMS == 3) {
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
-                    }
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) {
+                const bf8 wh = W[(g * 4 + kq) * 64 + n * 16 + li];
+                if (TERMS == 3) {
+                    const bf8 wl = W[IMG + (g * 4 + kq) * 64 + n * 16 + li];
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[0][n], 0, 0, 0);
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[0][n], 0, 0, 0);
                 }
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[0][n], 0, 0, 0);
+            }
         }
-        if (more) store_x(buf ^ 1);
+        if (more) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { xv[g][0] = xn[g][0]; xv[g][1] = xn[g][1]; }
+        }
         __syncthreads();
     }
-    gemm_epilogue(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+    gemm_epilogue<1, 4>(a, acc, m0 + wave * 16 + li, n0 + kq * 4);
+}
+
+
+// ---- split-bf16 path, all-LDS-DMA pipeline (default when there is no causal row shift) --------------------------------
+// Both operands are copied global -> LDS by global_load_lds into a 4-slot ring, 3 K-steps (of 32) ahead of the MFMAs; the
+// only waits are a counted s_waitcnt vmcnt (the two youngest step groups stay in flight) and one raw s_barrier per step.
+// (Mixing ordinary register loads of X with the LDS-DMA of W makes hipcc wait vmcnt(0) at the first use of the register
+//  operand, which exposed a full L2 round trip in every K-step of the kernel above: r01c profile, 12.8 us for a 13 %-MFMA
+//  busy 2176x512x512 product.)
+//  * X stays fp32 in LDS: image [64 rows][8 quads] (128 B per row), filled 8 rows x 128 contiguous bytes per piece
+//    (fully coalesced), with the quad position XOR-swizzled on the SOURCE side, q -> q ^ ((r ^ r>>1) & 7), so that the
+//    fragment reads (16 consecutive rows, same octet) are bank-conflict free; split to (hi, lo) bf16 in registers.
+//  * W: tile-planar bf16 images as above (4 octets per step = 4 contiguous 1-KiB pieces per image).
+//  Rows >= M are clamped (their results are never stored); k >= K is clamped to finite data (the packed weights are zero there).
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr int RING = 4, XS = 64 * 8, WS = NIMG * 4 * 64, SLOT = XS + WS;      // 16-byte slots
+    constexpr int G = 2 + NIMG;                                                    // LDS-DMA instructions per wave per step
+    __shared__ f4 lds[RING * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int kbeg = blockIdx.z * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nsteps = (kend - kbeg + 31) / 32;
+    const int KO = a.ldw >> 3;
+
+    // X copy role of this lane: rows (p*4 + wave)*8 + (lane>>3), swizzled quad
+    const float* xsrc[2];
+    int xq[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (p * 4 + wave) * 8 + (lane >> 3);
+        const int m = min(m0 + r, a.M - 1);
+        xsrc[p] = a.x + (size_t)m * a.lda;
+        xq[p] = ((lane & 7) ^ ((r ^ (r >> 1)) & 7)) * 4;
+    }
+    const int klast = kend - 4;
+    auto issue = [&](int step, int slot) {
+        const int k0 = kbeg + step * 32;
+        f4* X = lds + slot * SLOT;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int k = min(k0 + xq[p], klast);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[p] + k),
+                                             (__attribute__((address_space(3))) void*)(X + (p * 4 + wave) * 64), 16, 0, 0);
+        }
+        const size_t gbase = ((size_t)blockIdx.y * KO + (k0 >> 3)) * 64 + wave * 64 + lane;
+        bf8* W = reinterpret_cast<bf8*>(X + XS);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gbase),
+                                         (__attribute__((address_space(3))) void*)(W + wave * 64), 16, 0, 0);
+        if (TERMS == 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gbase),
+                                             (__attribute__((address_space(3))) void*)(W + 256 + wave * 64), 16, 0, 0);
+    };
+    auto wait_groups = [&](int groups_in_flight) {      // all but the youngest `groups_in_flight` step groups have landed
+        if (groups_in_flight >= 2) {
+            if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (groups_in_flight == 1) {
+            if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    f4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int pre = min(nsteps, RING - 1);
+    for (int s = 0; s < pre; ++s) issue(s, s);
+    wait_groups(pre - 1);
+    __builtin_amdgcn_s_barrier();
+    const int fsw = (li ^ (li >> 1)) & 7;
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) & (RING - 1));
+        const f4* X = lds + (s & (RING - 1)) * SLOT;
+        const bf8* W = reinterpret_cast<const bf8*>(X + XS);
+        bf8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f4* xr = X + (wm + t * 16 + li) * 8;
+            const f4 q0 = xr[(2 * kq) ^ fsw], q1 = xr[(2 * kq + 1) ^ fsw];
+            split_octet<TERMS == 3>(q0, q1, xh[t], xl[t]);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            wh[n] = W[kq * 64 + wn + n * 16 + li];
+            if (TERMS == 3) wl[n] = W[256 + kq * 64 + wn + n * 16 + li];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (TERMS == 3) {
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
+                }
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xh[t], acc[t][n], 0, 0, 0);
+            }
+        // next step's group must have landed; groups beyond it stay in flight across the barrier
+        const int newest = min(s + RING - 1, nsteps - 1);
+        wait_groups(max(0, newest - (s + 1)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's LDS reads are done before the slot is reused
+        __builtin_amdgcn_s_barrier();
+    }
+    gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+}
+
+// ---- split-bf16 path with PRE-SPLIT activations ---------------------------------------------------------------------
+// X arrives already split to bf16 (hi, lo) in the same tile-planar layout as the weights ([m/64][k/8][64 rows][8]); it is
+// produced by the upstream kernel's epilogue (or by split_tile_kernel), once, instead of being re-split by every one of
+// the N/64 workgroups that consume it.  The K loop then has no VALU work at all: LDS-DMA copies of both operands 3 steps
+// ahead, fragments of step s+1 read from LDS while the MFMAs of step s run (register double buffer), one counted vmcnt and
+// one raw barrier per 32-deep step.
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr int RING = 4, OP = NIMG * 4 * 64, SLOT = 2 * OP;          // bf8 slots: [X hi|lo][W hi|lo], 4 octets x 64 rows each
+    constexpr int G = 2 * NIMG;                                           // LDS-DMA instructions per wave per step
+    __shared__ bf8 lds[RING * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int kbeg = blockIdx.z * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nsteps = (kend - kbeg + 31) / 32;
+    const int KO = a.ldw >> 3;
+    auto issue = [&](int step, int slot) {
+        const int ko = (kbeg + step * 32) >> 3;
+        bf8* S = lds + slot * SLOT;
+        const size_t gx = ((size_t)blockIdx.x * xKO + a.xoct0 + ko) * 64 + wave * 64 + lane;
+        const size_t gw = ((size_t)blockIdx.y * KO + ko) * 64 + wave * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx),
+                                         (__attribute__((address_space(3))) void*)(S + wave * 64), 16, 0, 0);
+        if (TERMS == 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xlo + gx),
+                                             (__attribute__((address_space(3))) void*)(S + 256 + wave * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gw),
+                                         (__attribute__((address_space(3))) void*)(S + OP + wave * 64), 16, 0, 0);
+        if (TERMS == 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gw),
+                                             (__attribute__((address_space(3))) void*)(S + OP + 256 + wave * 64), 16, 0, 0);
+    };
+    auto wait_groups = [&](int n) {                 // all but the youngest n step groups of this wave have landed
+        if (n >= 2) { if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (n == 1) { if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    struct Frags { bf8 xh[2], xl[2], wh[2], wl[2]; };
+    auto read_frags = [&](Frags& f, int slot) {
+        const bf8* S = lds + slot * SLOT + kq * 64 + li;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f.xh[t] = S[wm + t * 16];
+            if (TERMS == 3) f.xl[t] = S[256 + wm + t * 16];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f.wh[n] = S[OP + wn + n * 16];
+            if (TERMS == 3) f.wl[n] = S[OP + 256 + wn + n * 16];
+        }
+    };
+    f4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (TERMS == 3) {
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[n], f.xh[t], acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[t][n], 0, 0, 0);
+                }
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
+            }
+    };
+
+    // prologue: groups 0..2 in flight; group 0 (and 1) landed before the loop
+    const int pre = min(nsteps, RING - 1);
+    for (int s = 0; s < pre; ++s) issue(s, s);
+    wait_groups(max(0, pre - 2));
+    __builtin_amdgcn_s_barrier();
+    Frags fa, fb;
+    read_frags(fa, 0);
+    // steps are processed in pairs so that the two fragment sets have static names
+    auto step = [&](int s, Frags& cur, Frags& nxt) {
+        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) & (RING - 1));
+        if (s + 1 < nsteps) read_frags(nxt, (s + 1) & (RING - 1));
+        mfma_step(cur);
+        // at the next step's start, group s+2 must be landed (its fragments are read then); s+3 may stay in flight
+        const int newest = min(s + RING - 1, nsteps - 1);
+        wait_groups(max(0, min(1, newest - (s + 2))));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, fa, fb);
+        if (s + 1 < nsteps) step(s + 1, fb, fa);
+    }
+    gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+}
+
+// fp32 [M, K] (row stride lda) -> bf16 (hi, lo) tile-planar images [ceil(M/64)][Kpad/8][64][8]; rows >= M and k >= K are zero.
+__global__ __launch_bounds__(256) void split_tile_kernel(const float* __restrict__ x, int lda, int M, int K, int KO,
+                                                         bf8* __restrict__ hi, bf8* __restrict__ lo) {
+    const size_t total = (size_t)gridDim.y * 64 * KO;       // one thread per (row, octet)
+    const int mt = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 64 * KO; i += gridDim.x * 256) {
+        const int o = i >> 6, r = i & 63, m = mt * 64 + r, k = o * 8;
+        f4 v0 = (f4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (m < M) {
+            if (k < K) v0 = *reinterpret_cast<const f4*>(x + (size_t)m * lda + k);
+            if (k + 4 < K) v1 = *reinterpret_cast<const f4*>(x + (size_t)m * lda + k + 4);
+        }
+        bf8 h, l;
+        split_octet<true>(v0, v1, h, l);
+        hi[((size_t)mt * KO + o) * 64 + r] = h;
+        lo[((size_t)mt * KO + o) * 64 + r] = l;
+    }
+    (void)total;
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
@@ -307,8 +538,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int launch_gemm(GemmArgs& a, int splits, int precision, hipStream_t st) {
     dim3 grid(eg_cdiv(a.M, 64), eg_cdiv(a.N, 64), splits), block(256);
     if (precision == EG_PREC_F32) hipLaunchKernelGGL((gemm_kernel<EG_PREC_F32>), grid, block, 0, st, a);
-    else if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_bf16_kernel<3>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<1>), grid, block, 0, st, a);
+    else if (a.a_shift) {       // causal row shift needs zero rows: register-staged X path
+        if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_bf16_kernel<3>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<1>), grid, block, 0, st, a);
+    } else {
+        if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_glds_kernel<3>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm_glds_kernel<1>), grid, block, 0, st, a);
+    }
     return eg_check_launch("gemm");
 }
 
@@ -332,6 +568,42 @@ int fill_common(GemmArgs& a, const float* x, int lda, const float* w, int ldw, i
 }
 
 }  // namespace
+
+// Internal (C++ linkage) product with every option; generator.hip uses it to chain products through pre-split images.
+int egi_linear(const EgiLinear& p, hipStream_t st) {
+    GemmArgs a;
+    EG_REQUIRE((p.x || p.ximg) && p.w && (p.y || p.yimg) && p.m > 0 && p.n > 0 && p.k > 0, EG_ERR_BAD_ARG, "egi_linear: null pointer or empty shape");
+    EG_REQUIRE((p.k & 3) == 0 && (p.ldw & 3) == 0, EG_ERR_ALIGN, "egi_linear: K, ldw %% 4");
+    a.x = p.x; a.w = p.w; a.lda = p.lda; a.ldw = p.ldw; a.M = p.m; a.N = p.n; a.K = p.k;
+    a.whi = a.wlo = nullptr;
+    if (p.precision != EG_PREC_F32) {
+        EG_REQUIRE((p.ldw & 63) == 0, EG_ERR_ALIGN, "egi_linear: packed weights need ldw %% 64 == 0");
+        const size_t rows = (size_t)eg_round_up(p.n, 64);
+        a.whi = reinterpret_cast<const unsigned short*>(p.w + rows * p.ldw);
+        a.wlo = a.whi + rows * p.ldw;
+    }
+    a.bias = p.bias; a.res1 = p.res1; a.res2 = p.res2; a.ldr = p.ldr; a.y = p.y; a.ldc = p.ldc; a.relu = p.relu;
+    a.a_shift = p.a_shift; a.a_seq = p.a_seq > 0 ? p.a_seq : 1; a.k_per_split = (int)eg_round_up(p.k, 64); a.partial = nullptr;
+    if (p.yimg) {
+        EG_REQUIRE((p.n & 3) == 0 && (p.yK & 63) == 0 && (p.yk0 & 7) == 0, EG_ERR_ALIGN, "egi_linear: image output alignment");
+        a.yimg = reinterpret_cast<unsigned short*>(p.yimg); a.yKO = p.yK >> 3; a.yoct0 = p.yk0 >> 3;
+    }
+    EgProfScope prof(2, 2.0 * p.m * (double)p.n * p.k, st);
+    if (p.ximg && p.precision != EG_PREC_F32) {
+        EG_REQUIRE((p.xK & 63) == 0 && (p.xk0 & 31) == 0 && (p.k & 31) == 0, EG_ERR_ALIGN, "egi_linear: pre-split X needs K %% 32 == 0");
+        const int xko = p.xK >> 3, mt = eg_cdiv(p.m, 64);
+        const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
+        const bf8* xlo = xhi + (size_t)mt * xko * 64;
+        a.xoct0 = p.xk0 >> 3;
+        dim3 grid(mt, eg_cdiv(p.n, 64), 1), block(256);
+        if (p.precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_presplit_kernel<3>), grid, block, 0, st, a, xhi, xlo, xko);
+        else hipLaunchKernelGGL((gemm_presplit_kernel<1>), grid, block, 0, st, a, xhi, xlo, xko);
+        return eg_check_launch("gemm_presplit");
+    }
+    EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
+    return launch_gemm(a, 1, p.precision, st);
+}
+int egi_split_tiles(const float* x, int lda, int m, int k, void* images, hipStream_t st) { return eg_split_tiles(x, lda, m, k, images, st); }
 
 extern "C" int eg_linear(const float* x, int32_t lda, const float* w, int32_t ldw, const float* bias,
                          const float* res1, const float* res2, int32_t ldr, float* y, int32_t ldc,
@@ -364,4 +636,38 @@ extern "C" int eg_linear_splitk(const float* x, int32_t lda, const float* w, int
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(eg_cdiv(m * n, 256)), dim3(256), 0, (hipStream_t)stream, partial, bias, y, ldc,
                        m, n, nsplit, relu);
     return eg_check_launch("splitk_reduce");
+}
+
+// X -> pre-split tile-planar bf16 images (workspace-resident; consumed by eg_linear_presplit).  images must hold
+// 2 * ceil(M/64)*64 * Kpad bf16 (hi image then lo image), Kpad = K rounded up to 64.
+extern "C" int eg_split_tiles(const float* x, int32_t lda, int32_t m, int32_t k, void* images, void* stream) {
+    EG_REQUIRE(x && images && m > 0 && k > 0 && (k & 3) == 0 && (lda & 3) == 0, EG_ERR_BAD_ARG, "eg_split_tiles: bad argument");
+    const int kpad = (int)eg_round_up(k, 64), ko = kpad / 8, mt = eg_cdiv(m, 64);
+    bf8* hi = reinterpret_cast<bf8*>(images);
+    bf8* lo = hi + (size_t)mt * ko * 64;
+    hipLaunchKernelGGL(split_tile_kernel, dim3(eg_cdiv(64 * ko, 256), mt), dim3(256), 0, (hipStream_t)stream, x, lda, m, k, ko, hi, lo);
+    return eg_check_launch("split_tiles");
+}
+
+extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float* w, int32_t ldw, const float* bias,
+                                  const float* res1, const float* res2, int32_t ldr, float* y, int32_t ldc,
+                                  int32_t m, int32_t n, int32_t k, int32_t relu, int32_t precision, void* stream) {
+    GemmArgs a;
+    EG_REQUIRE(x_images && w && y && m > 0 && n > 0 && k > 0, EG_ERR_BAD_ARG, "eg_linear_presplit: null pointer or empty shape");
+    EG_REQUIRE(precision == EG_PREC_BF16X3 || precision == EG_PREC_BF16, EG_ERR_BAD_ARG, "eg_linear_presplit: bf16 modes only");
+    EG_REQUIRE((ldw & 63) == 0, EG_ERR_ALIGN, "eg_linear_presplit: ldw %% 64");
+    a.x = nullptr; a.w = w; a.lda = 0; a.ldw = ldw; a.M = m; a.N = n; a.K = k;
+    const size_t rows = (size_t)eg_round_up(n, 64);
+    a.whi = reinterpret_cast<const unsigned short*>(w + rows * ldw);
+    a.wlo = a.whi + rows * ldw;
+    a.bias = bias; a.res1 = res1; a.res2 = res2; a.ldr = ldr; a.y = y; a.ldc = ldc; a.relu = relu;
+    a.a_shift = 0; a.a_seq = 1; a.k_per_split = (int)eg_round_up(k, 64); a.partial = nullptr;
+    const int xko = (int)eg_round_up(k_x, 64) / 8, mt = eg_cdiv(m, 64);
+    const bf8* xhi = reinterpret_cast<const bf8*>(x_images);
+    const bf8* xlo = xhi + (size_t)mt * xko * 64;
+    dim3 grid(mt, eg_cdiv(n, 64), 1), block(256);
+    EgProfScope prof(2, 2.0 * m * (double)n * k, (hipStream_t)stream);
+    if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_presplit_kernel<3>), grid, block, 0, (hipStream_t)stream, a, xhi, xlo, xko);
+    else hipLaunchKernelGGL((gemm_presplit_kernel<1>), grid, block, 0, (hipStream_t)stream, a, xhi, xlo, xko);
+    return eg_check_launch("gemm_presplit");
 }

@@ -79,6 +79,8 @@ int egi_embedding(const int64_t* idx, const float* table, float* out, int rows, 
 int egi_add(const float* a, const float* b, float* out, size_t n, int row_len, int period, hipStream_t st);
 int egi_time_linear(const float* x, const float* w, const float* bias, float* y, int batch, int L, int C, int ld, hipStream_t st);
 int egi_copy2d(const float* src, int lds_, float* dst, int ldd, int rows, int cols, hipStream_t st);
+int egi_linear(const EgiLinear& p, hipStream_t st);
+int egi_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* img, int rows, int d, float eps, hipStream_t st);
 int egi_add_bcast(const float* a, const float* b, float* out, size_t rows, int row_len, int period, int rep, hipStream_t st);
 int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float* tm_mem, float* tm_pe, float* tm_gram, int batch,
                       int P, int F, int D, int Dpad, int chunk, int variant, hipStream_t st);
@@ -251,7 +253,7 @@ namespace {
 
 struct GenWs {      // byte offsets into the workspace, for a given batch
     int64_t act[3], gap, gate, amap, afc1, afeat, emo_t, emo, sem_t, sem, cls_part, cls_h[3], cls_out;
-    int64_t fus_in, fus_h, fusion, xa, xb, q, qkv, ao, proj, ffn_h;
+    int64_t fus_in, fus_h, fusion, xa, xb, q, qkv, ao, proj, ffn_h, im_x[2], im_enc, im_h, im_a[3], im_p[2];
     int64_t prior_cat, prior_h, prior_enc, prior_rep, tm_mem, tm_pe, tm_gram, post_a, post_b, post_c, pose;
     int64_t t_emb, t_a, t_b, t_c, t_out;
     int64_t tap_stem, tap_l[3];
@@ -278,6 +280,12 @@ GenWs carve(const EgGenerator* g, int B, int NB = 0) {
     w.xa = cv.take(NF * D); w.xb = cv.take(NF * D);
     w.q = cv.take(NF * D); w.qkv = cv.take(NF * D * 3); w.ao = cv.take(NF * D); w.proj = cv.take(NF * D);
     w.ffn_h = cv.take(NF * c.d_inner);
+    {   // pre-split bf16 (hi, lo) images: 4 bytes per element, rows rounded up to the 64-row tile
+        const int64_t N64 = eg_round_up(NF, 64), B64 = eg_round_up(BF, 64), KX = D > g->Dpad ? D : g->Dpad;
+        w.im_x[0] = cv.take(N64 * KX); w.im_x[1] = cv.take(N64 * KX); w.im_enc = cv.take(N64 * D); w.im_h = cv.take(N64 * c.d_inner);
+        w.im_a[0] = cv.take(B64 * D); w.im_a[1] = cv.take(B64 * D); w.im_a[2] = cv.take(B64 * D * 2);
+        w.im_p[0] = cv.take(B64 * D); w.im_p[1] = cv.take(B64 * D);
+    }
     w.prior_cat = cv.take(BF * g->Dpad); w.prior_h = cv.take(BF * D); w.prior_enc = cv.take(BF * D);
     w.prior_rep = cv.take(NB > B ? NF * D : 16);
     w.tm_mem = cv.take((int64_t)B * c.pose_dim); w.tm_pe = cv.take((int64_t)B * c.chunk + 16); w.tm_gram = cv.take((int64_t)c.pose_dim * c.chunk);
@@ -310,32 +318,60 @@ int run_conv(const float* arena, const ConvW& c, const float* x, float* y, float
                       c.shift >= 0 ? arena + c.shift : nullptr, y, gap, B, h, w, c.cin, c.cout, c.stride, relu, nchw, prec, st);
 }
 
-// MultiHeadAttention.forward (SubLayers.py:30-59).  xkv == nullptr: self attention (fused Q|K|V projection of xq).
-int run_mha(const EgGenerator* g, const float* arena, const MhaW& m, const float* xq, const float* xkv, float* out, const GenWs& w,
+// An activation as the products see it: fp32 rows and/or its bf16 (hi, lo) tile-planar images (bf16 modes only).
+struct Act { float* f = nullptr; int ld = 0; void* img = nullptr; int kimg = 0; };
+inline Act act(float* f, int ld, void* img = nullptr, int kimg = 0) { Act a; a.f = f; a.ld = ld; a.img = img; a.kimg = kimg; return a; }
+
+// nn.Linear with optional pre-split input/output images.  In the bf16 modes an input that comes with images is consumed
+// through them (no in-kernel split), and an output with an image slot is emitted split for the next product;
+// want_f32 = false then skips the fp32 copy.  In f32 mode images are ignored and everything flows through fp32 buffers.
+int lin(const EgGenerator* g, const float* arena, const LinW& w, const Act& x, int xk0, const Act& y, bool want_f32, int m, int relu,
+        const float* res1, int ldr, hipStream_t st, int n_override = 0) {
+    const bool img_ok = g->cfg.precision != EG_PREC_F32;
+    EgiLinear p;
+    p.w = arena + w.w; p.ldw = w.kpad; p.bias = w.b >= 0 ? arena + w.b : nullptr;
+    p.res1 = res1; p.ldr = ldr; p.m = m; p.n = n_override ? n_override : w.n; p.relu = relu; p.precision = g->cfg.precision;
+    if (img_ok && x.img) {
+        p.ximg = x.img; p.xK = x.kimg; p.xk0 = xk0; p.k = w.kpad;
+    } else {
+        p.x = x.f + xk0; p.lda = x.ld; p.k = (w.kpad <= x.ld - xk0 || w.kpad <= x.ld) && (x.ld >= w.kpad) ? w.kpad : w.k;
+    }
+    const bool yimg = img_ok && y.img;
+    if (yimg) { p.yimg = y.img; p.yK = y.kimg; }
+    if (want_f32 || !yimg) { p.y = y.f; p.ldc = y.ld; }
+    return egi_linear(p, st);
+}
+
+// MultiHeadAttention.forward (SubLayers.py:30-59).  xkv.f == nullptr: self attention (fused Q|K|V projection of xq).
+// out receives LN(fc(attn) + xq) as fp32 and (bf16 modes) as images for the FFN that follows.
+int run_mha(const EgGenerator* g, const float* arena, const MhaW& m, const Act& xq, const Act& xkv, const Act& out, const GenWs& w,
             void* ws, int B, int Lq, int Lk, hipStream_t st) {
-    const int D = g->cfg.d_model, prec = g->cfg.precision;
+    const int D = g->cfg.d_model;
     float *qkv = P(ws, w.qkv), *ao = P(ws, w.ao), *pr = P(ws, w.proj);
-    if (!xkv) {
-        EG_TRY(run_linear(arena, m.qkv, xq, D, qkv, 3 * D, B * Lq, 0, nullptr, 0, prec, st));
+    if (!xkv.f) {
+        EG_TRY(lin(g, arena, m.qkv, xq, 0, act(qkv, 3 * D), true, B * Lq, 0, nullptr, 0, st));
         EG_TRY(eg_attention(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, ao, D, nullptr, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
     } else {
         float* q = P(ws, w.q);
-        EG_TRY(run_linear(arena, m.q, xq, D, q, D, B * Lq, 0, nullptr, 0, prec, st));
-        EG_TRY(run_linear(arena, m.kv, xkv, D, qkv, 2 * D, B * Lk, 0, nullptr, 0, prec, st));
+        EG_TRY(lin(g, arena, m.q, xq, 0, act(q, D), true, B * Lq, 0, nullptr, 0, st));
+        EG_TRY(lin(g, arena, m.kv, xkv, 0, act(qkv, 2 * D), true, B * Lk, 0, nullptr, 0, st));
         EG_TRY(eg_attention(q, D, qkv, 2 * D, qkv + D, 2 * D, ao, D, nullptr, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
     }
-    EG_TRY(run_linear(arena, m.o, ao, D, pr, D, B * Lq, 0, xq, D, prec, st));
-    return eg_layernorm(pr, arena + m.ln_g, arena + m.ln_b, out, B * Lq, D, 1e-6f, st);
+    EG_TRY(lin(g, arena, m.o, act(ao, D), 0, act(pr, D), true, B * Lq, 0, xq.f, D, st));
+    return egi_layernorm(pr, arena + m.ln_g, arena + m.ln_b, out.f, g->cfg.precision != EG_PREC_F32 ? out.img : nullptr, B * Lq, D, 1e-6f, st);
 }
 
-int run_ffn(const EgGenerator* g, const float* arena, const FfnW& f, const float* x, float* out, const GenWs& w, void* ws, int rows,
+// PositionwiseFeedForward.forward (SubLayers.py:74-84); the 2048-wide hidden only exists as images in the bf16 modes
+int run_ffn(const EgGenerator* g, const float* arena, const FfnW& f, const Act& x, const Act& out, const GenWs& w, void* ws, int rows,
             hipStream_t st) {
-    const int D = g->cfg.d_model, DI = g->cfg.d_inner, prec = g->cfg.precision;
+    const int D = g->cfg.d_model, DI = g->cfg.d_inner;
     float *h = P(ws, w.ffn_h), *pr = P(ws, w.proj);
-    EG_TRY(run_linear(arena, f.w1, x, D, h, DI, rows, 1, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, f.w2, h, DI, pr, D, rows, 0, x, D, prec, st));
-    return eg_layernorm(pr, arena + f.ln_g, arena + f.ln_b, out, rows, D, 1e-6f, st);
+    const Act hid = act(h, DI, P(ws, w.im_h), DI);
+    EG_TRY(lin(g, arena, f.w1, x, 0, hid, false, rows, 1, nullptr, 0, st));
+    EG_TRY(lin(g, arena, f.w2, hid, 0, act(pr, D), true, rows, 0, x.f, D, st));
+    return egi_layernorm(pr, arena + f.ln_g, arena + f.ln_b, out.f, g->cfg.precision != EG_PREC_F32 ? out.img : nullptr, rows, D, 1e-6f, st);
 }
+
 
 // audio tower: spec [B,n_mels,T] -> audio_feat [B*F, D]  (ResNetSE34V2.py:62-74, Models_spatial_memory.py:118-133)
 int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec, const GenWs& w, void* ws, int B, hipStream_t st) {
@@ -365,8 +401,9 @@ int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec,
     }
     float* amap = P(ws, w.amap);
     EG_TRY(run_conv(arena, g->final_conv, bufs[xi], amap, nullptr, B, h, wd, 0, 1, prec, st));
-    EG_TRY(run_linear(arena, g->a_fc1, amap, g->HW3, P(ws, w.afc1), D, B * F, 0, nullptr, 0, prec, st));
-    return run_linear(arena, g->a_fc2, P(ws, w.afc1), D, P(ws, w.afeat), D, B * F, 0, nullptr, 0, prec, st);
+    const Act h1 = act(P(ws, w.afc1), D, P(ws, w.im_a[0]), D);
+    EG_TRY(lin(g, arena, g->a_fc1, act(amap, g->HW3), 0, h1, false, B * F, 0, nullptr, 0, st));
+    return lin(g, arena, g->a_fc2, h1, 0, act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), true, B * F, 0, nullptr, 0, st);
 }
 
 // text branch: TextEncoderTCN.forward (Models_spatial_memory.py:171-179) channels-last
@@ -406,38 +443,48 @@ int run_prior(const EgGenerator* g, const float* arena, const float* prior, cons
     EG_TRY(egi_prior_encoder(prior, pw, P(ws, w.prior_cat), P(ws, w.tm_mem), P(ws, w.tm_pe), P(ws, w.tm_gram), B, c.prior_frames, c.frames,
                              c.pose_dim, g->Dpad, c.chunk, c.variant, st));
     const int rows = B * c.frames;
-    EG_TRY(run_linear(arena, g->prior_h0, P(ws, w.prior_cat), g->Dpad, P(ws, w.prior_h), c.d_model, rows, 0, nullptr, 0, c.precision, st));
-    return run_linear(arena, g->prior_h2, P(ws, w.prior_h), c.d_model, P(ws, w.prior_enc), c.d_model, rows, 0, nullptr, 0, c.precision, st);
+    const Act ph = act(P(ws, w.prior_h), c.d_model, P(ws, w.im_p[0]), c.d_model);
+    EG_TRY(lin(g, arena, g->prior_h0, act(P(ws, w.prior_cat), g->Dpad), 0, ph, false, rows, 0, nullptr, 0, st));
+    return lin(g, arena, g->prior_h2, ph, 0, act(P(ws, w.prior_enc), c.d_model, P(ws, w.im_p[1]), c.d_model), true, rows, 0, nullptr, 0, st);
 }
 
-// fusion -> encoder -> decoder -> post_projector for `rows_b` sequences (Models_spatial_memory.py:601-614)
-int run_transformer(const EgGenerator* g, const float* arena, const float* fusion_in, const float* prior_enc, float* pose, const GenWs& w,
+// fusion -> encoder -> decoder -> post_projector for NB sequences (Models_spatial_memory.py:601-614)
+int run_transformer(const EgGenerator* g, const float* arena, const float* fusion_in, const Act& prior_enc, float* pose, const GenWs& w,
                     void* ws, int NB, hipStream_t st) {
     const EgGeneratorConfig& c = g->cfg;
-    const int F = c.frames, D = c.d_model, rows = NB * F, prec = c.precision;
-    EG_TRY(run_linear(arena, g->fus0, fusion_in, D, P(ws, w.fus_h), D, rows, 1, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->fus2, P(ws, w.fus_h), D, P(ws, w.fusion), D, rows, 0, nullptr, 0, prec, st));
+    const int F = c.frames, D = c.d_model, rows = NB * F;
+    void *im0 = P(ws, w.im_x[0]), *im1 = P(ws, w.im_x[1]), *ime = P(ws, w.im_enc), *imh = P(ws, w.im_h);
+    const Act fh = act(P(ws, w.fus_h), D, im0, D);
+    EG_TRY(lin(g, arena, g->fus0, act(const_cast<float*>(fusion_in), D), 0, fh, false, rows, 1, nullptr, 0, st));
+    EG_TRY(lin(g, arena, g->fus2, fh, 0, act(P(ws, w.fusion), D), true, rows, 0, nullptr, 0, st));
     float *xa = P(ws, w.xa), *xb = P(ws, w.xb);
     EG_TRY(egi_add(P(ws, w.fusion), arena + g->pos_table, xa, (size_t)rows * D, D, F, st));
+    Act x = act(xa, D);                                  // first layer input has no images (comes from the positional add)
     for (int l = 0; l < c.n_layers; ++l) {
-        EG_TRY(run_mha(g, arena, g->enc_attn[l], xa, nullptr, xb, w, ws, NB, F, F, st));
-        EG_TRY(run_ffn(g, arena, g->enc_ffn[l], xb, xa, w, ws, rows, st));
+        const Act mid = act(xb, D, im0, D);
+        const Act nxt = act(xa, D, l + 1 < c.n_layers ? im1 : ime, D);
+        EG_TRY(run_mha(g, arena, g->enc_attn[l], x, Act(), mid, w, ws, NB, F, F, st));
+        EG_TRY(run_ffn(g, arena, g->enc_ffn[l], mid, nxt, w, ws, rows, st));
+        x = nxt;
     }
-    // encoder output now in xa; decoder stream starts from prior_enc
-    float* enc_out = xa;
-    float* da = P(ws, w.fus_h);      // reuse (fusion hidden is dead)
-    float* db = xb;
-    const float* dx = prior_enc;
+    const Act enc_out = x;                               // xa + images in im_enc, alive through the decoder
+    float* da = P(ws, w.fus_h);                          // reuse (fusion hidden is dead)
+    Act dx = prior_enc;
     for (int l = 0; l < c.n_layers; ++l) {
-        EG_TRY(run_mha(g, arena, g->dec_attn[l], dx, enc_out, db, w, ws, NB, F, F, st));
-        EG_TRY(run_ffn(g, arena, g->dec_ffn[l], db, da, w, ws, rows, st));
-        dx = da;
+        const Act mid = act(xb, D, im0, D);
+        const Act nxt = act(da, D, im1, D);
+        EG_TRY(run_mha(g, arena, g->dec_attn[l], dx, enc_out, mid, w, ws, NB, F, F, st));
+        EG_TRY(run_ffn(g, arena, g->dec_ffn[l], mid, nxt, w, ws, rows, st));
+        dx = nxt;
     }
-    EG_TRY(run_linear(arena, g->post[0], dx, D, P(ws, w.post_a), D * 4, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->post[1], P(ws, w.post_a), D * 4, P(ws, w.post_b), D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->post[2], P(ws, w.post_b), D, P(ws, w.post_c), g->Dpad, rows, 0, nullptr, 0, prec, st, g->Dpad));
-    return run_linear(arena, g->post[3], P(ws, w.post_c), g->Dpad, pose, c.pose_dim, rows, 0, nullptr, 0, prec, st);
+    // post_projector: four affine layers chained through images (fp32 copies only in f32 mode)
+    const Act pa = act(P(ws, w.post_a), D * 4, imh, D * 4), pb = act(P(ws, w.post_b), D, im0, D), pc = act(P(ws, w.post_c), g->Dpad, im1, g->Dpad);
+    EG_TRY(lin(g, arena, g->post[0], dx, 0, pa, false, rows, 0, nullptr, 0, st));
+    EG_TRY(lin(g, arena, g->post[1], pa, 0, pb, false, rows, 0, nullptr, 0, st));
+    EG_TRY(lin(g, arena, g->post[2], pb, 0, pc, false, rows, 0, nullptr, 0, st, g->Dpad));
+    return lin(g, arena, g->post[3], pc, 0, act(pose, c.pose_dim), true, rows, 0, nullptr, 0, st);
 }
+
 
 int validate_cfg(const EgGeneratorConfig& c) {
     EG_REQUIRE(c.frames > c.prior_frames && c.prior_frames >= c.chunk && c.chunk > 0, EG_ERR_BAD_ARG, "config: frames/prior/chunk inconsistent");
@@ -626,9 +673,10 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
     float* emo = emotion_feature ? emotion_feature : P(ws, w.emo);
     float* sem = semantic_feature ? semantic_feature : P(ws, w.sem);
     // emotion_proj.0 | semantic_proj.0 fused: [rows, 2D] = (emotion hidden | semantic hidden)
-    EG_TRY(run_linear(arena, g->emosem0, feat, D, P(ws, w.emo_t), 2 * D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->emo2, P(ws, w.emo_t), 2 * D, emo, D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->sem2, P(ws, w.emo_t) + D, 2 * D, sem, D, rows, 0, nullptr, 0, prec, st));
+    const Act afeat = act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), es = act(P(ws, w.emo_t), 2 * D, P(ws, w.im_a[2]), 2 * D);
+    EG_TRY(lin(g, arena, g->emosem0, afeat, 0, es, false, rows, 0, nullptr, 0, st));
+    EG_TRY(lin(g, arena, g->emo2, es, 0, act(emo, D), true, rows, 0, nullptr, 0, st));
+    EG_TRY(lin(g, arena, g->sem2, es, D, act(sem, D), true, rows, 0, nullptr, 0, st));
     // emotion classifier header on emotion_feature.reshape(B, F*D)  (:592)
     {
         const int K0 = F * D;
@@ -645,7 +693,7 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
         (void)hipStreamWaitEvent(st, g->ev_join[1], 0);
         (void)hipStreamWaitEvent(st, g->ev_join[0], 0);
     }
-    return run_transformer(g, arena, P(ws, w.fus_in), P(ws, w.prior_enc), pose_out, w, ws, B, st);
+    return run_transformer(g, arena, P(ws, w.fus_in), act(P(ws, w.prior_enc), D, P(ws, w.im_p[1]), D), pose_out, w, ws, B, st);
 }
 
 extern "C" int64_t eg_generator_draws_workspace_bytes(const EgGenerator* g, int32_t batch, int32_t draws) {
@@ -666,12 +714,13 @@ extern "C" int eg_generator_forward_draws(const EgGenerator* g, const float* are
     const int F = c.frames, D = c.d_model, rows = B * F, prec = c.precision;
     EG_TRY(run_audio_tower(g, arena, spec, w, ws, B, st));
     EG_TRY(run_prior(g, arena, prior, w, ws, B, st));
-    EG_TRY(run_linear(arena, g->emosem0, P(ws, w.afeat), D, P(ws, w.emo_t), 2 * D, rows, 0, nullptr, 0, prec, st));
-    EG_TRY(run_linear(arena, g->sem2, P(ws, w.emo_t) + D, 2 * D, P(ws, w.sem), D, rows, 0, nullptr, 0, prec, st));
+    const Act afeat = act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), es = act(P(ws, w.emo_t), 2 * D, P(ws, w.im_a[2]), 2 * D);
+    EG_TRY(lin(g, arena, g->emosem0, afeat, 0, es, false, rows, 0, nullptr, 0, st));
+    EG_TRY(lin(g, arena, g->sem2, es, D, act(P(ws, w.sem), D), true, rows, 0, nullptr, 0, st));
     // fusion_in[(b,r,f)] = sampled[(b,r,f)] + semantic[(b,f)];  decoder target stream = prior_enc[b] for every draw
     EG_TRY(egi_add_bcast(sampled, P(ws, w.sem), P(ws, w.fus_in), (size_t)B * R * F, D, F, R, st));
     EG_TRY(egi_add_bcast(nullptr, P(ws, w.prior_enc), P(ws, w.prior_rep), (size_t)B * R * F, D, F, R, st));
-    return run_transformer(g, arena, P(ws, w.fus_in), P(ws, w.prior_rep), pose, w, ws, B * R, st);
+    return run_transformer(g, arena, P(ws, w.fus_in), act(P(ws, w.prior_rep), D), pose, w, ws, B * R, st);
 }
 
 extern "C" int eg_generator_tap(const EgGenerator* g, int32_t batch, void* ws, const char* name, float** d_ptr, int64_t* numel) {

@@ -8,7 +8,7 @@ namespace {
 template <int NV>   // NV f4 per lane (D <= NV*256)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, float* __restrict__ y, int rows, int D,
-                                                        float eps) {
+                                                        float eps, unsigned short* __restrict__ img) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * D);
@@ -36,7 +36,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int q = lane + i * 64;
-        if (q < nq) yr[q] = (v[i] - mean) * rstd * reinterpret_cast<const f4*>(g)[q] + reinterpret_cast<const f4*>(b)[q];
+        if (q < nq) {
+            const f4 o = (v[i] - mean) * rstd * reinterpret_cast<const f4*>(g)[q] + reinterpret_cast<const f4*>(b)[q];
+            yr[q] = o;
+            if (img) {      // also emit the row as bf16 (hi, lo) tile-planar images for the products that consume it
+                const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+                bf8 h8, l8;
+                split_octet<true>(o, z, h8, l8);
+                const int KO = D >> 3;
+                const size_t slot = (((size_t)(row >> 6) * KO + (q >> 1)) * 64 + (row & 63)) * 8 + (q & 1) * 4;
+                const size_t lo_off = (size_t)((rows + 63) >> 6) * KO * 512;
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x4_t hh = __builtin_bit_cast(u32x4_t, h8), ll = __builtin_bit_cast(u32x4_t, l8);
+                *reinterpret_cast<u32x2*>(img + slot) = (u32x2){hh[0], hh[1]};
+                *reinterpret_cast<u32x2*>(img + lo_off + slot) = (u32x2){ll[0], ll[1]};
+            }
+        }
     }
 }
 
@@ -431,17 +446,21 @@ inline int grid_for(size_t n, int cap = 4096) {
 
 // ================================ C ABI + internal launchers =============================================
 
-extern "C" int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
-                            float eps, void* stream) {
+int egi_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* img, int rows, int d, float eps, hipStream_t st) {
     EG_REQUIRE(x && gamma && beta && y && rows > 0, EG_ERR_BAD_ARG, "eg_layernorm: null pointer");
     EG_REQUIRE((d & 3) == 0 && d <= 2048, EG_ERR_UNSUPPORTED, "eg_layernorm: D=%d", d);
-    hipStream_t st = (hipStream_t)stream;
+    EG_REQUIRE(!img || (d & 63) == 0, EG_ERR_ALIGN, "layernorm image output needs D %% 64 == 0");
+    unsigned short* im = reinterpret_cast<unsigned short*>(img);
     dim3 grid(eg_cdiv(rows, 4)), block(256);
-    if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
-    else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
-    else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
-    else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
+    if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
+    else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
+    else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
+    else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
     return eg_check_launch("layernorm");
+}
+extern "C" int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
+                            float eps, void* stream) {
+    return egi_layernorm(x, gamma, beta, y, nullptr, rows, d, eps, (hipStream_t)stream);
 }
 
 extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,

@@ -247,6 +247,15 @@ int eg_linear(const float* x, int32_t lda, const float* w, int32_t ldw, const fl
               const float* res1, const float* res2, int32_t ldr, float* y, int32_t ldc,
               int32_t m, int32_t n, int32_t k, int32_t relu, int32_t a_shift, int32_t a_seq,
               int32_t precision, void* stream);
+/* Pre-split activations: eg_split_tiles converts fp32 X [M,K] into bf16 (hi, lo) tile-planar images
+ * [ceil(M/64)][Kpad/8][64][8] (hi image then lo image; Kpad = K rounded up to 64; 4*ceil(M/64)*64*Kpad bytes);
+ * eg_linear_presplit consumes them (same epilogue as eg_linear, bf16 modes only).  Used where one activation feeds several
+ * products, so that it is split once instead of by every consuming workgroup. */
+int eg_split_tiles(const float* x, int32_t lda, int32_t m, int32_t k, void* images, void* stream);
+int eg_linear_presplit(const void* x_images, int32_t k_x, const float* w, int32_t ldw, const float* bias,
+                       const float* res1, const float* res2, int32_t ldr, float* y, int32_t ldc,
+                       int32_t m, int32_t n, int32_t k, int32_t relu, int32_t precision, void* stream);
+
 /* Split-K variant for tall-K, short-M products (emotion_classifer_header.0: K = frames*d_model,
  * Models_spatial_memory.py:500).  partial >= splits*M*N floats. */
 int eg_linear_splitk(const float* x, int32_t lda, const float* w, int32_t ldw, const float* bias, float* y,

@@ -32,15 +32,26 @@ def gemm(prec):
     pc = L.precision_code(prec)
     shapes = [(2176, 512, 512), (2176, 1536, 512), (2176, 2048, 512), (2176, 512, 2048), (2176, 512, 992), (3840, 300, 300),
               (8704, 512, 512), (2176, 128, 512)]
+    pad = int(os.environ.get("LDA_PAD", "0"))
     for (M, N, K) in shapes:
-        x = torch.randn(M, K, device=dev)
+        x = torch.randn(M, K + pad, device=dev)
         w = torch.randn(N, K) * 0.05
         wp, npad, kpad = ops.pack_linear_weight(w, dev)
         y = torch.empty(M, N, device=dev)
         st = _stream(dev)
-        f = lambda: lib.eg_linear(_ptr(x), K, _ptr(wp), kpad, None, None, None, 0, _ptr(y), N, M, N, K, 0, 0, 0, pc, st)
+        f = lambda: lib.eg_linear(_ptr(x), K + pad, _ptr(wp), kpad, None, None, None, 0, _ptr(y), N, M, N, K, 0, 0, 0, pc, st)
         us = timeit(f)
         print(f"gemm {prec:7s} M={M:5d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s (algorithmic)")
+        if pc != 0 and pad == 0:
+            kp, mt = (K + 63) // 64 * 64, (M + 63) // 64
+            img = torch.empty(2 * mt * 64 * kp, dtype=torch.int16, device=dev)
+            xc = x.contiguous()
+            us_s = timeit(lambda: lib.eg_split_tiles(_ptr(xc), K, M, K, _ptr(img), st))
+            y2 = torch.empty(M, N, device=dev)
+            us_p = timeit(lambda: lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, None, None, None, 0, _ptr(y2), N, M, N, K, 0, pc, st))
+            f(); torch.cuda.synchronize()
+            err = float((y2 - y).abs().max() / y.abs().max())
+            print(f"     presplit: split {us_s:6.1f} us  gemm {us_p:6.1f} us  {2.0 * M * N * K / us_p / 1e6:8.1f} TFLOP/s  max rel diff vs eg_linear {err:.1e}")
 
 
 def conv(prec):
