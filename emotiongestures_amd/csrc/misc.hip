@@ -56,64 +56,67 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---- attention (Full_model/Modules.py:13-23), one workgroup per (q-chunk, head, clip) --------------------
-constexpr int ATT_QC = 32;      // query rows per workgroup
+// Q (pre-scaled by 1/sqrt(dk), as the reference divides q first), K, V rows live in LDS with a 68-float row pitch
+// (272 B = 17 slots: 16 consecutive rows read with ds_read_b128 hit 16 different slots); every thread works on float4s:
+// scores: 4 FMAs per pair of b128 reads; PV: one b128 of V per broadcast probability.
+constexpr int ATT_QC = 64;      // query rows per workgroup (34- and 60-frame sequences fit one workgroup per head)
+constexpr int ATT_P = 68;       // row pitch in floats
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                         const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
                                                         float* __restrict__ attn, int H, int Lq, int Lk, float inv_temp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int qc = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const int q0 = qc * ATT_QC, nq = min(ATT_QC, Lq - q0);
-    float* Qs = sm;                         // [ATT_QC][65]
-    float* Ks = Qs + ATT_QC * 65;           // [Lk][65]
-    float* Vs = Ks + Lk * 65;               // [Lk][64]
-    float* Ss = Vs + Lk * 64;               // [ATT_QC][Lk]
+    float* Qs = sm;                         // [ATT_QC][68]
+    float* Ks = Qs + ATT_QC * ATT_P;        // [Lk][68]
+    float* Vs = Ks + Lk * ATT_P;            // [Lk][68]
+    float* Ss = Vs + Lk * ATT_P;            // [ATT_QC][LkP]
+    const int LkP = (Lk + 3) & ~3;
     for (int i = tid; i < nq * 16; i += 256) {
         const int r = i >> 4, c = (i & 15) * 4;
         const f4 t = *reinterpret_cast<const f4*>(q + ((size_t)b * Lq + q0 + r) * ldq + h * 64 + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Qs[r * 65 + c + j] = t[j] * inv_temp;      // q / temperature first (Modules.py:15)
+        *reinterpret_cast<f4*>(Qs + r * ATT_P + c) = t * inv_temp;       // q / temperature first (Modules.py:15)
     }
     for (int i = tid; i < Lk * 16; i += 256) {
         const int r = i >> 4, c = (i & 15) * 4;
-        const f4 tk = *reinterpret_cast<const f4*>(k + ((size_t)b * Lk + r) * ldk + h * 64 + c);
-        const f4 tv = *reinterpret_cast<const f4*>(v + ((size_t)b * Lk + r) * ldv + h * 64 + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Ks[r * 65 + c + j] = tk[j];
-        *reinterpret_cast<f4*>(Vs + r * 64 + c) = tv;
+        *reinterpret_cast<f4*>(Ks + r * ATT_P + c) = *reinterpret_cast<const f4*>(k + ((size_t)b * Lk + r) * ldk + h * 64 + c);
+        *reinterpret_cast<f4*>(Vs + r * ATT_P + c) = *reinterpret_cast<const f4*>(v + ((size_t)b * Lk + r) * ldv + h * 64 + c);
     }
     __syncthreads();
     for (int i = tid; i < nq * Lk; i += 256) {
         const int r = i / Lk, c = i - r * Lk;
-        float s = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < 64; ++d) s += Qs[r * 65 + d] * Ks[c * 65 + d];
-        Ss[r * Lk + c] = s;
+        const f4* qp = reinterpret_cast<const f4*>(Qs + r * ATT_P);
+        const f4* kp = reinterpret_cast<const f4*>(Ks + c * ATT_P);
+        f4 s4 = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 16; ++d) s4 += qp[d] * kp[d];
+        Ss[r * LkP + c] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
     for (int r = wave; r < nq; r += 4) {
         float m = -3.0e38f;
-        for (int c = lane; c < Lk; c += 64) m = fmaxf(m, Ss[r * Lk + c]);
+        for (int c = lane; c < Lk; c += 64) m = fmaxf(m, Ss[r * LkP + c]);
         m = wave_max(m);
         float s = 0.f;
         for (int c = lane; c < Lk; c += 64) {
-            const float e = expf(Ss[r * Lk + c] - m);
-            Ss[r * Lk + c] = e;
+            const float e = expf(Ss[r * LkP + c] - m);
+            Ss[r * LkP + c] = e;
             s += e;
         }
         const float inv = 1.0f / wave_sum(s);
         for (int c = lane; c < Lk; c += 64) {
-            const float p = Ss[r * Lk + c] * inv;
-            Ss[r * Lk + c] = p;
+            const float p = Ss[r * LkP + c] * inv;
+            Ss[r * LkP + c] = p;
             if (attn) attn[(((size_t)b * H + h) * Lq + q0 + r) * Lk + c] = p;
         }
     }
     __syncthreads();
-    for (int i = tid; i < nq * 64; i += 256) {
-        const int r = i >> 6, d = i & 63;
-        float s = 0.f;
-        for (int c = 0; c < Lk; ++c) s += Ss[r * Lk + c] * Vs[c * 64 + d];
-        out[((size_t)b * Lq + q0 + r) * ldo + h * 64 + d] = s;
+    for (int i = tid; i < nq * 16; i += 256) {
+        const int r = i >> 4, d4 = i & 15;
+        f4 o = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Lk; ++c) o += *reinterpret_cast<const f4*>(Vs + c * ATT_P + d4 * 4) * Ss[r * LkP + c];
+        *reinterpret_cast<f4*>(out + ((size_t)b * Lq + q0 + r) * ldo + h * 64 + d4 * 4) = o;
     }
 }
 
@@ -469,8 +472,8 @@ extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t
     EG_REQUIRE(q && k && v && out && batch > 0 && heads > 0 && lq > 0 && lk > 0, EG_ERR_BAD_ARG, "eg_attention: null pointer or empty shape");
     EG_REQUIRE(dk == 64, EG_ERR_UNSUPPORTED, "eg_attention: d_k=%d (64 supported)", dk);
     EG_REQUIRE(lk <= 256, EG_ERR_UNSUPPORTED, "eg_attention: Lk=%d > 256", lk);
-    EG_REQUIRE(((ldq | ldk | ldv) & 3) == 0, EG_ERR_ALIGN, "eg_attention: row strides must be multiples of 4");
-    const size_t smem = sizeof(float) * ((size_t)ATT_QC * 65 + (size_t)lk * 65 + (size_t)lk * 64 + (size_t)ATT_QC * lk);
+    EG_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, EG_ERR_ALIGN, "eg_attention: row strides must be multiples of 4");
+    const size_t smem = sizeof(float) * ((size_t)ATT_QC * ATT_P + 2 * (size_t)lk * ATT_P + (size_t)ATT_QC * ((lk + 3) & ~3));
     dim3 grid(eg_cdiv(lq, ATT_QC), heads, batch);
     if (smem > 64 * 1024) {
         static bool once = false;
