@@ -202,6 +202,9 @@ def main():
     # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
     if rank == 0 and not args.no_roofline:
         cap = 400 * max(args.steps, 1)
+        gen.concurrent = False                  # per-launch durations are only meaningful without overlapping side streams
+        side = None
+        eager_step()
         _lib.check(lib.eg_profile_enable(cap), "eg_profile_enable")
         for _ in range(args.steps):
             eager_step()                    # per-launch event timing runs eagerly (events are not part of the graph)
@@ -216,7 +219,9 @@ def main():
             groups[int(tg)] = (float(ms[sel].sum()), float(ms[sel].mean()), float(fl[sel].mean()), int(sel.sum()))
         dom = max(groups, key=lambda k: groups[k][0])
         tot_ms, avg_ms, flop, cnt = groups[dom]
-        name = "gemm(all eg_linear launches)" if dom == 2 else f"conv3x3<cin={dom // 1000000},cout={(dom // 1000) % 1000},stride={(dom // 100) % 10}>"
+        gemm_names = {2: "gemm_glds_kernel (fp32 X via LDS-DMA)", 3: "gemm_presplit_kernel (pre-split X)", 4: "gemm_bf16_kernel (causal shift)",
+                      5: "gemm_kernel (f32 MFMA)"}
+        name = gemm_names[dom] if dom in gemm_names else f"conv3x3<cin={dom // 1000000},cout={(dom // 1000) % 1000},stride={(dom // 100) % 10}>"
         achieved = flop / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         step_ms = elapsed / args.steps * 1e3

@@ -547,26 +547,32 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ y,
                                                         int B, int H, int W, int C) {
+    // lane = (pixel, channel quad); the grid stride is a multiple of C/4, so a thread keeps its channel quad and holds the
+    // 9 taps + bias + BN affine of that quad in registers for all its pixels (was: 12 vector loads per output)
     const int cq_n = C >> 2;
     const size_t total = (size_t)B * H * W * cq_n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % cq_n);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cq = (int)(i0 % cq_n);
+    f4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f4*>(w + t * C + cq * 4);
+    const f4 bi = *reinterpret_cast<const f4*>(bias + cq * 4);
+    const f4 sc = *reinterpret_cast<const f4*>(scale + cq * 4), sh = *reinterpret_cast<const f4*>(shift + cq * 4);
+    for (size_t i = i0; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i / cq_n;
         const int ox = (int)(p % W);
         const int oy = (int)((p / W) % H);
         const size_t b = p / ((size_t)W * H);
         const float* xb = x + b * H * W;
-        f4 acc = *reinterpret_cast<const f4*>(bias + cq * 4);
+        f4 acc = bi;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int gy = oy + kh - 1, gx = ox + kw - 1;
-                const float xv = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.f;
-                const f4 wv = *reinterpret_cast<const f4*>(w + (kh * 3 + kw) * C + cq * 4);
-                acc += wv * xv;
+                const float xv = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[gy * W + gx] : 0.f;
+                acc += wv[kh * 3 + kw] * xv;
             }
-        const f4 sc = *reinterpret_cast<const f4*>(scale + cq * 4), sh = *reinterpret_cast<const f4*>(shift + cq * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
         *reinterpret_cast<f4*>(y + p * C + cq * 4) = acc * sc + sh;
@@ -756,9 +762,9 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
 extern "C" int eg_stem_conv(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift,
                             float* y, int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream) {
     EG_REQUIRE(x && w9xc && bias && scale && shift && y && batch > 0, EG_ERR_BAD_ARG, "eg_stem_conv: null pointer");
-    EG_REQUIRE(c % 4 == 0 && c <= 128, EG_ERR_UNSUPPORTED, "eg_stem_conv: C=%d", c);
+    EG_REQUIRE(c % 4 == 0 && c <= 128 && 256 % (c / 4) == 0, EG_ERR_UNSUPPORTED, "eg_stem_conv: C=%d", c);
     const size_t total = (size_t)batch * h * wdt * (c / 4);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);     // 256 % (C/4) == 0: a thread keeps its channel quad
     hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w9xc, bias, scale, shift, y,
                        batch, h, wdt, c);
     return eg_check_launch("stem_conv");

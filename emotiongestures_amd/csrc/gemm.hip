@@ -588,7 +588,7 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         EG_REQUIRE((p.n & 3) == 0 && (p.yK & 63) == 0 && (p.yk0 & 7) == 0, EG_ERR_ALIGN, "egi_linear: image output alignment");
         a.yimg = reinterpret_cast<unsigned short*>(p.yimg); a.yKO = p.yK >> 3; a.yoct0 = p.yk0 >> 3;
     }
-    EgProfScope prof(2, 2.0 * p.m * (double)p.n * p.k, st);
+    EgProfScope prof(p.precision == EG_PREC_F32 ? 5 : ((p.ximg) ? 3 : (p.a_shift ? 4 : 2)), 2.0 * p.m * (double)p.n * p.k, st);
     if (p.ximg && p.precision != EG_PREC_F32) {
         EG_REQUIRE((p.xK & 63) == 0 && (p.xk0 & 31) == 0 && (p.k & 31) == 0, EG_ERR_ALIGN, "egi_linear: pre-split X needs K %% 32 == 0");
         const int xko = p.xK >> 3, mt = eg_cdiv(p.m, 64);
@@ -616,7 +616,7 @@ extern "C" int eg_linear(const float* x, int32_t lda, const float* w, int32_t ld
     EG_REQUIRE(a_shift == 0 || a_seq > 0, EG_ERR_BAD_ARG, "eg_linear: a_seq must be positive when a_shift is set");
     a.bias = bias; a.res1 = res1; a.res2 = res2; a.ldr = ldr; a.y = y; a.ldc = ldc; a.relu = relu;
     a.a_shift = a_shift; a.a_seq = a_seq > 0 ? a_seq : 1; a.k_per_split = (int)eg_round_up(k, 64); a.partial = nullptr;
-    EgProfScope prof(2, 2.0 * m * (double)n * k, (hipStream_t)stream);
+    EgProfScope prof(precision == EG_PREC_F32 ? 5 : (a_shift ? 4 : 2), 2.0 * m * (double)n * k, (hipStream_t)stream);
     return launch_gemm(a, 1, precision, (hipStream_t)stream);
 }
 

@@ -180,7 +180,7 @@ struct PriorArgs {
     float* cat;                 // [B,F,Dpad] = cat(prior, pred), zero padded
     float* tm_mem;              // [B,D]
     float* tm_pe;               // [B,chunk]
-    int P, PL, D, Dpad, chunk, variant;
+    int P, PL, D, Dpad, chunk, variant, stage_w;
 };
 
 __device__ __forceinline__ float block_dot(const float* __restrict__ wrow, const float* __restrict__ xs, int n, int lane) {
@@ -199,6 +199,14 @@ __global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
     float* v0 = h2 + PL * D;            // [chunk*D] flat chunk / scratch
     float* v1 = v0 + a.chunk * D;       // [D]
     float* v2 = v1 + D;                 // [D]
+    float* w1s = v2 + D;                // [PL*P*3]   conv weights staged once (each is re-read D times per output row)
+    float* w2s = w1s + PL * P * 3;      // [PL*PL*3]
+    if (a.stage_w) {
+        for (int i = tid; i < PL * P * 3; i += 256) w1s[i] = a.w1[i];
+        for (int i = tid; i < PL * PL * 3; i += 256) w2s[i] = a.w2[i];
+    }
+    const float* w1p = a.stage_w ? w1s : a.w1;
+    const float* w2p = a.stage_w ? w2s : a.w2;
     for (int i = tid; i < P * DW; i += 256) {
         const int f = i / DW, d = i - f * DW - 1;
         xs[i] = (d >= 0 && d < D) ? a.prior[((size_t)b * P + f) * D + d] : 0.f;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
         const int co = i / D, d = i - co * D;
         float s = a.b1[co];
         for (int ci = 0; ci < P; ++ci) {
-            const float* wp = a.w1 + (co * P + ci) * 3;
+            const float* wp = w1p + (co * P + ci) * 3;
             const float* xp = xs + ci * DW + d;
             s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
         }
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
         const int co = i / D, d = i - co * D;
         float s = a.b2[co];
         for (int ci = 0; ci < PL; ++ci) {
-            const float* wp = a.w2 + (co * PL + ci) * 3;
+            const float* wp = w2p + (co * PL + ci) * 3;
             const float* xp = h1 + ci * DW + d;
             s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
         }
@@ -542,7 +550,10 @@ int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float*
     a.cat = cat; a.tm_mem = tm_mem; a.tm_pe = tm_pe;
     a.P = P; a.PL = F - P; a.D = D; a.Dpad = Dpad; a.chunk = chunk; a.variant = variant;
     const int PL = F - P;
-    const size_t smem = sizeof(float) * ((size_t)P * (D + 2) + (size_t)PL * (D + 2) + (size_t)PL * D + (size_t)chunk * D + 2 * (size_t)D);
+    const size_t base = sizeof(float) * ((size_t)P * (D + 2) + (size_t)PL * (D + 2) + (size_t)PL * D + (size_t)chunk * D + 2 * (size_t)D);
+    const size_t wbytes = sizeof(float) * ((size_t)PL * P * 3 + (size_t)PL * PL * 3);
+    a.stage_w = (base + wbytes <= 160 * 1024) ? 1 : 0;          // conv weights in LDS when they fit, else read through L1
+    const size_t smem = base + (a.stage_w ? wbytes : 0);
     if (smem > 160 * 1024) { eg_set_error("prior encoder: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
     static bool once = false;
     if (!once) {

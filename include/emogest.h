@@ -59,7 +59,8 @@ int eg_get_default_precision(void);
 /* Optional per-launch timing of the contraction kernels (bench.py's roofline leg; a debugging facility, process
  * global, not thread safe).  While enabled, every eg_conv3x3 / eg_linear launch is bracketed by a hipEvent pair on its
  * own stream (no synchronisation).  eg_profile_read synchronises those events and returns, per record, a tag
- * (conv: cin*1000000 + cout*1000 + stride*100 + 1; linear: 2) , its work in FLOP and its duration in ms. */
+ * (conv: cin*1000000 + cout*1000 + stride*100 + 1; linear: 2 = LDS-DMA kernel, 3 = pre-split-input kernel, 4 = causal-shift
+ * kernel, 5 = f32 kernel), its work in FLOP and its duration in ms. */
 int eg_profile_enable(int32_t max_records);
 int eg_profile_disable(void);
 int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacity);
