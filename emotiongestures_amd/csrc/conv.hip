@@ -754,7 +754,8 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
         if (coutp <= 48) return launch_conv<128, 3, 1, 4, 4, 1>(a, batch, precision, st);
         return launch_conv<128, 4, 1, 4, 4, 1>(a, batch, precision, st);
     }
-    if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4, 2, 2>(a, batch, precision, st);
+    // final_conv1 with 65..128 frames (BEAT-long, 120): the 128-wide body kernel on weights zero-padded to 128 channels
+    if (cin == 128 && coutp <= 128 && stride == 1) return launch_conv<128, 8, 1, 4, 2, 2>(a, batch, precision, st);
     eg_set_error("eg_conv3x3: unsupported channels cin=%d cout=%d stride=%d", cin, cout, stride);
     return EG_ERR_UNSUPPORTED;
 }

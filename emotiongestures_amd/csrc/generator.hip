@@ -273,7 +273,7 @@ GenWs carve(const EgGenerator* g, int B, int NB = 0) {
     w.amap = cv.take(BF * g->HW3);
     w.afc1 = cv.take(BF * D); w.afeat = cv.take(BF * D);
     w.emo_t = cv.take(BF * D * 2); w.emo = cv.take(BF * D); w.sem_t = cv.take(16); w.sem = cv.take(BF * D);
-    w.cls_part = cv.take((int64_t)64 * B * D);
+    w.cls_part = cv.take((int64_t)(c.frames > 64 ? c.frames : 64) * B * D);
     w.cls_h[0] = cv.take((int64_t)B * D); w.cls_h[1] = cv.take((int64_t)B * 256); w.cls_h[2] = cv.take((int64_t)B * 64);
     w.cls_out = cv.take((int64_t)B * 16);
     w.fus_in = cv.take(NF * D); w.fus_h = cv.take(NF * D); w.fusion = cv.take(NF * D);
@@ -491,7 +491,7 @@ int validate_cfg(const EgGeneratorConfig& c) {
     EG_REQUIRE(c.d_model % 64 == 0 && c.d_model >= 64 && c.d_model <= 2048, EG_ERR_UNSUPPORTED, "config: d_model=%d", c.d_model);
     EG_REQUIRE(c.d_k == 64 && c.n_head * c.d_k == c.d_model, EG_ERR_UNSUPPORTED, "config: heads*d_k must equal d_model with d_k=64");
     EG_REQUIRE(c.n_mels % 16 == 0 && c.n_mels <= 512 && c.spec_len >= 4, EG_ERR_UNSUPPORTED, "config: spectrogram %dx%d", c.n_mels, c.spec_len);
-    EG_REQUIRE(c.frames <= 64, EG_ERR_UNSUPPORTED, "config: frames=%d > 64 (final conv width)", c.frames);
+    EG_REQUIRE(c.frames <= 128, EG_ERR_UNSUPPORTED, "config: frames=%d > 128 (final conv width)", c.frames);
     EG_REQUIRE(c.embed_dim == c.tcn_hidden && c.embed_dim % 4 == 0, EG_ERR_UNSUPPORTED, "config: TCN needs embed_dim == hidden, %%4");
     EG_REQUIRE(c.variant == 0 || c.variant == 1, EG_ERR_BAD_ARG, "config: variant=%d", c.variant);
     EG_REQUIRE(c.precision >= 0 && c.precision <= 2, EG_ERR_BAD_ARG, "config: precision=%d", c.precision);
@@ -559,6 +559,13 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
         }
     }
     g->final_conv = add_conv3(L, "audio_encoder.final_conv1", 128, F, 1);
+    if (g->final_conv.coutp > 64) {         // 65..128 frames run on the 128-wide kernel: pad the packed weights to 128 channels
+        g->final_conv.coutp = 128;
+        L.entries.back().dims[2] = 128;
+        L.total -= L.entries.back().numel;
+        L.entries.back().numel = (int64_t)9 * 128 * 128 * 2;
+        L.total += L.entries.back().numel;
+    }
     g->final_conv.bias = L.vec("audio_encoder.final_conv1.bias", F, g->final_conv.coutp);
     add_bn(L, "audio_encoder.bn1", F, g->final_conv.coutp, g->final_conv.scale, g->final_conv.shift);
     g->a_fc1 = add_linear(L, "audio_encoder.fc1", D, g->HW3, true);

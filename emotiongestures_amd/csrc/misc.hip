@@ -180,7 +180,7 @@ struct PriorArgs {
     float* cat;                 // [B,F,Dpad] = cat(prior, pred), zero padded
     float* tm_mem;              // [B,D]
     float* tm_pe;               // [B,chunk]
-    int P, PL, D, Dpad, chunk, variant, stage_w;
+    int P, PL, D, Dpad, chunk, variant, stage_w, dchunk;
 };
 
 __device__ __forceinline__ float block_dot(const float* __restrict__ wrow, const float* __restrict__ xs, int n, int lane) {
@@ -190,57 +190,63 @@ __device__ __forceinline__ float block_dot(const float* __restrict__ wrow, const
 }
 
 __global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
+    // one workgroup = (clip, slice [d0, d0+dc) of the pose axis); the two stacked k=3 convs need a halo of 2 on the input and
+    // 1 on the hidden map.  The memory variant (SP_v1 / TM need whole-row inner products) runs with one slice = the whole axis.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int P = a.P, PL = a.PL, D = a.D, DW = D + 2;
-    float* xs = sm;                     // [P][D+2]  (zero halo)
-    float* h1 = xs + P * DW;            // [PL][D+2]
-    float* h2 = h1 + PL * DW;           // [PL][D]
-    float* v0 = h2 + PL * D;            // [chunk*D] flat chunk / scratch
-    float* v1 = v0 + a.chunk * D;       // [D]
-    float* v2 = v1 + D;                 // [D]
-    float* w1s = v2 + D;                // [PL*P*3]   conv weights staged once (each is re-read D times per output row)
-    float* w2s = w1s + PL * P * 3;      // [PL*PL*3]
+    const int P = a.P, PL = a.PL, D = a.D;
+    const int d0 = blockIdx.y * a.dchunk, dc = min(a.dchunk, D - d0);
+    const int XW = dc + 4, HW = dc + 2;
+    float* xs = sm;                     // [P][dc+4]   x[d0-2 .. d0+dc+1], zero outside [0, D)
+    float* h1 = xs + P * XW;            // [PL][dc+2]  hidden[d0-1 .. d0+dc], zero outside [0, D) (conv2's padding)
+    float* h2 = h1 + PL * HW;           // [PL][dc]
+    float* v0 = h2 + PL * dc;           // [chunk*D] flat chunk / scratch (memory variant)
+    float* v1 = v0 + (a.variant == 1 ? a.chunk * D : 0);
+    float* v2 = v1 + (a.variant == 1 ? D : 0);
+    float* w1s = v2 + (a.variant == 1 ? D : 0);         // conv weights staged once when they fit
+    float* w2s = w1s + PL * P * 3;
     if (a.stage_w) {
         for (int i = tid; i < PL * P * 3; i += 256) w1s[i] = a.w1[i];
         for (int i = tid; i < PL * PL * 3; i += 256) w2s[i] = a.w2[i];
     }
     const float* w1p = a.stage_w ? w1s : a.w1;
     const float* w2p = a.stage_w ? w2s : a.w2;
-    for (int i = tid; i < P * DW; i += 256) {
-        const int f = i / DW, d = i - f * DW - 1;
+    for (int i = tid; i < P * XW; i += 256) {
+        const int f = i / XW, d = d0 - 2 + (i - f * XW);
         xs[i] = (d >= 0 && d < D) ? a.prior[((size_t)b * P + f) * D + d] : 0.f;
     }
-    for (int i = tid; i < PL * DW; i += 256) h1[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < PL * D; i += 256) {
-        const int co = i / D, d = i - co * D;
-        float s = a.b1[co];
-        for (int ci = 0; ci < P; ++ci) {
-            const float* wp = w1p + (co * P + ci) * 3;
-            const float* xp = xs + ci * DW + d;
-            s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
+    for (int i = tid; i < PL * HW; i += 256) {
+        const int co = i / HW, j = i - co * HW, d = d0 - 1 + j;
+        float v = 0.f;
+        if (d >= 0 && d < D) {
+            float s = a.b1[co];
+            for (int ci = 0; ci < P; ++ci) {
+                const float* wp = w1p + (co * P + ci) * 3;
+                const float* xp = xs + ci * XW + j;           // x[d-1], x[d], x[d+1]
+                s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
+            }
+            v = fmaxf(s, 0.f) * a.s1[co] + a.t1[co];
         }
-        h1[co * DW + d + 1] = fmaxf(s, 0.f) * a.s1[co] + a.t1[co];
+        h1[i] = v;
     }
     __syncthreads();
-    for (int i = tid; i < PL * D; i += 256) {
-        const int co = i / D, d = i - co * D;
+    for (int i = tid; i < PL * dc; i += 256) {
+        const int co = i / dc, j = i - co * dc;
         float s = a.b2[co];
         for (int ci = 0; ci < PL; ++ci) {
             const float* wp = w2p + (co * PL + ci) * 3;
-            const float* xp = h1 + ci * DW + d;
+            const float* xp = h1 + ci * HW + j;               // hidden[d-1], [d], [d+1]
             s += wp[0] * xp[0] + wp[1] * xp[1] + wp[2] * xp[2];
         }
         h2[i] = fmaxf(s, 0.f) * a.s2[co] + a.t2[co];
     }
     __syncthreads();
-    if (a.variant == 1) {
+    if (a.variant == 1) {               // d0 == 0, dc == D here
         const int CD = a.chunk * D;
-        // flat last-chunk prior frames (Models_memory.py:237)
-        for (int i = tid; i < CD; i += 256) {
+        for (int i = tid; i < CD; i += 256) {               // flat last-chunk prior frames (Models_memory.py:237)
             const int f = i / D, d = i - f * D;
-            v0[i] = xs[(P - a.chunk + f) * DW + d + 1];
+            v0[i] = xs[(P - a.chunk + f) * XW + d + 2];
         }
         __syncthreads();
         // SP_v1: mem = L1(L0(flat)) ; s = sigmoid(<mem, pred_c>) ; pred_c = s*pred_c + (1-s)*mem
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
             if (lane == 0) v2[n] = s + a.sp_b1[n];
         }
         __syncthreads();
-        // TM memory encoding uses the same flat chunk (Models_memory.py:285): compute before v0 is reused
+        // TM memory encoding uses the same flat chunk (Models_memory.py:285): compute before v1 is reused
         for (int n = wave; n < D; n += 4) {
             const float s = block_dot(a.tc_w0 + (size_t)n * CD, v0, CD, lane);
             if (lane == 0) v1[n] = s + a.tc_b0[n];
@@ -282,11 +288,13 @@ __global__ __launch_bounds__(256) void prior_pred_kernel(PriorArgs a) {
             a.tm_pe[(size_t)b * a.chunk + tid] = s;
         }
     }
+    // cat(prior, pred) rows for this slice; the last slice also zeroes the pad columns [D, Dpad)
     const int F = P + PL;
-    for (int i = tid; i < F * a.Dpad; i += 256) {
-        const int f = i / a.Dpad, d = i - f * a.Dpad;
+    const int dend = (d0 + dc >= D) ? a.Dpad : d0 + dc, wcols = dend - d0;
+    for (int i = tid; i < F * wcols; i += 256) {
+        const int f = i / wcols, d = d0 + (i - f * wcols);
         float v = 0.f;
-        if (d < D) v = f < P ? xs[f * DW + d + 1] : h2[(f - P) * D + d];
+        if (d < D) v = f < P ? xs[f * XW + (d - d0) + 2] : h2[(f - P) * dc + (d - d0)];
         a.cat[((size_t)b * F + f) * a.Dpad + d] = v;
     }
 }
@@ -550,7 +558,10 @@ int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float*
     a.cat = cat; a.tm_mem = tm_mem; a.tm_pe = tm_pe;
     a.P = P; a.PL = F - P; a.D = D; a.Dpad = Dpad; a.chunk = chunk; a.variant = variant;
     const int PL = F - P;
-    const size_t base = sizeof(float) * ((size_t)P * (D + 2) + (size_t)PL * (D + 2) + (size_t)PL * D + (size_t)chunk * D + 2 * (size_t)D);
+    a.dchunk = variant == 1 ? D : (D < 64 ? D : 64);
+    const int dc = a.dchunk;
+    const size_t base = sizeof(float) * ((size_t)P * (dc + 4) + (size_t)PL * (dc + 2) + (size_t)PL * dc +
+                                         (variant == 1 ? (size_t)chunk * D + 2 * (size_t)D : 0));
     const size_t wbytes = sizeof(float) * ((size_t)PL * P * 3 + (size_t)PL * PL * 3);
     a.stage_w = (base + wbytes <= 160 * 1024) ? 1 : 0;          // conv weights in LDS when they fit, else read through L1
     const size_t smem = base + (a.stage_w ? wbytes : 0);
@@ -560,7 +571,7 @@ int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float*
         hipFuncSetAttribute(reinterpret_cast<const void*>(prior_pred_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    hipLaunchKernelGGL(prior_pred_kernel, dim3(batch), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(prior_pred_kernel, dim3(batch, eg_cdiv(D, dc)), dim3(256), smem, st, a);
     int rc = eg_check_launch("prior_pred");
     if (rc || variant != 1) return rc;
     hipLaunchKernelGGL(tm_gram_kernel, dim3(eg_cdiv(D * chunk, 256)), dim3(256), 0, st, tm_mem, tm_pe, tm_gram, batch, D, chunk);
@@ -575,7 +586,16 @@ int egi_conv1d(const float* x, const float* w, const float* bias, const float* s
     const int per_wave = eg_cdiv(cout, 4);
     const int cog = per_wave <= 4 ? 4 : (per_wave <= 8 ? 8 : 16);
     const size_t smem = sizeof(float) * ((((size_t)cin * (63 * stride + k) + 3) & ~(size_t)3) + (size_t)cin * k * 4 * cog);
-    if (smem > 64 * 1024) { eg_set_error("conv1d: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
+    if (smem > 160 * 1024) { eg_set_error("conv1d: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
+    if (smem > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once = true;
+        }
+    }
     dim3 grid(eg_cdiv(lout, 64), n, eg_cdiv(cout, 4 * cog));
     if (cog == 4)
         hipLaunchKernelGGL((conv1d_kernel<4>), grid, dim3(256), smem, st, x, w, bias, scale, shift, y, cin, cout, lin, lout, k, stride, pad, act);

@@ -532,6 +532,9 @@ class Transformer(nn.Module):
                 nn.init.xavier_uniform_(p)
         if d_k != d_v:
             raise NotImplementedError("HIP path: d_k == d_v")
+        if n_position < frames:
+            raise ValueError(f"n_position={n_position} < frames={frames}: the positional table would be too short "
+                             "(the reference hard-codes n_position=60, Models_spatial_memory.py:477)")
         self._cfg = dict(frames=frames, pose_dim=pose_dim, prior_frames=prior_frames, chunk=args.chunk, d_model=d_model,
                          d_inner=d_inner, n_layers=n_layers, n_head=n_head, d_k=d_k, n_mels=n_mels, spec_len=spec_len,
                          text_len=60, n_words=lang_model.n_words, embed_dim=args.wordembed_dim, tcn_hidden=args.hidden_size,

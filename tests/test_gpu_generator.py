@@ -192,3 +192,33 @@ def test_melspectrogram_matches_oracle():
     assert np.abs(g2 - O.melspectrogram(short)).max() <= 0.0626
     silent = mel(torch.zeros(1, 16000, device=dev())).cpu().numpy()
     assert np.all(silent == 0.0)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_beat_long_120_frames_matches_oracle(prec):
+    """BASELINE config 4 (10 s audio -> spec 128x312, 120 frames, pose_dim 282, prior 10).  The reference hard-codes
+    32*31 / n_position=60 / 60 CVAE channels, so the checker here is the oracle, which is generic."""
+    from conftest import make_args, make_lang
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.Full_model.Models_spatial_memory import Transformer
+    from oracle import emogest_oracle as O
+    F, D, P, T = 120, 282, 10, 312
+    model = Transformer(make_args(10), make_lang(200), frames=F, pose_dim=D, prior_frames=P, d_word_vec=512, d_model=512, d_inner=2048,
+                        n_layers=3, n_head=8, d_k=64, d_v=64, n_position=F, spec_len=T, precision=prec)
+    load_synth_weights(model, 21).eval()
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=F), 21).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sdv = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    inp = synth_inputs(2, F, D, P, spec_len=T, seed=21)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    with torch.no_grad():
+        s_ref = O.cvae_sample(sdv, t["label"], t["z"])
+        ref = O.generator_forward(sd, O.GenCfg(frames=F, pose_dim=D, prior_frames=P, chunk=10), t["spec"], t["text"], t["pre_pose"], s_ref)
+    model.to(dev()); vae.to(dev())
+    with torch.no_grad():
+        s = vae.sample(t["label"].to(dev()), z=t["z"])
+        got = model(t["spec"].to(dev()), t["text"].to(dev()), t["pre_pose"].to(dev()), s)
+    assert tuple(got[0].shape) == (2, F, D)
+    assert rel_l2(s.cpu().numpy(), s_ref.numpy()) < 1e-5
+    assert clip_rel_l2(got[0].cpu().numpy(), ref[0].numpy()) < POSE_TOL[prec]
+    assert rel_l2(got[3].cpu().numpy(), ref[3].numpy()) < POSE_TOL[prec] * 5
