@@ -113,13 +113,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)            # (ranks > GPUs only happens in the single-GPU gloo smoke test of this launcher path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    backend = os.environ.get("EG_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from emotiongestures_amd import _lib
     lib = _lib.load()
@@ -179,12 +185,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     total_clips = B * world * args.steps
     value = total_clips / elapsed
 
+    timed_concurrent = bool(gen.concurrent)
     # ---- parity spot check on this very batch (first 2 clips) against the CPU oracle ----
     parity = None
     roof = None
@@ -245,7 +252,7 @@ def main():
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "variant": "Models_spatial_memory",
                        "parallelism": f"clip-sharded x{world}, no data-path collective",
                        "launch": "eager" if graph is None else "hipGraph replay",
-                       "branch_streams": bool(gen.concurrent),
+                       "branch_streams": timed_concurrent,
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
             "pose_rel_l2_vs_cpu_oracle": parity, "roofline": roof, "cpu_baseline": cpu,
         }
