@@ -4,7 +4,8 @@ Layout:
   csrc/ + libemogest_hip.so   hand-written HIP kernels behind the C ABI of include/emogest.h
   _lib / packing / engine / ops  ctypes binding, weight-arena packing, per-batch engines, block operators
   modules                     host mirror of the reference's nn.Module surface
-  Full_model/, CAVE/          the reference's import paths (thin re-exports of ``modules``)
+  Full_model/, CAVE/, model/, skeleton_classifer/   the reference's import paths (thin re-exports of ``modules`` / ``harness``)
+  harness                     the eval loop around the generator: FGD features, Frechet/diversity, emotion classifier
   synth                       platform-exact synthetic weights / inputs
   dist                        clip sharding across ranks (one process per GPU)
 """
@@ -20,9 +21,10 @@ def install_aliases() -> None:
     import importlib
     import sys
 
-    for top in ("Full_model", "CAVE"):
+    for top in ("Full_model", "CAVE", "model", "skeleton_classifer"):
         pkg = importlib.import_module(f"{__name__}.{top}")
         sys.modules.setdefault(top, pkg)
     for name in ("Full_model.Models_spatial_memory", "Full_model.Models_memory", "Full_model.Layers", "Full_model.SubLayers",
-                 "Full_model.Modules", "Full_model.tcn", "Full_model.ResNetSE34V2", "Full_model.ResNetBlocks", "CAVE.BEAT_CVAE"):
+                 "Full_model.Modules", "Full_model.tcn", "Full_model.ResNetSE34V2", "Full_model.ResNetBlocks", "CAVE.BEAT_CVAE",
+                 "model.FGD", "model.FHD_score", "skeleton_classifer.Models"):
         sys.modules.setdefault(name, importlib.import_module(f"{__name__}.{name}"))

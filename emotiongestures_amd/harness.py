@@ -1,0 +1,226 @@
+"""Evaluation harness of the audio->gesture path.
+
+Mirrors what the reference's eval loop does around the generator
+(test_emotion_gesture_diversity_iterative.py:191-261): CVAE sample -> generator -> pose, then the FGD auto-encoder
+features of predicted and target poses (model/FGD.py:26-82), their Frechet distance and diversity score
+(model/FHD_score.py:159-217,247-311), MPJRE, pose L2 and the emotion accuracy of a skeleton classifier
+(skeleton_classifer/Models.py:199-283).  The beat-alignment score is left out: it is a per-sample librosa routine
+(model/Beat_score_v2.py) and librosa is neither vendored nor installed.
+
+Every network forward runs on the GPU through libemogest_hip.so (the FGD encoder and the classifier are built from the
+same Linear / attention / LayerNorm operators as the generator); the Gaussian statistics and the matrix square root
+stay float64 numpy/scipy on the host exactly as upstream.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .modules import Encoder, Linear, _eval_only, _seq
+
+__all__ = ["MLP_Reconstruct", "SkeletonTransformer", "Prior_Encoder", "compute_acc", "l2_distance_pose", "mpjre", "calc_motion",
+           "calculate_frechet_distance", "calculate_diversity", "diversity_score", "evaluate"]
+
+
+class _PackCache:
+    """Packed (EG_PACK_LINEAR) copies of nn.Linear weights, rebuilt only when the parameter changes."""
+
+    def __init__(self):
+        self._c: Dict[int, tuple] = {}
+
+    def get(self, lin: Linear, device):
+        key = id(lin)
+        ver = (lin.weight._version, str(device))
+        hit = self._c.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_linear_weight(lin.weight, device))
+            self._c[key] = hit
+        return hit[1]
+
+
+def _affine_chain(cache: _PackCache, x: torch.Tensor, layers, relu_between: bool, precision: str) -> torch.Tensor:
+    """x [rows, K] through Linear layers (optionally ReLU between them, never after the last)."""
+    for i, lin in enumerate(layers):
+        last = i == len(layers) - 1
+        k = lin.weight.shape[1]
+        if k % 4:                         # e.g. pose_dim 282/126: pad K with zero columns (layout plumbing)
+            pad = (-k) % 4
+            x = torch.cat([x, x.new_zeros(x.shape[0], pad)], 1)
+            w = torch.cat([lin.weight, lin.weight.new_zeros(lin.weight.shape[0], pad)], 1)
+            x = ops.linear(x, w, lin.bias, relu=relu_between and not last, precision=precision)
+        elif x.shape[0] <= 64 and k >= 8192:
+            x = ops.linear_splitk(x, lin.weight, lin.bias, relu=relu_between and not last, splits=max(1, k // 512), precision=precision)
+        else:
+            x = ops.linear(x, lin.weight, lin.bias, relu=relu_between and not last, precision=precision, packed=cache.get(lin, x.device))
+    return x
+
+
+class MLP_Reconstruct(nn.Module):
+    """model/FGD.py:26-82: per-frame pose auto-encoder whose 512-d latent is the FGD feature.  ``pose_dim`` is 282 upstream
+    (hard-coded :32,58); Dropout layers are identity in eval."""
+
+    def __init__(self, bath=True, *, pose_dim=282, precision="f32"):
+        super().__init__()
+        self.Encoder = _seq(Linear(pose_dim, 512), None, Linear(512, 512), None, Linear(512, 512))
+        self.Decoder = _seq(Linear(512, 512), None, Linear(512, 512), None, Linear(512, pose_dim))
+        self.precision = precision
+        self._cache = _PackCache()
+
+    def forward(self, Input):
+        _eval_only(self)
+        shp = Input.shape
+        x = Input.reshape(-1, shp[-1]).contiguous()
+        latent = _affine_chain(self._cache, x, [self.Encoder[0], self.Encoder[2], self.Encoder[4]], False, self.precision)
+        out = _affine_chain(self._cache, latent, [self.Decoder[0], self.Decoder[2], self.Decoder[4]], False, self.precision)
+        return out.view(*shp[:-1], out.shape[-1]), latent.view(*shp[:-1], 512)
+
+
+class Prior_Encoder(nn.Module):
+    """skeleton_classifer/Models.py:88-116"""
+
+    def __init__(self, pose_dim, d_model):
+        super().__init__()
+        self.fc1, self.fc2 = Linear(pose_dim, d_model), Linear(d_model, d_model)
+
+
+class SkeletonTransformer(nn.Module):
+    """skeleton_classifer/Models.py:199-283: emotion classifier on a pose sequence -> (logits [B,8], mid_feature [B,T,d])."""
+
+    def __init__(self, class_dim=8, pose_dim=242, src_pad_idx=1, trg_pad_idx=1, d_word_vec=64, d_model=64, d_inner=512,
+                 n_layers=3, n_head=8, d_k=32, d_v=32, dropout=0.2, n_position=60, *, precision="f32"):
+        super().__init__()
+        assert d_model == d_word_vec
+        self.d_model = d_model
+        self.prior_seq_encoder = Prior_Encoder(pose_dim, d_model)
+        self.post_projector = _seq(Linear(n_position * d_model, d_model * 4), None, Linear(d_model * 4, d_model), None,
+                                   Linear(d_model, 128), None, Linear(128, 64), None, Linear(64, class_dim))
+        self.encoder = Encoder(n_position=n_position, d_word_vec=d_word_vec, d_model=d_model, d_inner=d_inner, n_layers=n_layers,
+                               n_head=n_head, d_k=d_k, d_v=d_v, pad_idx=src_pad_idx, dropout=dropout)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.precision = precision
+        self._cache = _PackCache()
+
+    def forward(self, prior_seq):
+        _eval_only(self)
+        B, T, D = prior_seq.shape
+        for layer in self.encoder.layer_stack:
+            layer.slf_attn.precision = layer.pos_ffn.precision = self.precision
+        x = _affine_chain(self._cache, prior_seq.reshape(B * T, D).contiguous(), [self.prior_seq_encoder.fc1, self.prior_seq_encoder.fc2],
+                          False, self.precision).view(B, T, self.d_model)
+        enc, *_ = self.encoder(x, None)
+        mid = enc
+        head = [self.post_projector[i] for i in (0, 2, 4, 6, 8)]
+        logits = _affine_chain(self._cache, enc.reshape(B, -1).contiguous(), head, True, self.precision)
+        return logits, mid
+
+
+# ---- metrics (host side, as upstream) ---------------------------------------------------------------------------------
+def compute_acc(input_label: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """test_emotion_gesture_diversity_iterative.py:35-39"""
+    pred = out.topk(1, 1)[1].squeeze(1)
+    return 100 * torch.true_divide(torch.sum(pred == input_label), input_label.size(0))
+
+
+def calc_motion(motion: torch.Tensor) -> torch.Tensor:
+    """test_emotion_gesture_diversity_iterative.py:41-44 (frame-to-frame offsets; 60 upstream = n_frames)."""
+    n = motion.shape[1]
+    return motion[:, 1:n, :] - motion[:, : n - 1, :]
+
+
+def l2_distance_pose(fake: np.ndarray, gt: np.ndarray) -> float:
+    """test_emotion_gesture_diversity_iterative.py:46-49"""
+    return float(np.mean(np.linalg.norm(gt - fake, axis=-1)))
+
+
+def mpjre(target: torch.Tensor, pred: torch.Tensor) -> float:
+    """Mean per-joint rotation error term, :223 (mean |target - pred| over 6-d groups)."""
+    b = target.shape[0]
+    return float(torch.mean(torch.absolute(target.reshape(b, -1, 6) - pred.reshape(b, -1, 6))))
+
+
+def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """model/FHD_score.py:159-217: ||mu1-mu2||^2 + Tr(C1 + C2 - 2 sqrt(C1 C2)), float64, scipy sqrtm; returns 100 when the
+    square root has a non-negligible imaginary part (as upstream)."""
+    from scipy import linalg
+
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    assert mu1.shape == mu2.shape and sigma1.shape == sigma2.shape
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            return 100
+        covmean = covmean.real
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+
+
+def calculate_diversity(activations: np.ndarray, labels, diversity_times: int = 5) -> np.float32:
+    """model/FHD_score.py:270-286: mean L2 distance of `diversity_times` random pairs (np.random.randint twice, in that order)."""
+    num = len(labels)
+    first = np.random.randint(0, num, diversity_times)
+    second = np.random.randint(0, num, diversity_times)
+    acc = 0.0
+    for i, j in zip(first, second):
+        acc += float(np.sqrt(((activations[i] - activations[j]) ** 2).sum()))
+    return np.float32(acc / diversity_times)
+
+
+def diversity_score(activations: np.ndarray, frames: int = 60):
+    """model/FHD_score.py:247-268: 10 repeats of calculate_diversity -> centre and 95 % normal interval."""
+    from scipy import stats
+
+    act = activations.reshape(-1, frames, 512)
+    window = np.empty((10, 1))
+    for i in range(10):
+        window[i] = calculate_diversity(act, act)
+    mean, std = np.mean(window, axis=0), np.std(window, axis=0)
+    interval = stats.norm.interval(0.95, mean, std)
+    return (interval[0] + interval[1]) / 2, interval
+
+
+# ---- the eval loop ---------------------------------------------------------------------------------------------------
+def evaluate(generator, vae, fgd: MLP_Reconstruct, classifier: Optional[SkeletonTransformer], batches: Iterable[dict],
+             n_pre_poses: int, device="cuda", z_list: Optional[list] = None) -> Dict[str, float]:
+    """One pass of test_model's hot loop (:191-261) over an iterable of batches, each a dict with
+    ``spec [B,128,T]``, ``text [B,60]``, ``pose_seq [B,F,D]`` (target; the first n_pre_poses frames are the prior) and
+    ``label [B,8]`` one-hot.  ``z_list`` optionally fixes the CVAE latents per batch (default: torch.randn on the CPU
+    generator as upstream).  Returns the metrics of the summary line (:261) except the beat score."""
+    pred_feats, tgt_feats, l2s, rots, accs = [], [], [], [], []
+    frames = None
+    with torch.no_grad():
+        for bi, batch in enumerate(batches):
+            pose_seq = batch["pose_seq"].to(device)
+            frames = pose_seq.shape[1]
+            pre_pose = pose_seq[:, :n_pre_poses].contiguous()
+            label = batch["label"].to(device)
+            sampled = vae.sample(label, z=None if z_list is None else z_list[bi])                                    # :203
+            pred_pose, _, _, _, _ = generator(batch["spec"].to(device), batch["text"].to(device), pre_pose, sampled)  # :205
+            if classifier is not None:
+                logits, _ = classifier(pred_pose)                                                                    # :217
+                accs.append(float(compute_acc(torch.max(label, 1)[1], logits)))
+            rots.append(mpjre(pose_seq, pred_pose))                                                                 # :223
+            _, pf = fgd(pred_pose)                                                                                   # :226-229
+            _, tf = fgd(pose_seq)
+            pred_feats.append(pf.reshape(-1, 512).cpu().numpy().astype(np.float64))
+            tgt_feats.append(tf.reshape(-1, 512).cpu().numpy().astype(np.float64))
+            l2s.append(l2_distance_pose(pred_pose.cpu().numpy().astype(np.float32), pose_seq.cpu().numpy().astype(np.float32)))
+    pred_arr, tgt_arr = np.concatenate(pred_feats), np.concatenate(tgt_feats)
+    fid = calculate_frechet_distance(np.mean(pred_arr, axis=0), np.cov(pred_arr, rowvar=False),
+                                     np.mean(tgt_arr, axis=0), np.cov(tgt_arr, rowvar=False))                       # :250-255
+    div, interval = diversity_score(pred_arr, frames)                                                               # :256
+    out = {"pose_l2": float(np.mean(l2s)), "rotation_deg": float(np.mean(rots)) * 57.2958, "fgd": float(np.real(fid)),
+           "diversity": float(np.ravel(div)[0]), "diversity_lo": float(np.ravel(interval[0])[0]), "diversity_hi": float(np.ravel(interval[1])[0])}
+    if accs:
+        out["emotion_acc"] = float(np.mean(accs))
+    return out

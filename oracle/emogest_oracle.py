@@ -411,6 +411,63 @@ def spectrogram_length(n_frames: int, fps: float) -> int:
 
 
 # --------------------------------------------------------------------------------------------
+# a16 / f1 / f2  eval harness pieces
+# --------------------------------------------------------------------------------------------
+
+def fgd_autoencoder(sd: SD, x: torch.Tensor):
+    """MLP_Reconstruct.forward, model/FGD.py:63-70 (eval: Dropout identity) -> (reconstruction, 512-d latent)."""
+    lat = x
+    for i in (0, 2, 4):
+        lat = _lin(sd, f"Encoder.{i}", lat)
+    out = lat
+    for i in (0, 2, 4):
+        out = _lin(sd, f"Decoder.{i}", out)
+    return out, lat
+
+
+def skeleton_classifier(sd: SD, pose: torch.Tensor, cfg: Optional[GenCfg] = None):
+    """skeleton_classifer.Models.Transformer.forward, skeleton_classifer/Models.py:256-283 -> (logits, mid_feature)."""
+    cfg = cfg or GenCfg()
+    b = pose.shape[0]
+    x = _lin(sd, "prior_seq_encoder.fc2", _lin(sd, "prior_seq_encoder.fc1", pose))
+    enc = encoder(sd, "encoder", x, cfg)
+    h = enc.reshape(b, -1)
+    for i in (0, 2, 4, 6):
+        h = F.relu(_lin(sd, f"post_projector.{i}", h))
+    return _lin(sd, "post_projector.8", h), enc
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2):
+    """calculate_frechet_distance, model/FHD_score.py:159-217 (float64, scipy.linalg.sqrtm)."""
+    from scipy import linalg
+    diff = np.asarray(mu1) - np.asarray(mu2)
+    covmean, _ = linalg.sqrtm(np.asarray(sigma1).dot(np.asarray(sigma2)), disp=False)
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            return 100
+        covmean = covmean.real
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+
+
+def diversity_score(activations: np.ndarray, frames: int = 60):
+    """diversity_score / calculate_diversity, model/FHD_score.py:247-286 (consumes np.random like upstream: two randint(5)
+    draws per repeat, 10 repeats)."""
+    from scipy import stats
+    act = activations.reshape(-1, frames, 512)
+    window = np.empty((10, 1))
+    for i in range(10):
+        first = np.random.randint(0, len(act), 5)
+        second = np.random.randint(0, len(act), 5)
+        d = 0.0
+        for a_, b_ in zip(first, second):
+            d += float(torch.dist(torch.from_numpy(act[a_]), torch.from_numpy(act[b_])))
+        window[i] = np.float32(d / 5)
+    mean, std = np.mean(window, axis=0), np.std(window, axis=0)
+    interval = stats.norm.interval(0.95, mean, std)
+    return (interval[0] + interval[1]) / 2, interval
+
+
+# --------------------------------------------------------------------------------------------
 # convenience
 # --------------------------------------------------------------------------------------------
 

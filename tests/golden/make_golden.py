@@ -127,8 +127,48 @@ def cvae_case(seed=0):
     print("cvae_v3", s.shape, os.path.getsize(path) // 1024, "KiB")
 
 
+def harness_case(seed=0):
+    """FGD auto-encoder, skeleton emotion classifier and the Frechet / diversity metrics of the eval loop
+    (test_emotion_gesture_diversity_iterative.py:217-256) from the reference's own code."""
+    _stub_unused_imports()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from model.FGD import MLP_Reconstruct
+    from model.FHD_score import calculate_frechet_distance, diversity_score
+    from skeleton_classifer.Models import Transformer as Skel
+    from emotiongestures_amd.synth import hash_uniform
+    fgd = load_synth_weights(MLP_Reconstruct(), seed).eval()
+    skel = load_synth_weights(Skel(class_dim=8, pose_dim=282, d_word_vec=512, d_model=512, d_inner=2048, n_layers=3, n_head=8,
+                                   d_k=64, d_v=64, n_position=60), seed).eval()
+    pred = torch.from_numpy(hash_uniform("h/pred", (4, 60, 282), -1.0, 1.0, seed))
+    tgt = torch.from_numpy(hash_uniform("h/tgt", (4, 60, 282), -1.0, 1.0, seed))
+    with torch.no_grad():
+        rec, pf = fgd(pred)
+        _, tf = fgd(tgt)
+        logits, mid = skel(pred)
+    pa, ta = pf.reshape(-1, 512).numpy().astype(np.float64), tf.reshape(-1, 512).numpy().astype(np.float64)
+    fid = calculate_frechet_distance(np.mean(pa, 0), np.cov(pa, rowvar=False), np.mean(ta, 0), np.cov(ta, rowvar=False))
+    np.random.seed(1234)
+    div, interval = diversity_score(pa, torch.device("cpu"))
+    out = {"logits": logits.numpy(), "fid": np.float64(np.real(fid)), "div": np.float64(div[0]),
+           "div_interval": np.asarray([interval[0][0], interval[1][0]], np.float64), "meta": np.asarray([4, 60, 282, seed], np.int64)}
+    out.update(_flat("fgd_latent", digest(pf.numpy(), 8192)))
+    out.update(_flat("fgd_recon", digest(rec.numpy(), 8192)))
+    out.update(_flat("skel_mid", digest(mid.numpy(), 8192)))
+    path = os.path.join(ROOT, "tests", "golden", "harness.npz")
+    np.savez_compressed(path, **out)
+    print("harness fid", fid, "div", div, os.path.getsize(path) // 1024, "KiB")
+    import json
+    schema = {"fgd": [[k, list(v.shape)] for k, v in fgd.state_dict().items()],
+              "skeleton": [[k, list(v.shape)] for k, v in skel.state_dict().items()]}
+    json.dump(schema, open(os.path.join(ROOT, "tests", "golden", "harness_schema.json"), "w"))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "harness":
+        harness_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cvae":
         cvae_case()
         sys.exit(0)
@@ -139,3 +179,4 @@ if __name__ == "__main__":
     generator_case("beat_spatial_b1", "spatial", 1, 60, 282, 10, 10, use_sampled=True, seed=4)
     generator_case("beat_memory_b2", "memory", 2, 60, 282, 10, 10, seed=5)
     cvae_case()
+    harness_case()
