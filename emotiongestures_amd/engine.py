@@ -80,7 +80,7 @@ class GeneratorEngine:
         return ws
 
     # ---- Transformer.forward ----
-    def forward(self, spec, text, prior, sampled=None, want_aux=True):
+    def forward(self, spec, text, prior, sampled=None, want_aux=True, slot=0):
         if self.arena is None:
             raise L.EgError("GeneratorEngine.forward before load_weights")
         dev = self.arena.device
@@ -100,7 +100,7 @@ class GeneratorEngine:
             if tuple(sampled.shape) != (B, c.frames, c.d_model):
                 raise L.EgError(f"sampled_emotion_feature shape {tuple(sampled.shape)} != (B,{c.frames},{c.d_model})")
         ws_bytes = self._lib.eg_generator_workspace_bytes(self._h, B)
-        ws = self._workspace(("fwd", B), ws_bytes, dev)
+        ws = self._workspace(("fwd", B) if slot == 0 else ("fwd", B, slot), ws_bytes, dev)   # one workspace per concurrent slot
         pose = torch.empty(B, c.frames, c.pose_dim, device=dev)
         emo = torch.empty(B, c.frames, c.d_model, device=dev) if want_aux else None
         sem = torch.empty(B, c.frames, c.d_model, device=dev) if want_aux else None

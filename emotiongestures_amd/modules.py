@@ -561,9 +561,9 @@ class Transformer(nn.Module):
             self._engine_key = key
         return self._engine
 
-    def forward(self, input_spectrum, text, prior_seq, sampled_emotion_feature=None):
+    def forward(self, input_spectrum, text, prior_seq, sampled_emotion_feature=None, *, slot=0):
         _eval_only(self)
-        return self.engine().forward(input_spectrum, text, prior_seq, sampled_emotion_feature)
+        return self.engine().forward(input_spectrum, text, prior_seq, sampled_emotion_feature, slot=slot)
 
     def forward_draws(self, input_spectrum, prior_seq, sampled_emotion_features):
         """Diversity sampling (BASELINE config 5): sampled [B,R,frames,d_model] -> pose [B,R,frames,pose_dim]."""
