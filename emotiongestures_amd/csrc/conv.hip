@@ -16,6 +16,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef EG_CONV_SETPRIO
+#define EG_CONV_SETPRIO 0      // measured: pinning the MFMA cluster with s_setprio costs 20-50 % here (hipcc stops interleaving the LDS reads)
+#endif
 #ifndef EG_CONV_RING
 #define EG_CONV_RING 3
 #endif
@@ -301,6 +304,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         }
     };
     auto mfma_step = [&](const Frags& f) {
+#if EG_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -311,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
                 }
                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
             }
+#if EG_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     static_assert(RING == 3, "schedule below assumes a 3-slot ring");
     issue_weights(0, 0);
