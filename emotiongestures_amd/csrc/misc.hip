@@ -63,7 +63,8 @@ constexpr int ATT_QC = 64;      // query rows per workgroup (34- and 60-frame se
 constexpr int ATT_P = 68;       // row pitch in floats
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                         const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
-                                                        float* __restrict__ attn, int H, int Lq, int Lk, float inv_temp) {
+                                                        float* __restrict__ attn, int H, int Lq, int Lk, float inv_temp,
+                                                        unsigned short* __restrict__ oimg, int rows_total) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int qc = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const int q0 = qc * ATT_QC, nq = min(ATT_QC, Lq - q0);
@@ -117,6 +118,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         f4 o = (f4){0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < Lk; ++c) o += *reinterpret_cast<const f4*>(Vs + c * ATT_P + d4 * 4) * Ss[r * LkP + c];
         *reinterpret_cast<f4*>(out + ((size_t)b * Lq + q0 + r) * ldo + h * 64 + d4 * 4) = o;
+        if (oimg) {         // also emit the head-concatenated row as bf16 (hi, lo) tile-planar images for the output projection
+            const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+            bf8 h8, l8;
+            split_octet<true>(o, z, h8, l8);
+            const int row = b * Lq + q0 + r, k = h * 64 + d4 * 4, KO = H * 8;
+            const size_t slot = (((size_t)(row >> 6) * KO + (k >> 3)) * 64 + (row & 63)) * 8 + (k & 7);
+            const size_t lo_off = (size_t)((rows_total + 63) >> 6) * KO * 512;
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4_t hh = __builtin_bit_cast(u32x4_t, h8), ll = __builtin_bit_cast(u32x4_t, l8);
+            *reinterpret_cast<u32x2*>(oimg + slot) = (u32x2){hh[0], hh[1]};
+            *reinterpret_cast<u32x2*>(oimg + lo_off + slot) = (u32x2){ll[0], ll[1]};
+        }
     }
 }
 
@@ -482,9 +495,8 @@ extern "C" int eg_layernorm(const float* x, const float* gamma, const float* bet
     return egi_layernorm(x, gamma, beta, y, nullptr, rows, d, eps, (hipStream_t)stream);
 }
 
-extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
-                            float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
-                            int32_t dk, void* stream) {
+int egi_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, float* attn,
+                  void* oimg, int batch, int heads, int lq, int lk, int dk, hipStream_t st) {
     EG_REQUIRE(q && k && v && out && batch > 0 && heads > 0 && lq > 0 && lk > 0, EG_ERR_BAD_ARG, "eg_attention: null pointer or empty shape");
     EG_REQUIRE(dk == 64, EG_ERR_UNSUPPORTED, "eg_attention: d_k=%d (64 supported)", dk);
     EG_REQUIRE(lk <= 256, EG_ERR_UNSUPPORTED, "eg_attention: Lk=%d > 256", lk);
@@ -498,9 +510,14 @@ extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t
             once = true;
         }
     }
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, attn, heads,
-                       lq, lk, 1.0f / sqrtf((float)dk));
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, st, q, ldq, k, ldk, v, ldv, out, ldo, attn, heads, lq, lk,
+                       1.0f / sqrtf((float)dk), reinterpret_cast<unsigned short*>(oimg), batch * lq);
     return eg_check_launch("attention");
+}
+extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
+                            float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
+                            int32_t dk, void* stream) {
+    return egi_attention(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, dk, (hipStream_t)stream);
 }
 
 extern "C" int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream) {
