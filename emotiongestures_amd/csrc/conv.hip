@@ -47,7 +47,18 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
     __shared__ f4 tile[8 * PL];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
-    const int tile_id = blockIdx.x, b = blockIdx.y;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles
+    // (whole clips at B >= 8); halo rows / columns shared by neighbouring tiles then hit in that XCD's L2.
+    int tile_id = blockIdx.x, b = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const int log = (lin & 7) * (total >> 3) + (lin >> 3);
+            b = log / (int)gridDim.x;
+            tile_id = log - b * (int)gridDim.x;
+        }
+    }
     const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * 32;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
@@ -205,7 +216,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile_id = blockIdx.x, b = blockIdx.y;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles
+    // (whole clips at B >= 8); halo rows / columns shared by neighbouring tiles then hit in that XCD's L2.
+    int tile_id = blockIdx.x, b = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const int log = (lin & 7) * (total >> 3) + (lin >> 3);
+            b = log / (int)gridDim.x;
+            tile_id = log - b * (int)gridDim.x;
+        }
+    }
     const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * 32;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;

@@ -8,6 +8,7 @@
 // LDS images are k-quad (fp32) / k-octet (bf16) planar: [k/4][row][4] -- 64 rows per plane = 0 mod 16 slots, so the
 // ds_read_b128 of 16 consecutive rows is bank-conflict free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -411,53 +412,73 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 // the N/64 workgroups that consume it.  The K loop then has no VALU work at all: LDS-DMA copies of both operands 3 steps
 // ahead, fragments of step s+1 read from LDS while the MFMAs of step s run (register double buffer), one counted vmcnt and
 // one raw barrier per 32-deep step.
-template <int TERMS>
+template <int N> __device__ __forceinline__ void wait_vmcnt_imm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "unsupported vmcnt immediate");
+}
+
+// BK = K elements per barrier interval (32 or 64), RING = LDS slots.  BK 64 halves the barriers / waits per MFMA for the
+// small-grid products (one workgroup per CU anyway); BK 32 x 4 slots keeps two workgroups per CU for the large grids.
+template <int TERMS, int BK, int RING>
 __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr int RING = 4, OP = NIMG * 4 * 64, SLOT = 2 * OP;          // bf8 slots: [X hi|lo][W hi|lo], 4 octets x 64 rows each
-    constexpr int G = 2 * NIMG;                                           // LDS-DMA instructions per wave per step
-    __shared__ bf8 lds[RING * SLOT];
+    constexpr int KG = BK / 32;                                           // MFMA k-groups per step
+    constexpr int OP = NIMG * KG * 4 * 64, SLOT = 2 * OP;                 // bf8 slots: [X hi|lo][W hi|lo], KG*4 octets x 64 rows each
+    constexpr int G = 2 * NIMG * KG;                                      // LDS-DMA instructions per wave per step
+    extern __shared__ __attribute__((aligned(16))) bf8 lds[];             // RING * SLOT
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
-    const int nsteps = (kend - kbeg + 31) / 32;
+    const int nsteps = (kend - kbeg + BK - 1) / BK;
     const int KO = a.ldw >> 3;
     auto issue = [&](int step, int slot) {
-        const int ko = (kbeg + step * 32) >> 3;
+        const int ko = (kbeg + step * BK) >> 3;
         bf8* S = lds + slot * SLOT;
-        const size_t gx = ((size_t)blockIdx.x * xKO + a.xoct0 + ko) * 64 + wave * 64 + lane;
-        const size_t gw = ((size_t)blockIdx.y * KO + ko) * 64 + wave * 64 + lane;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx),
-                                         (__attribute__((address_space(3))) void*)(S + wave * 64), 16, 0, 0);
-        if (TERMS == 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xlo + gx),
-                                             (__attribute__((address_space(3))) void*)(S + 256 + wave * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gw),
-                                         (__attribute__((address_space(3))) void*)(S + OP + wave * 64), 16, 0, 0);
-        if (TERMS == 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gw),
-                                             (__attribute__((address_space(3))) void*)(S + OP + 256 + wave * 64), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < KG; ++p) {                                    // piece = octet (p*4 + wave) of this step
+            const size_t gx = ((size_t)blockIdx.x * xKO + a.xoct0 + ko + p * 4 + wave) * 64 + lane;
+            const size_t gw = ((size_t)blockIdx.y * KO + ko + p * 4 + wave) * 64 + lane;
+            const int d = (p * 4 + wave) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx),
+                                             (__attribute__((address_space(3))) void*)(S + d), 16, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xlo + gx),
+                                                 (__attribute__((address_space(3))) void*)(S + KG * 256 + d), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gw),
+                                             (__attribute__((address_space(3))) void*)(S + OP + d), 16, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gw),
+                                                 (__attribute__((address_space(3))) void*)(S + OP + KG * 256 + d), 16, 0, 0);
+        }
     };
     auto wait_groups = [&](int n) {                 // all but the youngest n step groups of this wave have landed
-        if (n >= 2) { if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else if (n == 1) { if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (n >= 2) wait_vmcnt_imm<2 * G>();
+        else if (n == 1) wait_vmcnt_imm<G>();
+        else wait_vmcnt_imm<0>();
     };
-    struct Frags { bf8 xh[2], xl[2], wh[2], wl[2]; };
+    struct Frags { bf8 xh[KG][2], xl[KG][2], wh[KG][2], wl[KG][2]; };
     auto read_frags = [&](Frags& f, int slot) {
-        const bf8* S = lds + slot * SLOT + kq * 64 + li;
+        const bf8* S = lds + slot * SLOT + li;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f.xh[t] = S[wm + t * 16];
-            if (TERMS == 3) f.xl[t] = S[256 + wm + t * 16];
-        }
+        for (int g = 0; g < KG; ++g) {
+            const int o = (g * 4 + kq) * 64;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            f.wh[n] = S[OP + wn + n * 16];
-            if (TERMS == 3) f.wl[n] = S[OP + 256 + wn + n * 16];
+            for (int t = 0; t < 2; ++t) {
+                f.xh[g][t] = S[o + wm + t * 16];
+                if (TERMS == 3) f.xl[g][t] = S[KG * 256 + o + wm + t * 16];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f.wh[g][n] = S[OP + o + wn + n * 16];
+                if (TERMS == 3) f.wl[g][n] = S[OP + KG * 256 + o + wn + n * 16];
+            }
         }
     };
     f4 acc[2][2];
@@ -467,18 +488,20 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
     auto mfma_step = [&](const Frags& f) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                if (TERMS == 3) {
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[n], f.xh[t], acc[t][n], 0, 0, 0);
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[t][n], 0, 0, 0);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (TERMS == 3) {
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[g][n], f.xh[g][t], acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[g][n], f.xl[g][t], acc[t][n], 0, 0, 0);
+                    }
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[g][n], f.xh[g][t], acc[t][n], 0, 0, 0);
                 }
-                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
-            }
     };
 
-    // prologue: groups 0..2 in flight; group 0 (and 1) landed before the loop
+    // prologue: groups 0..RING-2 in flight; groups 0 and 1 landed before the loop
     const int pre = min(nsteps, RING - 1);
     for (int s = 0; s < pre; ++s) issue(s, s);
     wait_groups(max(0, pre - 2));
@@ -487,12 +510,12 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
     read_frags(fa, 0);
     // steps are processed in pairs so that the two fragment sets have static names
     auto step = [&](int s, Frags& cur, Frags& nxt) {
-        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) & (RING - 1));
-        if (s + 1 < nsteps) read_frags(nxt, (s + 1) & (RING - 1));
+        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) % RING);
+        if (s + 1 < nsteps) read_frags(nxt, (s + 1) % RING);
         mfma_step(cur);
-        // at the next step's start, group s+2 must be landed (its fragments are read then); s+3 may stay in flight
+        // at the next step's start, group s+2 must be landed (its fragments are read then); younger ones may stay in flight
         const int newest = min(s + RING - 1, nsteps - 1);
-        wait_groups(max(0, min(1, newest - (s + 2))));
+        wait_groups(max(0, min(RING - 3, newest - (s + 2))));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
@@ -502,6 +525,23 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         if (s + 1 < nsteps) step(s + 1, fb, fa);
     }
     gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+}
+
+template <int TERMS, int BK, int RING>
+int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, dim3 grid, hipStream_t st) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr size_t LDS_BYTES = (size_t)RING * 2 * NIMG * (BK / 32) * 4 * 64 * 16;
+    auto kern = gemm_presplit_kernel<TERMS, BK, RING>;
+    static bool attr_done = false;
+    if (!attr_done && LDS_BYTES > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
+            eg_set_error("gemm_presplit: cannot reserve %zu B of LDS", LDS_BYTES);
+            return EG_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, xhi, xlo, xko);
+    return eg_check_launch("gemm_presplit");
 }
 
 // fp32 [M, K] (row stride lda) -> bf16 (hi, lo) tile-planar images [ceil(M/64)][Kpad/8][64][8]; rows >= M and k >= K are zero.
@@ -595,10 +635,12 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
-        dim3 grid(mt, eg_cdiv(p.n, 64), 1), block(256);
-        if (p.precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_presplit_kernel<3>), grid, block, 0, st, a, xhi, xlo, xko);
-        else hipLaunchKernelGGL((gemm_presplit_kernel<1>), grid, block, 0, st, a, xhi, xlo, xko);
-        return eg_check_launch("gemm_presplit");
+        dim3 grid(mt, eg_cdiv(p.n, 64), 1);
+        // 32-deep steps, 4 slots, two workgroups per CU.  The 64-deep variant (EG_GEMM_BK64=1, small grids only) measured 16 % slower in round 1.
+        const bool deep = (p.k % 64 == 0) && ((long)grid.x * grid.y <= 2 * 256) && getenv("EG_GEMM_BK64");
+        if (p.precision == EG_PREC_BF16X3)
+            return deep ? launch_presplit<3, 64, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st);
+        return deep ? launch_presplit<1, 64, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
     return launch_gemm(a, 1, p.precision, st);
@@ -665,9 +707,10 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
     const int xko = (int)eg_round_up(k_x, 64) / 8, mt = eg_cdiv(m, 64);
     const bf8* xhi = reinterpret_cast<const bf8*>(x_images);
     const bf8* xlo = xhi + (size_t)mt * xko * 64;
-    dim3 grid(mt, eg_cdiv(n, 64), 1), block(256);
-    EgProfScope prof(2, 2.0 * m * (double)n * k, (hipStream_t)stream);
-    if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_presplit_kernel<3>), grid, block, 0, (hipStream_t)stream, a, xhi, xlo, xko);
-    else hipLaunchKernelGGL((gemm_presplit_kernel<1>), grid, block, 0, (hipStream_t)stream, a, xhi, xlo, xko);
-    return eg_check_launch("gemm_presplit");
+    dim3 grid(mt, eg_cdiv(n, 64), 1);
+    EgProfScope prof(3, 2.0 * m * (double)n * k, (hipStream_t)stream);
+    const bool deep = (k % 64 == 0) && ((long)grid.x * grid.y <= 2 * 256) && getenv("EG_GEMM_BK64");
+    if (precision == EG_PREC_BF16X3)
+        return deep ? launch_presplit<3, 64, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream) : launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+    return deep ? launch_presplit<1, 64, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
 }
