@@ -78,6 +78,20 @@ __device__ __forceinline__ void split_octet(const f4& v0, const f4& v1, bf8& hi,
 }
 
 // ---- optional launch profiler (generator.hip) ----------------------------------------------------------------
+// s_waitcnt as real instructions (builtins, not inline asm) so that the compiler's own wait insertion accounts for them
+template <int N> __device__ __forceinline__ void wait_vmcnt_imm() {
+    // s_waitcnt vmcnt(N) with expcnt / lgkmcnt left at their maxima (gfx9 encoding: vmcnt[3:0] | expcnt<<4 | lgkmcnt<<8 | vmcnt[5:4]<<14)
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xF00 | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+// raw workgroup barrier (no implied vmcnt/lgkmcnt drain).  The s_barrier builtin is "no memory" at IR level, so the empty asm
+// statements keep the optimiser from moving LDS reads / LDS-DMA issues across it.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 struct EgProfScope {
     int slot;
     hipStream_t st;

@@ -16,6 +16,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef EG_CONV_MIDSYNC_ALL
+#define EG_CONV_MIDSYNC_ALL 1
+#endif
 #ifndef EG_CONV_SETPRIO
 #define EG_CONV_SETPRIO 0      // measured: pinning the MFMA cluster with s_setprio costs 20-50 % here (hipcc stops interleaving the LDS reads)
 #endif
@@ -186,17 +189,6 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 //    (pixel tile, channel tile) pair:  acc += Whi*Xhi + Whi*Xlo + Wlo*Xhi   (3 x v_mfma_f32_16x16x32_bf16).
 // Without the LDS weight ring every wave re-read all weights from L1/L2 (170 B/clk/CU demanded at C=128 vs 64 B/clk
 // of L1): the r01a profile's 115 us per 128->128 launch.
-__device__ __forceinline__ void wait_vmcnt(int n) {      // counted wait: all but the n youngest VMEM ops of this wave are done
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
 
 template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS, int RING>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
@@ -248,19 +240,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     // one step's weights = NIMG runs of WIMG slots; 64-slot (1 KiB) pieces are dealt round-robin to the 4 waves
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     constexpr int PIECES = WIMG / 64;
+    // (image, piece) pairs are dealt round-robin to the 4 waves as one flat list, so that every wave issues the same number
+    // of copies per step whenever NIMG * PIECES is a multiple of 4 (then the per-step wait can be a counted vmcnt)
+    constexpr int GTOT = NIMG * PIECES;
+    constexpr bool COUNTED = (GTOT % 4 == 0);
+    constexpr int GW = GTOT / 4;
+    constexpr bool MIDSYNC = EG_CONV_MIDSYNC_ALL || !(MT * NT >= 16);      // see the schedule comment below
     auto issue_weights = [&](int step, int buf) {
         const int chunk = step / 9, tap = step - chunk * 9;
         const size_t gbase = ((size_t)tap * (CIN / 8) + chunk * 4) * COUTP;
+        if constexpr (PIECES % 4 == 0) {        // every wave copies PIECES / 4 pieces of each image (image known at compile time)
 #pragma unroll
-        for (int img = 0; img < NIMG; ++img) {
-            const bf8* src = (img ? wlo : whi) + gbase;
+            for (int img = 0; img < NIMG; ++img) {
+                const bf8* src = (img ? wlo : whi) + gbase;
 #pragma unroll
-            for (int p = 0; p < (PIECES + 3) / 4; ++p) {
-                const int piece = p * 4 + wave_u;
-                if (PIECES % 4 == 0 || piece < PIECES)
+                for (int p = 0; p < PIECES / 4; ++p) {
+                    const int piece = p * 4 + wave_u;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
                                                      (__attribute__((address_space(3))) void*)(wring + buf * WBUF + img * WIMG + piece * 64),
                                                      16, 0, 0);
+                }
+            }
+        } else {                                // few pieces: deal the flat (image, piece) list
+#pragma unroll
+            for (int p = 0; p < (GTOT + 3) / 4; ++p) {
+                const int flat = p * 4 + wave_u;
+                if (COUNTED || flat < GTOT) {
+                    const int img = flat / PIECES, piece = flat - img * PIECES;
+                    const bf8* src = (img ? wlo : whi) + gbase;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                                     (__attribute__((address_space(3))) void*)(wring + buf * WBUF + img * WIMG + piece * 64),
+                                                     16, 0, 0);
+                }
             }
         }
     };
@@ -311,26 +322,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     //            ... the MFMAs of step s  ->  vmcnt(0) + barrier (copies of s+1, s+2 landed; slot of s is free)
     // so neither the LDS fragment reads nor the global->LDS weight copies sit on the MFMA critical path.
     struct Frags { bf8 wh[NT], wl[NT], xh[MT], xl[MT]; };
-    auto read_frags = [&](Frags& f, int tap) {
-        const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
+    auto read_w = [&](Frags& f, int tap) {
         const bf8* Wh = wring + (tap % 3) * WBUF + kq * COUTP + wn * NT * 16 + li;      // step % 3 == tap % 3 (9 taps per chunk)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f.wh[n] = Wh[n * 16];
             if (TERMS == 3) f.wl[n] = Wh[WIMG + n * 16];
         }
+    };
+    auto read_x = [&](Frags& f, int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             f.xh[t] = tile[kq * PL + pbase[t] + toff];
             if (TERMS == 3) f.xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
         }
     };
-    auto mfma_step = [&](const Frags& f) {
-#if EG_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+    static_assert(MT % 2 == 0, "a step's MFMAs are issued as two halves (pixel tiles)");
+    auto mfma_half = [&](const Frags& f, int half) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int t = half * (MT / 2); t < (half + 1) * (MT / 2); ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if (TERMS == 3) {
@@ -339,32 +350,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
                 }
                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
             }
-#if EG_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
     static_assert(RING == 3, "schedule below assumes a 3-slot ring");
+    // Schedule of step s (one tap of one 32-channel chunk), one barrier per step, placed between the two MFMA halves:
+    //   issue copy W(s+2) -> slot (s+2)%3        (its previous content, W(s-1), was last read before the barrier of step s-1)
+    //   read the pixel fragments of step s+1     (hidden under ...)
+    //   MFMAs of step s, first half
+    //   wait: W(s+1) landed [counted vmcnt: W(s+2) stays in flight], LDS reads so far complete; barrier
+    //   read the weight fragments of step s+1    (hidden under ...)
+    //   MFMAs of step s, second half
+    // so a weight copy has 1.5 steps of MFMAs to hide under and the fragment reads half a step.
+    auto mid_sync = [&](bool copy_in_flight) {
+        if constexpr (COUNTED) {
+            __builtin_amdgcn_sched_barrier(0);  // keep the first-half MFMAs in front of the wait (the scheduler would sink them)
+            if (copy_in_flight) wait_vmcnt_imm<GW>(); else wait_vmcnt_imm<0>();
+            wait_lgkmcnt0();
+            wg_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
     issue_weights(0, 0);
     if (NSTEP > 1) issue_weights(1, 1);
     load_tile(0);
     Frags fr[2];
 #pragma unroll 1
     for (int chunk = 0; chunk < CIN / 32; ++chunk) {
-        store_tile();
-        __syncthreads();                        // tile visible; every weight copy issued so far has landed
+        store_tile();                           // the tile is free: its last reads completed before the barrier of the previous tap 8
+        if (MIDSYNC && COUNTED && chunk > 0) {  // W of this chunk's tap 0 landed at that barrier too; only W of tap 1 is in flight
+            wait_vmcnt_imm<GW>();
+            wait_lgkmcnt0();                    // tile writes visible
+            wg_barrier();
+        } else {
+            __syncthreads();                    // tile visible; every weight copy issued so far has landed
+        }
         if (chunk + 1 < CIN / 32) load_tile(chunk + 1);
-        read_frags(fr[0], 0);
+        read_w(fr[0], 0);
+        read_x(fr[0], 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int step = chunk * 9 + tap;
             if (step + 2 < NSTEP) issue_weights(step + 2, (tap + 2) % 3);
-            if (tap < 8) read_frags(fr[(tap + 1) & 1], tap + 1);
-            mfma_step(fr[tap & 1]);
-            __syncthreads();                    // vmcnt(0): copies of steps s+1, s+2 landed; slot s and (after tap 8) the tile are free
+            if constexpr (MIDSYNC) {
+                mfma_half(fr[tap & 1], 0);
+                mid_sync(step + 2 < NSTEP);
+                if (tap < 8) { read_w(fr[(tap + 1) & 1], tap + 1); read_x(fr[(tap + 1) & 1], tap + 1); }
+                mfma_half(fr[tap & 1], 1);
+            } else {
+                // register-heavy tilings (64 x 64 per wave): fragments of step s+1 are read during the whole of step s and the
+                // barrier (with a full vmcnt drain) sits at the end of the step; the mid-step variant spills there
+                if (tap < 8) { read_w(fr[(tap + 1) & 1], tap + 1); read_x(fr[(tap + 1) & 1], tap + 1); }
+                mfma_half(fr[tap & 1], 0);
+                mfma_half(fr[tap & 1], 1);
+                __syncthreads();
+            }
         }
     }
-
-
 
     // epilogue: v = acc + bias; relu; v*scale + shift.  Pixel offsets are 32-bit and computed once per pixel tile; the
     // per-image base is a scalar.  NHWC: one 16-byte store per (pixel tile, channel tile); NCHW (final_conv1 only): 4 stores.
@@ -405,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
             }
         }
     }
-    if (a.gap) {            // the last step's barrier already passed: the LDS is free for the reduction
+    if (a.gap) {            // no LDS reads follow the last step's barrier: the LDS is free for the reduction
         float* sred = reinterpret_cast<float*>(lds);        // [WM][COUTP]
 #pragma unroll
         for (int n = 0; n < NT; ++n) {

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     const int pre = min(nsteps, RING - 1);
     for (int s = 0; s < pre; ++s) issue(s, s);
     wait_groups(pre - 1);
-    __builtin_amdgcn_s_barrier();
+    wg_barrier();
     const int fsw = (li ^ (li >> 1)) & 7;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
         // next step's group must have landed; groups beyond it stay in flight across the barrier
         const int newest = min(s + RING - 1, nsteps - 1);
         wait_groups(max(0, newest - (s + 1)));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's LDS reads are done before the slot is reused
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this step's LDS reads are done before the slot is reused
+        wg_barrier();
     }
     gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
 }
@@ -412,14 +412,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 // the N/64 workgroups that consume it.  The K loop then has no VALU work at all: LDS-DMA copies of both operands 3 steps
 // ahead, fragments of step s+1 read from LDS while the MFMAs of step s run (register double buffer), one counted vmcnt and
 // one raw barrier per 32-deep step.
-template <int N> __device__ __forceinline__ void wait_vmcnt_imm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else static_assert(N == 0, "unsupported vmcnt immediate");
-}
 
 // BK = K elements per barrier interval (32 or 64), RING = LDS slots.  BK 64 halves the barriers / waits per MFMA for the
 // small-grid products (one workgroup per CU anyway); BK 32 x 4 slots keeps two workgroups per CU for the large grids.
@@ -505,9 +497,10 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
     const int pre = min(nsteps, RING - 1);
     for (int s = 0; s < pre; ++s) issue(s, s);
     wait_groups(max(0, pre - 2));
-    __builtin_amdgcn_s_barrier();
+    wg_barrier();
     Frags fa, fb;
     read_frags(fa, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // nothing pending at loop entry, else the compiler waits (lgkmcnt 0) in front of the first MFMAs of every pair
     // steps are processed in pairs so that the two fragment sets have static names
     auto step = [&](int s, Frags& cur, Frags& nxt) {
         if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) % RING);
@@ -516,8 +509,8 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         // at the next step's start, group s+2 must be landed (its fragments are read then); younger ones may stay in flight
         const int newest = min(s + RING - 1, nsteps - 1);
         wait_groups(max(0, min(RING - 3, newest - (s + 2))));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) as a real instruction, so the compiler's own wait insertion sees it
+        wg_barrier();
     };
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += 2) {
