@@ -84,7 +84,7 @@ SIGNATURES = {
     "eg_linear_splitk": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "eg_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_attention": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "eg_mha_workspace_bytes": (_L, [_I, _I, _I, _I]),
+    "eg_mha_workspace_bytes": (_L, [_I, _I, _I, _I, _I]),
     "eg_multi_head_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_ffn_workspace_bytes": (_L, [_I, _I, _I]),
     "eg_positionwise_ffn": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
@@ -95,6 +95,8 @@ SIGNATURES = {
     "eg_profile_disable": (C.c_int, []),
     "eg_profile_read": (_I, [_P, _P, _P, _I]),
     "eg_reparameterize": (C.c_int, [_P, _P, _P, _P, _L, _P]),
+    "eg_contrastive_workspace_bytes": (C.c_int64, [_I]),
+    "eg_contrastive_loss": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _L, _P]),
 }
 
 _lib = None

@@ -14,8 +14,9 @@
 
 static inline float* WP(void* ws, int64_t floats) { return reinterpret_cast<float*>(ws) + floats; }
 
-extern "C" int64_t eg_mha_workspace_bytes(int32_t batch, int32_t lq, int32_t lk, int32_t d_model) {
-    return (int64_t)sizeof(float) * ((int64_t)batch * lq * d_model * 3 + (int64_t)batch * lk * d_model * 2) + 1024;
+extern "C" int64_t eg_mha_workspace_bytes(int32_t batch, int32_t lq, int32_t lk, int32_t d_model, int32_t heads) {
+    const int64_t inner = (int64_t)heads * 64;
+    return (int64_t)sizeof(float) * ((int64_t)batch * lq * (2 * inner + d_model) + (int64_t)batch * lk * inner * 2) + 1024;
 }
 
 extern "C" int eg_multi_head_attention(const float* xq, const float* xkv, const float* wq, const float* wk, const float* wv,
@@ -23,19 +24,20 @@ extern "C" int eg_multi_head_attention(const float* xq, const float* xkv, const 
                                        int32_t batch, int32_t lq, int32_t lk, int32_t d_model, int32_t heads,
                                        int32_t precision, void* workspace, int64_t workspace_bytes, void* stream) {
     EG_REQUIRE(xq && xkv && wq && wk && wv && wo && ln_g && ln_b && out && workspace, EG_ERR_BAD_ARG, "eg_multi_head_attention: null pointer");
-    EG_REQUIRE(heads > 0 && d_model == heads * 64, EG_ERR_UNSUPPORTED, "eg_multi_head_attention: d_model=%d heads=%d (d_k must be 64)", d_model, heads);
-    EG_REQUIRE(workspace_bytes >= eg_mha_workspace_bytes(batch, lq, lk, d_model), EG_ERR_WORKSPACE, "eg_multi_head_attention: workspace too small");
-    const int D = d_model, rq = batch * lq, rk = batch * lk;
+    EG_REQUIRE(heads > 0 && d_model > 0 && d_model % 4 == 0, EG_ERR_UNSUPPORTED, "eg_multi_head_attention: d_model=%d heads=%d", d_model, heads);
+    EG_REQUIRE(workspace_bytes >= eg_mha_workspace_bytes(batch, lq, lk, d_model, heads), EG_ERR_WORKSPACE, "eg_multi_head_attention: workspace too small");
+    const int D = d_model, I = heads * 64, rq = batch * lq, rk = batch * lk;    // d_k = d_v = 64 (the attention kernel's head width)
+    const int dpad = (int)eg_round_up(D, 64), ipad = (int)eg_round_up(I, 64);   // K padding of the packed weights
     float* q = WP(workspace, 0);
-    float* ao = q + (int64_t)rq * D;
-    float* pr = ao + (int64_t)rq * D;
+    float* ao = q + (int64_t)rq * I;
+    float* pr = ao + (int64_t)rq * I;
     float* k = pr + (int64_t)rq * D;
-    float* v = k + (int64_t)rk * D;
-    EG_TRY(eg_linear(xq, D, wq, D, nullptr, nullptr, nullptr, 0, q, D, rq, D, D, 0, 0, 0, precision, stream));
-    EG_TRY(eg_linear(xkv, D, wk, D, nullptr, nullptr, nullptr, 0, k, D, rk, D, D, 0, 0, 0, precision, stream));
-    EG_TRY(eg_linear(xkv, D, wv, D, nullptr, nullptr, nullptr, 0, v, D, rk, D, D, 0, 0, 0, precision, stream));
-    EG_TRY(eg_attention(q, D, k, D, v, D, ao, D, attn, batch, heads, lq, lk, 64, stream));
-    EG_TRY(eg_linear(ao, D, wo, D, nullptr, xq, nullptr, D, pr, D, rq, D, D, 0, 0, 0, precision, stream));
+    float* v = k + (int64_t)rk * I;
+    EG_TRY(eg_linear(xq, D, wq, dpad, nullptr, nullptr, nullptr, 0, q, I, rq, I, D, 0, 0, 0, precision, stream));
+    EG_TRY(eg_linear(xkv, D, wk, dpad, nullptr, nullptr, nullptr, 0, k, I, rk, I, D, 0, 0, 0, precision, stream));
+    EG_TRY(eg_linear(xkv, D, wv, dpad, nullptr, nullptr, nullptr, 0, v, I, rk, I, D, 0, 0, 0, precision, stream));
+    EG_TRY(eg_attention(q, I, k, I, v, I, ao, I, attn, batch, heads, lq, lk, 64, stream));
+    EG_TRY(eg_linear(ao, I, wo, ipad, nullptr, xq, nullptr, D, pr, D, rq, D, I, 0, 0, 0, precision, stream));
     return eg_layernorm(pr, ln_g, ln_b, out, rq, D, 1e-6f, stream);
 }
 

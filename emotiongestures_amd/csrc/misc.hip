@@ -633,3 +633,108 @@ int egi_small_linear(const float* x, int ldx, const float* w, const float* bias,
                        ldy, in, out);
     return eg_check_launch("small_linear");
 }
+
+
+// ---- SoftmaxContrastiveLoss (test_emotion_gesture_diversity_iterative.py:80-127) -------------------------------------------
+namespace {
+// one workgroup per face row i: cross[i][:] (each thread owns columns j = tid, tid+256, ...), then the row's logsumexp / argmax
+__global__ __launch_bounds__(256) void contrastive_rows_kernel(const float* __restrict__ face, const float* __restrict__ audio, int n, int d,
+                                                               float* __restrict__ cross, float* __restrict__ row_loss,
+                                                               int* __restrict__ row_hit) {
+    extern __shared__ float sh[];                 // d normalised face values, then 256 x (max, argmax) / sums
+    float* f = sh;
+    float* red = sh + d;
+    int* redi = reinterpret_cast<int*>(red + 256);
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float part = 0.f;
+    for (int k = tid; k < d; k += 256) { const float v = face[(size_t)i * d + k]; f[k] = v; part += v * v; }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float finv = 1.f / fmaxf(sqrtf(red[0]), 1e-12f);
+    __syncthreads();
+    float vmax = -INFINITY, diag = 0.f;
+    int amax = 0x7fffffff;
+    float* crow = cross ? cross + (size_t)i * n : nullptr;
+    // pass 1: values, row maximum and its first index
+    for (int j = tid; j < n; j += 256) {
+        const float* a = audio + (size_t)j * d;
+        float na = 0.f;
+        for (int k = 0; k < d; ++k) na += a[k] * a[k];
+        const float ainv = 1.f / fmaxf(sqrtf(na), 1e-12f);
+        float dist = 0.f;
+        for (int k = 0; k < d; ++k) { const float t = f[k] * finv - a[k] * ainv; dist += t * t; }
+        const float c = fmaxf(1.f / (sqrtf(dist) + 1e-8f), 1e-8f);
+        if (crow) crow[j] = c;
+        if (j == i) diag = c;
+        if (c > vmax) { vmax = c; amax = j; }
+    }
+    red[tid] = vmax; redi[tid] = amax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float o = red[tid + s]; const int oi = redi[tid + s];
+            if (o > red[tid] || (o == red[tid] && oi < redi[tid])) { red[tid] = o; redi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    const float m = red[0];
+    const int am = redi[0];
+    __syncthreads();
+    // pass 2: sum exp(c - m); recompute c (cross may be absent) exactly as above
+    float se = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float* a = audio + (size_t)j * d;
+        float na = 0.f;
+        for (int k = 0; k < d; ++k) na += a[k] * a[k];
+        const float ainv = 1.f / fmaxf(sqrtf(na), 1e-12f);
+        float dist = 0.f;
+        for (int k = 0; k < d; ++k) { const float t = f[k] * finv - a[k] * ainv; dist += t * t; }
+        const float c = fmaxf(1.f / (sqrtf(dist) + 1e-8f), 1e-8f);
+        se += expf(c - m);
+    }
+    red[tid] = se;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    // the diagonal value lives in exactly one thread
+    __shared__ float sdiag;
+    if (i % 256 == tid) sdiag = diag;
+    __syncthreads();
+    if (tid == 0) {
+        row_loss[i] = m + logf(red[0]) - sdiag;
+        row_hit[i] = (am == i) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void contrastive_mean_kernel(const float* __restrict__ row_loss, const int* __restrict__ row_hit, int n,
+                                                               float* __restrict__ loss, float* __restrict__ acc) {
+    __shared__ float rl[256];
+    __shared__ int rh[256];
+    const int tid = threadIdx.x;
+    float l = 0.f; int h = 0;
+    for (int i = tid; i < n; i += 256) { l += row_loss[i]; h += row_hit[i]; }
+    rl[tid] = l; rh[tid] = h;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) { rl[tid] += rl[tid + s]; rh[tid] += rh[tid + s]; } __syncthreads(); }
+    if (tid == 0) { *loss = rl[0] / (float)n; *acc = (float)rh[0] / (float)n; }
+}
+}  // namespace
+
+extern "C" int64_t eg_contrastive_workspace_bytes(int32_t n) { return n > 0 ? (int64_t)n * 8 : 0; }
+
+extern "C" int eg_contrastive_loss(const float* face, const float* audio, int32_t n, int32_t d, float* cross, float* loss, float* acc,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    EG_REQUIRE(face && audio && loss && acc && workspace, EG_ERR_BAD_ARG, "eg_contrastive_loss: null pointer");
+    EG_REQUIRE(n >= 1 && n <= 4096 && d >= 1 && d <= 8192, EG_ERR_BAD_ARG, "eg_contrastive_loss: n=%d d=%d out of range", n, d);
+    EG_REQUIRE(workspace_bytes >= eg_contrastive_workspace_bytes(n), EG_ERR_WORKSPACE, "eg_contrastive_loss: workspace %lld < %lld",
+               (long long)workspace_bytes, (long long)eg_contrastive_workspace_bytes(n));
+    float* row_loss = static_cast<float*>(workspace);
+    int* row_hit = reinterpret_cast<int*>(row_loss + n);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(d + 512) * sizeof(float);
+    hipLaunchKernelGGL(contrastive_rows_kernel, dim3(n), dim3(256), lds, st, face, audio, n, d, cross, row_loss, row_hit);
+    int rc = eg_check_launch("contrastive_rows");
+    if (rc != EG_OK) return rc;
+    hipLaunchKernelGGL(contrastive_mean_kernel, dim3(1), dim3(256), 0, st, row_loss, row_hit, n, loss, acc);
+    return eg_check_launch("contrastive_mean");
+}

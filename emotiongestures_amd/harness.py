@@ -121,6 +121,112 @@ class SkeletonTransformer(nn.Module):
         return logits, mid
 
 
+# ---- training-side types on the path, forward only ---------------------------------------------------
+class Motion_Discriminator(nn.Module):
+    """Full_model/Models_spatial_memory.py:620-669 (identical class in Models_memory.py): encoder over the motion offsets,
+    per-frame Linear+ReLU, 6-layer ReLU MLP -> [B, 1] logit (no sigmoid).  Its forward needs pose_dim == d_word_vec == d_model
+    (the encoder adds a d_word_vec-wide table to the raw offsets and fc1 consumes the d_model-wide encoder output as if it were
+    pose_dim wide), which the upstream defaults (128 vs 282) violate; the constructor refuses such a combination up front.
+    Forward only: backward kernels are not built."""
+
+    def __init__(self, frames=59, pose_dim=282, src_pad_idx=1, trg_pad_idx=1, d_word_vec=128, d_model=128, d_inner=1024, n_layers=2,
+                 n_head=8, d_k=64, d_v=64, dropout=0.2, n_position=59, *, precision="f32"):
+        super().__init__()
+        if not (pose_dim == d_word_vec == d_model):
+            raise ValueError(f"Motion_Discriminator: forward needs pose_dim == d_word_vec == d_model (got {pose_dim}, {d_word_vec}, "
+                             f"{d_model}); the upstream defaults fail at the first tensor add")
+        self.d_model, self.frames = d_model, frames
+        self.encoder = Encoder(n_position=n_position, d_word_vec=d_word_vec, d_model=d_model, d_inner=d_inner, n_layers=n_layers,
+                               n_head=n_head, d_k=d_k, d_v=d_v, pad_idx=src_pad_idx, dropout=dropout)
+        self.fc1 = _seq(Linear(pose_dim, 64), None)
+        self.fc2 = _seq(Linear(frames * 64, 2048), None, Linear(2048, 1024), None, Linear(1024, 256), None, Linear(256, 64), None,
+                        Linear(64, 16), None, Linear(16, 1))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.precision = precision
+        self._cache = _PackCache()
+
+    def forward(self, x):
+        _eval_only(self)
+        B, T, D = x.shape
+        if T != self.frames or D != self.d_model:
+            raise ValueError(f"Motion_Discriminator.forward: expected [B, {self.frames}, {self.d_model}], got {tuple(x.shape)}")
+        for layer in self.encoder.layer_stack:
+            layer.slf_attn.precision = layer.pos_ffn.precision = self.precision
+        enc, *_ = self.encoder(x.contiguous(), None)
+        h = ops.linear(enc.reshape(B * T, D).contiguous(), self.fc1[0].weight, self.fc1[0].bias, relu=True, precision=self.precision,
+                       packed=self._cache.get(self.fc1[0], x.device))
+        head = [self.fc2[i] for i in (0, 2, 4, 6, 8, 10)]
+        return _affine_chain(self._cache, h.reshape(B, -1).contiguous(), head, True, self.precision)
+
+
+class SoftmaxContrastiveLoss(nn.Module):
+    """test_emotion_gesture_diversity_iterative.py:80-127 on the GPU (eg_contrastive_loss: one workgroup per row, fixed-order
+    reductions).  forward -> scalar loss tensor; evaluate -> (accuracy, cross_dist [n, n]).  Forward values only (no autograd)."""
+
+    def _run(self, face_feat, audio_feat, want_cross):
+        if face_feat.dim() != 2 or face_feat.shape != audio_feat.shape:
+            raise ValueError(f"SoftmaxContrastiveLoss: expected two [n, d] tensors, got {tuple(face_feat.shape)} and {tuple(audio_feat.shape)}")
+        if not face_feat.is_cuda or not audio_feat.is_cuda:
+            raise RuntimeError("SoftmaxContrastiveLoss runs on the GPU only (no CPU fallback)")
+        lib = L.load()
+        f, a = face_feat.detach().float().contiguous(), audio_feat.detach().float().contiguous()
+        n, d = f.shape
+        dev = f.device
+        cross = torch.empty(n, n, device=dev) if want_cross else None
+        res = torch.empty(2, device=dev)
+        nbytes = int(lib.eg_contrastive_workspace_bytes(n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        L.check(lib.eg_contrastive_loss(p(f), p(a), n, d, p(cross), res[0:1].data_ptr(), res[1:2].data_ptr(), p(ws), nbytes,
+                                        torch.cuda.current_stream(dev).cuda_stream), "eg_contrastive_loss")
+        return res[0], res[1], cross
+
+    @torch.no_grad()
+    def evaluate(self, face_feat, audio_feat, mode="max"):
+        if mode != "max":
+            raise ValueError(mode)
+        _loss, acc, cross = self._run(face_feat, audio_feat, True)
+        return acc, cross
+
+    def forward(self, face_feat, audio_feat, contrastive_device, mode="max"):
+        if mode != "max":
+            raise ValueError(mode)
+        dev = torch.device(contrastive_device)
+        return self._run(face_feat.to(dev), audio_feat.to(dev), False)[0]
+
+
+def adjust_lr(optimizer, init_lr, epoch, decay_rate=0.1, decay_epoch=4):
+    """test_emotion_gesture_diversity_iterative.py:64-78: piecewise-constant learning rate written into every param group
+    (`decay_rate` / `decay_epoch` are accepted and ignored, as upstream).  Past epoch 150 upstream dies on an unbound local;
+    here that is a ValueError."""
+    if epoch <= 15:
+        lr = init_lr
+    elif epoch <= 50:
+        lr = init_lr * 0.2
+    elif epoch <= 80:
+        lr = init_lr * 0.01
+    elif epoch <= 100:
+        lr = init_lr * 0.005
+    elif epoch <= 150:
+        lr = init_lr * 0.001
+    else:
+        raise ValueError(f"adjust_lr: the schedule is defined for epochs 0..150 (got {epoch})")
+    for param_group in optimizer.param_groups:
+        param_group["lr"] = lr
+
+
+def set_requires_grad(nets, requires_grad=False):
+    """test_emotion_gesture_diversity_iterative.py:51-62"""
+    if not isinstance(nets, list):
+        nets = [nets]
+    for net in nets:
+        if net is not None:
+            for param in net.parameters():
+                param.requires_grad = requires_grad
+
+
 # ---- metrics (host side, as upstream) ---------------------------------------------------------------------------------
 def compute_acc(input_label: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """test_emotion_gesture_diversity_iterative.py:35-39"""

@@ -166,7 +166,7 @@ def multi_head_attention(xq, xkv, wq, wk, wv, wo, ln_g, ln_b, heads: int, precis
     B, Lq, D = xq.shape
     Lk = xkv.shape[1]
     packs = [pack_linear_weight(w, dev)[0] for w in (wq, wk, wv, wo)]
-    nbytes = lib.eg_mha_workspace_bytes(B, Lq, Lk, D)
+    nbytes = lib.eg_mha_workspace_bytes(B, Lq, Lk, D, heads)
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     out = torch.empty_like(xq)
     attn = torch.empty(B, heads, Lq, Lk, device=dev) if want_attn else None

@@ -172,3 +172,18 @@ def digest(x, n: int = 2048) -> Dict[str, np.ndarray]:
     return {"sample": a[::stride][:n].copy(), "mean": np.float64(a.astype(np.float64).mean()),
             "absmean": np.float64(np.abs(a.astype(np.float64)).mean()),
             "shape": np.asarray(x.shape, dtype=np.int64)}
+
+
+def synth_clip(seed: int = 7, duration: float = 11.3, fps_in: int = 30, joints: int = 47, n_words: int = 24, start_time: float = 3.0) -> dict:
+    """One upstream-shaped clip dict (data_loader/data_preprocessor_expressive.py:70-77): skeleton [T, joints, 3] at fps_in,
+    raw 16 kHz audio, a synthetic whole-clip fp16 dB spectrogram [128, 1 + n // 512] and timed words (absolute times)."""
+    n_skel = int(duration * fps_in)
+    skel = (hash_unit("clip.skeletons", n_skel * joints * 3, seed) * 2 - 1).astype(np.float32).reshape(n_skel, joints, 3)
+    n_audio = int(duration * 16000)
+    audio = ((hash_unit("clip.audio_raw", n_audio, seed) * 2 - 1) * 0.3).astype(np.float32)
+    n_spec = 1 + n_audio // 512
+    spec = (-80.0 * hash_unit("clip.audio_feat", 128 * n_spec, seed)).astype(np.float16).reshape(128, n_spec)
+    starts = np.sort(hash_unit("clip.words", n_words, seed).astype(np.float64) * duration)
+    words = [["w%d" % i, float(start_time + s), float(start_time + min(duration, s + 0.25))] for i, s in enumerate(starts)]
+    return {"skeletons": skel, "audio_feat": spec, "audio_raw": audio, "words": words, "start_frame_no": 100,
+            "end_frame_no": 100 + n_skel, "start_time": start_time, "end_time": start_time + duration}

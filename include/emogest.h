@@ -276,9 +276,10 @@ int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const
                  int32_t dk, void* stream);
 
 /* MultiHeadAttention.forward (Full_model/SubLayers.py:30-59): LN(fc(attn(q Wq, k Wk, v Wv)) + q).
- * xq [B*Lq, D], xkv [B*Lk, D]; wq/wk/wv/wo raw nn.Linear [D,D]; out [B*Lq, D].
+ * xq [B*Lq, D], xkv [B*Lk, D]; wq/wk/wv packed nn.Linear [heads*64, D], wo packed [D, heads*64] (d_k = d_v = 64; D need not
+ * equal heads*64: Motion_Discriminator runs D = 128 with 8 heads); out [B*Lq, D].  D % 4 == 0.
  * workspace >= eg_mha_workspace_bytes. */
-int64_t eg_mha_workspace_bytes(int32_t batch, int32_t lq, int32_t lk, int32_t d_model);
+int64_t eg_mha_workspace_bytes(int32_t batch, int32_t lq, int32_t lk, int32_t d_model, int32_t heads);
 int eg_multi_head_attention(const float* xq, const float* xkv, const float* wq, const float* wk, const float* wv,
                             const float* wo, const float* ln_g, const float* ln_b, float* out, float* attn,
                             int32_t batch, int32_t lq, int32_t lk, int32_t d_model, int32_t heads,
@@ -303,6 +304,15 @@ int eg_add_rows(const float* a, const float* table, float* out, int64_t rows, in
 
 /* VAE reparameterisation (CAVE/BEAT_CVAE.py:397-399): z = eps*exp(0.5*logvar) + mu, n elements. */
 int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
+
+/* SoftmaxContrastiveLoss (test_emotion_gesture_diversity_iterative.py:80-127), forward and evaluate in one call.
+ * face, audio: [n, d] fp32.  Rows are L2-normalised (x / max(|x|, 1e-12)), cross[i][j] = max(1 / (|face_i - audio_j| + 1e-8), 1e-8),
+ * loss = mean_i( logsumexp_j cross[i][j] - cross[i][i] )  (= F.cross_entropy(cross, arange(n))),  acc = mean_i( argmax_j cross[i][j] == i ).
+ * cross ([n, n]) may be NULL; loss and acc are single floats on the device.  ws: eg_contrastive_workspace_bytes(n).
+ * Deterministic: per-row results are reduced in a fixed order (no atomics).  1 <= n <= 4096, 1 <= d. */
+int64_t eg_contrastive_workspace_bytes(int32_t n);
+int eg_contrastive_loss(const float* face, const float* audio, int32_t n, int32_t d, float* cross, float* loss, float* acc,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

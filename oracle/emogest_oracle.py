@@ -437,6 +437,57 @@ def skeleton_classifier(sd: SD, pose: torch.Tensor, cfg: Optional[GenCfg] = None
     return _lin(sd, "post_projector.8", h), enc
 
 
+# a15  training-side types, forward only
+def calc_motion(motion: torch.Tensor) -> torch.Tensor:
+    """calc_motion, test_emotion_gesture_diversity_iterative.py:41-44 (frame-to-frame offsets)."""
+    return motion[:, 1:] - motion[:, :-1]
+
+
+def motion_discriminator(sd: SD, x: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
+    """Motion_Discriminator.forward, Full_model/Models_spatial_memory.py:658-669 (same class in Models_memory.py):
+    encoder (self-attention + FFN layers) -> Linear+ReLU per frame -> flatten -> 6-layer ReLU MLP -> [B, 1] (no sigmoid)."""
+    b = x.shape[0]
+    h = encoder(sd, "encoder", x, cfg)
+    h = F.relu(_lin(sd, "fc1.0", h)).reshape(b, -1)
+    for i in (0, 2, 4, 6, 8):
+        h = F.relu(_lin(sd, f"fc2.{i}", h))
+    return _lin(sd, "fc2.10", h)
+
+
+def softmax_contrastive(face: np.ndarray, audio: np.ndarray):
+    """SoftmaxContrastiveLoss.forward / .evaluate, test_emotion_gesture_diversity_iterative.py:80-127, in float64 numpy:
+    rows L2-normalised (F.normalize eps 1e-12), cross = clamp(1 / (pairwise L2 + 1e-8), min 1e-8),
+    loss = cross_entropy(cross, arange(n)), acc = mean(argmax_j cross[i, j] == i).  Returns (loss, acc, cross)."""
+    f = np.asarray(face, np.float64)
+    a = np.asarray(audio, np.float64)
+    f = f / np.maximum(np.linalg.norm(f, axis=1, keepdims=True), 1e-12)
+    a = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+    dist = np.linalg.norm(f[:, None, :] - a[None, :, :], axis=2)
+    cross = np.maximum(1.0 / (dist + 1e-8), 1e-8)
+    m = cross.max(axis=1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(cross - m).sum(axis=1))
+    n = cross.shape[0]
+    loss = float(np.mean(lse - cross[np.arange(n), np.arange(n)]))
+    acc = float(np.mean(cross.argmax(axis=1) == np.arange(n)))
+    return loss, acc, cross
+
+
+def adjust_lr_value(init_lr: float, epoch: int) -> float:
+    """adjust_lr, test_emotion_gesture_diversity_iterative.py:64-78: piecewise-constant schedule (epochs past 150 are
+    undefined upstream: `base_lr` is unbound there)."""
+    if epoch <= 15:
+        return init_lr
+    if epoch <= 50:
+        return init_lr * 0.2
+    if epoch <= 80:
+        return init_lr * 0.01
+    if epoch <= 100:
+        return init_lr * 0.005
+    if epoch <= 150:
+        return init_lr * 0.001
+    raise ValueError("adjust_lr is undefined past epoch 150 upstream")
+
+
 def frechet_distance(mu1, sigma1, mu2, sigma2):
     """calculate_frechet_distance, model/FHD_score.py:159-217 (float64, scipy.linalg.sqrtm)."""
     from scipy import linalg
