@@ -652,14 +652,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 }
 
 // ---- SE gate: GAP finish + FC -> ReLU -> FC -> sigmoid, one workgroup per clip ---------------------
-__global__ __launch_bounds__(128) void se_gate_kernel(const float* __restrict__ gap, int tiles, const float* __restrict__ w1,
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ gap, int tiles, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, float* __restrict__ gate, int C, float inv_hw) {
-    __shared__ float m[128];
-    __shared__ float h[16];
+    __shared__ float m[256];
+    __shared__ float h[32];
     const int b = blockIdx.x, t = threadIdx.x, R = C >> 3;
-    {   // fixed-order (deterministic) two-level sum of the per-tile partials: 128/C groups x C channels
-        const int c = t % C, g = t / C, G = 128 / C;
+    {   // fixed-order (deterministic) two-level sum of the per-tile partials: blockDim/C groups x C channels
+        const int c = t % C, g = t / C, G = blockDim.x / C;
         float s = 0.f;
         for (int i = g; i < tiles; i += G) s += gap[((size_t)b * tiles + i) * C + c];
         m[t] = s;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void se_tail_downsample_kernel(const float* __
                                                                  const float* __restrict__ xin, const float* __restrict__ dsw,
                                                                  const float* __restrict__ dss, const float* __restrict__ dsh,
                                                                  float* __restrict__ out, int B, int Ho, int Wo, int Hin, int Win, int S) {
-    __shared__ f4 wl[CIN * COUT / 4];
+    extern __shared__ __attribute__((aligned(16))) f4 wl[];         // CIN * COUT / 4 (128 KB at 128 -> 256)
     for (int i = threadIdx.x; i < CIN * COUT / 4; i += 256) wl[i] = reinterpret_cast<const f4*>(dsw)[i];
     __syncthreads();
     constexpr int CQ = COUT / 4;
@@ -769,7 +769,7 @@ int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
 }
 
 int conv_tile_rows(int cin, int cout, int stride) {
-    if (stride == 2) return 2;
+    if (stride == 2 || cout >= 256) return 2;
     if (cin == 32 && cout == 32) return 4;       // 4-row tiles: smaller LDS footprint, more workgroups in flight (HBM-bound layer)
     return (cout >= 128 || cin >= 128) ? 4 : 8;
 }
@@ -822,6 +822,9 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
     if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 64 && coutp == 128 && stride == 2) return launch_conv<64, 8, 2, 2, 2, 2>(a, batch, precision, st);
     if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4, 2, 2>(a, batch, precision, st);
+    // 256-channel stage of the audio emotion classifier (model/audio_emotion_classifer.py:20-22): 2-row tiles, waves split the channels
+    if (cin == 128 && coutp == 256 && stride == 2) return launch_conv<128, 16, 2, 2, 1, 4>(a, batch, precision, st);
+    if (cin == 256 && coutp == 256 && stride == 1) return launch_conv<256, 16, 1, 2, 1, 4>(a, batch, precision, st);
     if (cin == 128 && coutp <= 64 && stride == 1) {       // final_conv1: 128 -> frames (34 -> 48, 60 -> 64)
         if (coutp <= 48) return launch_conv<128, 3, 1, 4, 4, 1>(a, batch, precision, st);
         return launch_conv<128, 4, 1, 4, 4, 1>(a, batch, precision, st);
@@ -846,8 +849,8 @@ extern "C" int eg_stem_conv(const float* x, const float* w9xc, const float* bias
 extern "C" int eg_se_gate(const float* gap_partial, int32_t tiles, const float* w1, const float* b1, const float* w2,
                           const float* b2, float* gate, int32_t batch, int32_t c, int32_t hw, void* stream) {
     EG_REQUIRE(gap_partial && w1 && b1 && w2 && b2 && gate && batch > 0, EG_ERR_BAD_ARG, "eg_se_gate: null pointer");
-    EG_REQUIRE(c % 8 == 0 && c <= 128, EG_ERR_UNSUPPORTED, "eg_se_gate: C=%d", c);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(128), 0, (hipStream_t)stream, gap_partial, tiles, w1, b1, w2, b2,
+    EG_REQUIRE(c % 8 == 0 && c <= 256 && (c <= 128 ? 128 % c : 256 % c) == 0, EG_ERR_UNSUPPORTED, "eg_se_gate: C=%d", c);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(c <= 128 ? 128 : 256), 0, (hipStream_t)stream, gap_partial, tiles, w1, b1, w2, b2,
                        gate, c, 1.0f / (float)hw);
     return eg_check_launch("se_gate");
 }
@@ -869,12 +872,24 @@ extern "C" int eg_se_residual_relu(const float* y, const float* gate, const floa
     const size_t total = (size_t)batch * ho * wo * (c / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (cin == 32 && c == 64)
-        hipLaunchKernelGGL((se_tail_downsample_kernel<32, 64>), dim3(blocks), dim3(256), 0, st, y, gate, x_in, ds_w, ds_scale,
+        hipLaunchKernelGGL((se_tail_downsample_kernel<32, 64>), dim3(blocks), dim3(256), 32 * 64 * 4, st, y, gate, x_in, ds_w, ds_scale,
                            ds_shift, out, batch, ho, wo, h_in, w_in, stride);
     else if (cin == 64 && c == 128)
-        hipLaunchKernelGGL((se_tail_downsample_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, y, gate, x_in, ds_w, ds_scale,
+        hipLaunchKernelGGL((se_tail_downsample_kernel<64, 128>), dim3(blocks), dim3(256), 64 * 128 * 4, st, y, gate, x_in, ds_w, ds_scale,
                            ds_shift, out, batch, ho, wo, h_in, w_in, stride);
-    else {
+    else if (cin == 128 && c == 256) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(se_tail_downsample_kernel<128, 256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4) != hipSuccess) {
+                eg_set_error("eg_se_residual_relu: cannot reserve 128 KiB of LDS");
+                return EG_ERR_HIP;
+            }
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((se_tail_downsample_kernel<128, 256>), dim3(blocks < 1024 ? blocks : 1024), dim3(256), 128 * 256 * 4, st, y, gate,
+                           x_in, ds_w, ds_scale, ds_shift, out, batch, ho, wo, h_in, w_in, stride);
+    } else {
         eg_set_error("eg_se_residual_relu: unsupported downsample %d->%d", cin, c);
         return EG_ERR_UNSUPPORTED;
     }

@@ -204,6 +204,8 @@ class ResNetSE(nn.Module):
         self.layer1 = self._make_layer(block, num_filters[0], layers[0])
         self.layer2 = self._make_layer(block, num_filters[1], layers[1], stride=(2, 2))
         self.layer3 = self._make_layer(block, num_filters[2], layers[2], stride=(2, 2))
+        if len(num_filters) > 3:        # model/emotion_ResNetSE34V2.py:26 (the audio emotion classifier's 256-channel stage)
+            self.layer4 = self._make_layer(block, num_filters[3], layers[3], stride=(2, 2))
         for m in self.modules():
             if isinstance(m, Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -224,7 +226,7 @@ class ResNetSE(nn.Module):
         _eval_only(self)
         s, t = self.bn1.affine()
         x = ops.stem_conv(spec, self.conv1.weight, self.conv1.bias, s, t)
-        for layer in (self.layer1, self.layer2, self.layer3):
+        for layer in (self.layer1, self.layer2, self.layer3, getattr(self, "layer4", ())):
             for blk in layer:
                 x = blk.forward_nhwc(x)
         return x

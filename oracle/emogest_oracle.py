@@ -437,6 +437,16 @@ def skeleton_classifier(sd: SD, pose: torch.Tensor, cfg: Optional[GenCfg] = None
     return _lin(sd, "post_projector.8", h), enc
 
 
+def emotion_net(sd: SD, mfcc: torch.Tensor) -> torch.Tensor:
+    """EmotionNet.forward, model/audio_emotion_classifer.py:39-49: 4-stage ResNetSE (model/emotion_ResNetSE34V2.py:57-71,
+    blocks [3,4,6,3]) on [B,128,128] -> [B,256,16,16] -> flatten (NCHW order) -> 5 x (Linear, ReLU) -> Linear(64, 8)."""
+    x = resnetse(sd, "emotion_encoder", mfcc.unsqueeze(1), layers=(3, 4, 6, 3))
+    h = x.reshape(x.shape[0], -1)
+    for i in (0, 2, 4, 6, 8):
+        h = F.relu(_lin(sd, f"emotion_eocder_fc.{i}", h))
+    return _lin(sd, "last_fc", h)
+
+
 # a15  training-side types, forward only
 def calc_motion(motion: torch.Tensor) -> torch.Tensor:
     """calc_motion, test_emotion_gesture_diversity_iterative.py:41-44 (frame-to-frame offsets)."""
