@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const float* __restrict__ x
                 float s = acc[j][r];
                 if (act) {
                     s = s > 0.f ? s : 0.2f * s;
-                    s = s * scale[co] + shift[co];
+                    if (scale) s = s * scale[co] + shift[co];
                 }
                 y[((size_t)n * Cout + co) * Lout + l] = s;
             }
@@ -621,6 +621,13 @@ int egi_conv1d(const float* x, const float* w, const float* bias, const float* s
     else
         hipLaunchKernelGGL((conv1d_kernel<16>), grid, dim3(256), smem, st, x, w, bias, scale, shift, y, cin, cout, lin, lout, k, stride, pad, act);
     return eg_check_launch("conv1d");
+}
+extern "C" int eg_conv1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int32_t n,
+                         int32_t cin, int32_t cout, int32_t lin, int32_t k, int32_t stride, int32_t pad, int32_t act, void* stream) {
+    EG_REQUIRE(x && w && bias && y && n > 0 && cin > 0 && cout > 0 && lin > 0, EG_ERR_BAD_ARG, "eg_conv1d: null pointer or empty shape");
+    EG_REQUIRE(k >= 1 && stride >= 1 && pad >= 0 && lin + 2 * pad >= k, EG_ERR_BAD_ARG, "eg_conv1d: k=%d stride=%d pad=%d lin=%d", k, stride, pad, lin);
+    EG_REQUIRE((scale == nullptr) == (shift == nullptr), EG_ERR_BAD_ARG, "eg_conv1d: scale and shift come together");
+    return egi_conv1d(x, w, bias, scale, shift, y, n, cin, cout, lin, k, stride, pad, act, (hipStream_t)stream);
 }
 int egi_convt1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int n, int cin,
                 int cout, int lin, hipStream_t st) {

@@ -242,3 +242,21 @@ def add_rows(a, table, period=0):
     out = torch.empty_like(a)
     L.check(lib.eg_add_rows(_ptr(a), _ptr(table), _ptr(out), a.numel() // d, d, period, _stream(a.device)), "eg_add_rows")
     return out
+
+
+def conv1d(x, weight, bias, stride=1, padding=0, leaky=False, scale=None, shift=None):
+    """nn.Conv1d on [n, cin, l] (contiguous) with an optional LeakyReLU(0.2) [+ per-channel affine] epilogue (eg_conv1d)."""
+    lib = L.load()
+    x = _need_cuda(x, "x").contiguous()
+    dev = x.device
+    n, cin, lin = x.shape
+    cout, _, k = weight.shape
+    lout = (lin + 2 * padding - k) // stride + 1
+    y = torch.empty(n, cout, lout, device=dev)
+    w = weight.detach().float().contiguous().to(dev)
+    b = (bias.detach().float() if bias is not None else torch.zeros(cout)).contiguous().to(dev)
+    sc = scale.detach().float().contiguous().to(dev) if scale is not None else None
+    sh = shift.detach().float().contiguous().to(dev) if shift is not None else None
+    L.check(lib.eg_conv1d(_ptr(x), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), _ptr(y), n, cin, cout, lin, k, stride, padding, int(leaky),
+                          _stream(dev)), "eg_conv1d")
+    return y

@@ -305,6 +305,13 @@ int eg_add_rows(const float* a, const float* table, float* out, int64_t rows, in
 /* VAE reparameterisation (CAVE/BEAT_CVAE.py:397-399): z = eps*exp(0.5*logvar) + mu, n elements. */
 int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
 
+/* nn.Conv1d over [n, cin, lin] -> [n, cout, lout], lout = (lin + 2*pad - k)/stride + 1, weight [cout, cin, k] (PyTorch layout):
+ * y = bias + conv(x); act != 0: LeakyReLU(0.2), then (scale != NULL) y*scale[co] + shift[co]  -- the CVAE's conv -> LeakyReLU -> BN
+ * order (CAVE/BEAT_CVAE.py:318-332); MotionAE's conv -> BN -> LeakyReLU (model/motion_ae.py:8-31) folds its BN into w / bias.
+ * The input tile and the weights of one workgroup must fit 160 KB of LDS (else EG_ERR_UNSUPPORTED). */
+int eg_conv1d(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int32_t n,
+              int32_t cin, int32_t cout, int32_t lin, int32_t k, int32_t stride, int32_t pad, int32_t act, void* stream);
+
 /* SoftmaxContrastiveLoss (test_emotion_gesture_diversity_iterative.py:80-127), forward and evaluate in one call.
  * face, audio: [n, d] fp32.  Rows are L2-normalised (x / max(|x|, 1e-12)), cross[i][j] = max(1 / (|face_i - audio_j| + 1e-8), 1e-8),
  * loss = mean_i( logsumexp_j cross[i][j] - cross[i][i] )  (= F.cross_entropy(cross, arange(n))),  acc = mean_i( argmax_j cross[i][j] == i ).

@@ -447,6 +447,31 @@ def emotion_net(sd: SD, mfcc: torch.Tensor) -> torch.Tensor:
     return _lin(sd, "last_fc", h)
 
 
+def motion_ae(sd: SD, pose: torch.Tensor):
+    """MotionAE.forward, model/motion_ae.py:125-130 -> (reconstruction [B,34,D], latent [B,latent]).  Encoder :54-61:
+    3 x (Conv1d -> BN -> LeakyReLU(0.2)) [k3, k3, k4 s2] -> Conv1d k3 -> flatten -> Linear/BN x2 -> Linear; decoder :107-116:
+    Linear/BN -> Linear -> [B,4,34] -> 2 x (ConvTranspose1d k3 -> BN -> LeakyReLU(0.2)) -> Conv1d k3 x2.
+    nn.LeakyReLU(True) in the dense stacks has slope 1.0 (identity)."""
+    def bn(p, x):
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+    x = pose.reshape(pose.shape[0], pose.shape[1], -1).transpose(1, 2)
+    for i, stride in ((0, 1), (1, 1), (2, 2)):
+        q = f"encoder.net.{i}"
+        x = F.leaky_relu(bn(q + ".1", F.conv1d(x, sd[q + ".0.weight"], sd[q + ".0.bias"], stride=stride)), 0.2)
+    x = F.conv1d(x, sd["encoder.net.3.weight"], sd["encoder.net.3.bias"]).flatten(1)
+    x = bn("encoder.out_net.1", _lin(sd, "encoder.out_net.0", x))
+    x = bn("encoder.out_net.4", _lin(sd, "encoder.out_net.3", x))
+    z = _lin(sd, "encoder.out_net.6", x)
+    h = bn("decoder.pre_net.1", _lin(sd, "decoder.pre_net.0", z))
+    h = _lin(sd, "decoder.pre_net.3", h).view(z.shape[0], 4, -1)
+    for i in (0, 3):
+        q = f"decoder.net.{i}"
+        h = F.leaky_relu(bn(f"decoder.net.{i + 1}", F.conv_transpose1d(h, sd[q + ".weight"], sd[q + ".bias"])), 0.2)
+    h = F.conv1d(h, sd["decoder.net.6.weight"], sd["decoder.net.6.bias"])
+    h = F.conv1d(h, sd["decoder.net.7.weight"], sd["decoder.net.7.bias"])
+    return h.transpose(1, 2), z
+
+
 # a15  training-side types, forward only
 def calc_motion(motion: torch.Tensor) -> torch.Tensor:
     """calc_motion, test_emotion_gesture_diversity_iterative.py:41-44 (frame-to-frame offsets)."""
