@@ -107,7 +107,9 @@ template <int PREC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     __shared__ f4 lds[1024];            // fp32: Xs[8][64] | Ws[8][64];  bf16: Xh[4][64] Xl[4][64] Wh[4][64] Wl[4][64] (bf8 = 16 B)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * 64, n0 = by * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     __shared__ bf8 lds[2 * NIMG * IMG];             // [buf][hi|lo][oct][row]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * 64, n0 = by * 64;
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nsteps = (kend - kbeg + 63) / 64;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     };
     auto issue_w = [&](int k0, int buf) {
         bf8* W = lds + buf * (NIMG * IMG);
-        const size_t gbase = ((size_t)blockIdx.y * KO + (k0 >> 3)) * 64;        // bf8 slots: [n/64][k/8][64]
+        const size_t gbase = ((size_t)by * KO + (k0 >> 3)) * 64;        // bf8 slots: [n/64][k/8][64]
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
             const bf8* src = reinterpret_cast<const bf8*>(img ? a.wlo : a.whi) + gbase;
@@ -314,7 +318,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     __shared__ f4 lds[RING * SLOT];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * 64, n0 = by * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[p] + k),
                                              (__attribute__((address_space(3))) void*)(X + (p * 4 + wave) * 64), 16, 0, 0);
         }
-        const size_t gbase = ((size_t)blockIdx.y * KO + (k0 >> 3)) * 64 + wave * 64 + lane;
+        const size_t gbase = ((size_t)by * KO + (k0 >> 3)) * 64 + wave * 64 + lane;
         bf8* W = reinterpret_cast<bf8*>(X + XS);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gbase),
                                          (__attribute__((address_space(3))) void*)(W + wave * 64), 16, 0, 0);
@@ -424,7 +430,9 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
     extern __shared__ __attribute__((aligned(16))) bf8 lds[];             // RING * SLOT
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * 64, n0 = by * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
@@ -435,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         bf8* S = lds + slot * SLOT;
 #pragma unroll
         for (int p = 0; p < KG; ++p) {                                    // piece = octet (p*4 + wave) of this step
-            const size_t gx = ((size_t)blockIdx.x * xKO + a.xoct0 + ko + p * 4 + wave) * 64 + lane;
-            const size_t gw = ((size_t)blockIdx.y * KO + ko + p * 4 + wave) * 64 + lane;
+            const size_t gx = ((size_t)bx * xKO + a.xoct0 + ko + p * 4 + wave) * 64 + lane;
+            const size_t gw = ((size_t)by * KO + ko + p * 4 + wave) * 64 + lane;
             const int d = (p * 4 + wave) * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx),
                                              (__attribute__((address_space(3))) void*)(S + d), 16, 0, 0);
