@@ -95,6 +95,25 @@ def cpu_baseline(sd_g, sd_v, inp, budget_s=20.0):
             "sample": f"{iters} x B={n} passes of oracle mel+cvae_sample+generator_forward (torch fp32 CPU, {cores} threads)"}
 
 
+def measured_traffic(tag, precision):
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r01_traffic.json, written by
+    tools/traffic_json.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench command).  Counters
+    cannot be read inside the timed process, so this is a lookup, None when the profile does not cover the kernel / precision."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    if precision != "bf16x3" or not os.path.exists(path):
+        return None
+    kern = json.load(open(path))["kernels"]
+    if tag in (2, 3, 4):
+        prefix = {2: "gemm_glds_kernel<3>", 3: "gemm_presplit_kernel<3,", 4: "gemm_bf16_kernel<3>"}[tag]
+    elif tag >= 1000:
+        cin, cout, s = tag // 1000000, (tag // 1000) % 1000, (tag // 100) % 10
+        prefix = f"conv3x3_bf16_kernel<{cin}, {(cout + 15) // 16}, {s},"
+    else:
+        return None
+    hits = [v for k, v in kern.items() if k.startswith(prefix)]
+    return hits[0]["bytes"] if hits else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +122,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--precision", default=os.environ.get("EG_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--no-concurrent", action="store_true", help="keep the independent branches on one stream")
+    ap.add_argument("--no-concurrent", action="store_true", help="keep the independent branches of a step on one stream")
+    ap.add_argument("--concurrent", action="store_true",
+                    help="fork the text / prior / CVAE branches of a step onto side streams (default only with --in-flight 1: with "
+                         "several steps in flight the overlap across steps already fills the GPU and the forks cost 5-7 %%)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EG_IN_FLIGHT", "4")),
+                    help="independent steps (batches) in flight per GPU: each has its own engine, workspace, hipGraph and stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -130,45 +154,68 @@ def main():
     from emotiongestures_amd import _lib
     lib = _lib.load()
     gen, vae, mel, sd_g, sd_v = build_models(args.precision, dev)
-    gen.concurrent = not args.no_concurrent
+    lanes = 1 if args.no_graph else max(1, args.in_flight)
+    gen.concurrent = args.concurrent or (lanes == 1 and not args.no_concurrent)
     B = args.batch
     inp = make_inputs(B, seed=1000 + rank)          # every rank generates its own shard of clips
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
 
-    side = torch.cuda.Stream(dev) if gen.concurrent else None
-
-    def step():
-        with torch.no_grad():
-            cur = torch.cuda.current_stream(dev)
-            if side is not None:            # the CVAE draw does not depend on the audio: fork it beside the mel front-end
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
+    def make_step(gen, vae, mel, side):
+        def step():
+            with torch.no_grad():
+                cur = torch.cuda.current_stream(dev)
+                if side is not None:        # the CVAE draw does not depend on the audio: fork it beside the mel front-end
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        sampled = vae.sample(g["label"], z=g["z"])
+                    spec = mel(g["audio"], out_frames=124)
+                    cur.wait_stream(side)
+                else:
+                    spec = mel(g["audio"], out_frames=124)
                     sampled = vae.sample(g["label"], z=g["z"])
-                spec = mel(g["audio"], out_frames=124)
-                cur.wait_stream(side)
-            else:
-                spec = mel(g["audio"], out_frames=124)
-                sampled = vae.sample(g["label"], z=g["z"])
-            return gen(spec, g["text"], g["pre_pose"], sampled)
+                return gen(spec, g["text"], g["pre_pose"], sampled)
+        return step
 
-    eager_step = step
+    side = torch.cuda.Stream(dev) if gen.concurrent else None
+    eager_step = make_step(gen, vae, mel, side)
+    step = eager_step
     graph = None
     if not args.no_graph:
-        # capture one step (all ~230 launches + the fork/join of the side streams) into a hipGraph and replay it
-        cap = torch.cuda.Stream(dev)
-        cap.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(cap):
-            for _ in range(2):
-                eager_step()              # allocate workspaces / set kernel attributes outside the capture
-        torch.cuda.current_stream(dev).wait_stream(cap)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            graph_out = eager_step()
+        # One lane = one captured step (all ~230 launches + the fork/join of its side streams) replayed on its own stream.
+        # Steps are independent batches, so `--in-flight` lanes (each with its own engine handle, weights arena, workspaces
+        # and outputs) are replayed round-robin: the low-occupancy GEMM / attention phase of one batch overlaps the
+        # convolution phase of the next.  The timed region still covers exactly K complete steps.
+        lane_graph, lane_out, lane_stream, keep = [], [], [], []
+        for i in range(lanes):
+            if i == 0:
+                mods = (gen, vae, mel, side)
+            else:
+                g2, v2, m2, _, _ = build_models(args.precision, dev)
+                g2.concurrent = gen.concurrent
+                mods = (g2, v2, m2, torch.cuda.Stream(dev) if gen.concurrent else None)
+            keep.append(mods)
+            fn = make_step(*mods)
+            cap = torch.cuda.Stream(dev)
+            cap.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(cap):
+                for _ in range(2):
+                    fn()                  # allocate workspaces / set kernel attributes outside the capture
+            torch.cuda.current_stream(dev).wait_stream(cap)
+            torch.cuda.synchronize(dev)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                lane_out.append(fn())
+            lane_graph.append(gr)
+            lane_stream.append(torch.cuda.Stream(dev))
+        graph = lane_graph[0]
+        counter = [0]
 
         def step():                         # noqa: F811
-            graph.replay()
-            return graph_out
+            i = counter[0] % lanes
+            counter[0] += 1
+            with torch.cuda.stream(lane_stream[i]):
+                lane_graph[i].replay()
+            return lane_out[i]
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -210,7 +257,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         cap = 400 * max(args.steps, 1)
         gen.concurrent = False                  # per-launch durations are only meaningful without overlapping side streams
-        side = None
+        eager_step = make_step(gen, vae, mel, None)
         eager_step()
         _lib.check(lib.eg_profile_enable(cap), "eg_profile_enable")
         for _ in range(args.steps):
@@ -231,10 +278,10 @@ def main():
         name = gemm_names[dom] if dom in gemm_names else f"conv3x3<cin={dom // 1000000},cout={(dom // 1000) % 1000},stride={(dom // 100) % 10}>"
         achieved = flop / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        step_ms = elapsed / args.steps * 1e3
+        traffic = measured_traffic(dom, args.precision)
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                "launches_per_step": cnt // max(args.steps, 1), "share_of_step": round(tot_ms / args.steps / step_ms, 3),
+                "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_step": cnt // max(args.steps, 1), "kernel_ms_per_step_isolated": round(tot_ms / args.steps, 4),
                 "flop_per_launch": flop,
                 "by_kernel_ms_per_step": {str(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -251,7 +298,7 @@ def main():
             "config": {"workload": "TED clips: 4 s 16 kHz audio -> mel(128x124) -> CVAE sample -> generator -> 34x126 pose",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "variant": "Models_spatial_memory",
                        "parallelism": f"clip-sharded x{world}, no data-path collective",
-                       "launch": "eager" if graph is None else "hipGraph replay",
+                       "launch": "eager" if graph is None else f"hipGraph replay, {lanes} step(s) in flight",
                        "branch_streams": timed_concurrent,
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
             "pose_rel_l2_vs_cpu_oracle": parity, "roofline": roof, "cpu_baseline": cpu,
