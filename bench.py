@@ -185,37 +185,19 @@ def main():
         # Steps are independent batches, so `--in-flight` lanes (each with its own engine handle, weights arena, workspaces
         # and outputs) are replayed round-robin: the low-occupancy GEMM / attention phase of one batch overlaps the
         # convolution phase of the next.  The timed region still covers exactly K complete steps.
-        lane_graph, lane_out, lane_stream, keep = [], [], [], []
-        for i in range(lanes):
-            if i == 0:
-                mods = (gen, vae, mel, side)
-            else:
-                g2, v2, m2, _, _ = build_models(args.precision, dev)
-                g2.concurrent = gen.concurrent
-                mods = (g2, v2, m2, torch.cuda.Stream(dev) if gen.concurrent else None)
-            keep.append(mods)
-            fn = make_step(*mods)
-            cap = torch.cuda.Stream(dev)
-            cap.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(cap):
-                for _ in range(2):
-                    fn()                  # allocate workspaces / set kernel attributes outside the capture
-            torch.cuda.current_stream(dev).wait_stream(cap)
-            torch.cuda.synchronize(dev)
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                lane_out.append(fn())
-            lane_graph.append(gr)
-            lane_stream.append(torch.cuda.Stream(dev))
-        graph = lane_graph[0]
-        counter = [0]
+        from emotiongestures_amd.pipeline import ClipPipeline
+        first = [(gen, vae, mel)]
+
+        def lane_models():
+            if first:
+                return first.pop()
+            g2, v2, m2, _, _ = build_models(args.precision, dev)
+            return g2, v2, m2
+        pipe = ClipPipeline(lane_models, g, dev, lanes=lanes, branch_streams=gen.concurrent)
+        graph = pipe.lanes[0].graph
 
         def step():                         # noqa: F811
-            i = counter[0] % lanes
-            counter[0] += 1
-            with torch.cuda.stream(lane_stream[i]):
-                lane_graph[i].replay()
-            return lane_out[i]
+            return pipe.outputs(pipe.launch_next())
 
     def barrier():
         torch.cuda.synchronize(dev)
