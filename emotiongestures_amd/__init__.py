@@ -21,10 +21,12 @@ def install_aliases() -> None:
     import importlib
     import sys
 
-    for top in ("Full_model", "CAVE", "model", "skeleton_classifer"):
+    for top in ("Full_model", "CAVE", "model", "skeleton_classifer", "data_loader", "utils"):
         pkg = importlib.import_module(f"{__name__}.{top}")
         sys.modules.setdefault(top, pkg)
     for name in ("Full_model.Models_spatial_memory", "Full_model.Models_memory", "Full_model.Layers", "Full_model.SubLayers",
                  "Full_model.Modules", "Full_model.tcn", "Full_model.ResNetSE34V2", "Full_model.ResNetBlocks", "CAVE.BEAT_CVAE",
-                 "model.FGD", "model.FHD_score", "skeleton_classifer.Models"):
+                 "model.FGD", "model.FHD_score", "model.audio_emotion_classifer", "model.motion_ae", "model.embedding_space_evaluator",
+                 "skeleton_classifer.Models", "data_loader.data_preprocessor_expressive", "data_loader.motion_preprocessor_expressive",
+                 "data_loader.lmdb_loader_BEAT_full", "utils.train_utils_BEAT", "utils.data_utils_expressive"):
         sys.modules.setdefault(name, importlib.import_module(f"{__name__}.{name}"))

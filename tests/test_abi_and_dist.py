@@ -128,3 +128,28 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_install_aliases_resolve_reference_import_lines():
+    """The reference's own import lines (test_emotion_gesture_diversity_iterative.py:25-30 and the data path) resolve to the
+    mirrors after install_aliases(); run in a child process so this session's sys.modules stays clean."""
+    import subprocess
+    import sys
+    code = (
+        "import emotiongestures_amd as E; E.install_aliases()\n"
+        "from Full_model.Models_memory import Transformer, Motion_Discriminator\n"
+        "from Full_model.Models_spatial_memory import Transformer as T2\n"
+        "from CAVE.BEAT_CVAE import MLP_Reconstruct_v3 as VAE\n"
+        "from model.FGD import MLP_Reconstruct\n"
+        "from model.FHD_score import calculate_frechet_distance, diversity_score\n"
+        "from skeleton_classifer.Models import Transformer as skeleton_header\n"
+        "from model.audio_emotion_classifer import EmotionNet\n"
+        "from model.motion_ae import MotionAE\n"
+        "from model.embedding_space_evaluator import EmbeddingSpaceEvaluator\n"
+        "from data_loader.data_preprocessor_expressive import DataPreprocessor\n"
+        "from data_loader.lmdb_loader_BEAT_full import SpeechMotionDataset, one_hot_eid\n"
+        "from utils.train_utils_BEAT import extract_melspectrogram, make_audio_fixed_length\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
