@@ -127,7 +127,7 @@ def main():
                     help="fork the text / prior / CVAE branches of a step onto side streams (default only with --in-flight 1: with "
                          "several steps in flight the overlap across steps already fills the GPU and the forks cost 5-7 %%)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EG_IN_FLIGHT", "4")),
-                    help="independent steps (batches) in flight per GPU: each has its own engine, workspace, hipGraph and stream")
+                    help="independent steps (batches) in flight per GPU: each lane has its own workspaces, I/O buffers, hipGraph and stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -155,7 +155,7 @@ def main():
     lib = _lib.load()
     gen, vae, mel, sd_g, sd_v = build_models(args.precision, dev)
     lanes = 1 if args.no_graph else max(1, args.in_flight)
-    gen.concurrent = args.concurrent or (lanes == 1 and not args.no_concurrent)
+    gen.concurrent = lanes == 1 and (args.concurrent or not args.no_concurrent)
     B = args.batch
     inp = make_inputs(B, seed=1000 + rank)          # every rank generates its own shard of clips
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
@@ -182,18 +182,11 @@ def main():
     graph = None
     if not args.no_graph:
         # One lane = one captured step (all ~230 launches + the fork/join of its side streams) replayed on its own stream.
-        # Steps are independent batches, so `--in-flight` lanes (each with its own engine handle, weights arena, workspaces
-        # and outputs) are replayed round-robin: the low-occupancy GEMM / attention phase of one batch overlaps the
-        # convolution phase of the next.  The timed region still covers exactly K complete steps.
+        # Steps are independent batches, so `--in-flight` lanes (own workspaces, I/O buffers and outputs each; the models and
+        # their weights arena are shared) are replayed round-robin: the low-occupancy GEMM / attention phase of one batch
+        # overlaps the convolution phase of the next.  The timed region still covers exactly K complete steps.
         from emotiongestures_amd.pipeline import ClipPipeline
-        first = [(gen, vae, mel)]
-
-        def lane_models():
-            if first:
-                return first.pop()
-            g2, v2, m2, _, _ = build_models(args.precision, dev)
-            return g2, v2, m2
-        pipe = ClipPipeline(lane_models, g, dev, lanes=lanes, branch_streams=gen.concurrent)
+        pipe = ClipPipeline((gen, vae, mel), g, dev, lanes=lanes, branch_streams=gen.concurrent)
         graph = pipe.lanes[0].graph
 
         def step():                         # noqa: F811

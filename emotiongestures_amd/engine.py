@@ -162,19 +162,19 @@ class CvaeEngine:
         self.arena = packing.build_arena(packing.strip_module_prefix(sd), self.entries, self.arena_floats).to(device)
         self._ws.clear()
 
-    def _workspace(self, n, device):
+    def _workspace(self, n, device, slot=0):
         nbytes = self._lib.eg_cvae_workspace_bytes(self._h, n)
-        ws = self._ws.get(n)
+        ws = self._ws.get((n, slot))                # one workspace per concurrent slot (ClipPipeline lane)
         if ws is None or ws.device != torch.device(device):
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self._ws[n] = ws
+            self._ws[(n, slot)] = ws
         return ws, nbytes
 
-    def sample(self, y, z):
+    def sample(self, y, z, slot=0):
         dev = self.arena.device
         y, z = _need_cuda(y, "y"), _need_cuda(z, "z")
         n = y.shape[0]
-        ws, nbytes = self._workspace(n, dev)
+        ws, nbytes = self._workspace(n, dev, slot)
         out = torch.empty(n, self.cfg.frames, self.cfg.d_model, device=dev)
         L.check(self._lib.eg_cvae_sample(self._h, _ptr(self.arena), n, _ptr(y), _ptr(z), _ptr(out), _ptr(ws), nbytes,
                                          _stream(dev)), "eg_cvae_sample")
@@ -205,16 +205,16 @@ class MelFrontEnd:
         self.fb, self.win, self.tw, self.band = (torch.from_numpy(a).to(device) for a in (fb, win, tw, band))
         self._lib, self.device, self._ws = lib, torch.device(device), {}
 
-    def __call__(self, audio: torch.Tensor, out_frames: Optional[int] = None) -> torch.Tensor:
+    def __call__(self, audio: torch.Tensor, out_frames: Optional[int] = None, slot: int = 0) -> torch.Tensor:
         audio = _need_cuda(audio, "audio")
         B, n = audio.shape
         n_frames = 1 + n // 512
         out_frames = n_frames if out_frames is None else out_frames
         nbytes = self._lib.eg_mel_workspace_bytes(B, n)
-        ws = self._ws.get((B, n))
+        ws = self._ws.get((B, n, slot))             # one workspace per concurrent slot (ClipPipeline lane)
         if ws is None:
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            self._ws[(B, n)] = ws
+            self._ws[(B, n, slot)] = ws
         spec = torch.empty(B, 128, out_frames, device=self.device)
         L.check(self._lib.eg_melspectrogram(_ptr(audio), B, n, _ptr(self.fb), _ptr(self.win), _ptr(self.tw), _ptr(self.band), _ptr(spec), out_frames,
                                             _ptr(ws), nbytes, _stream(self.device)), "eg_melspectrogram")

@@ -614,13 +614,13 @@ class MLP_Reconstruct_v3(nn.Module):
     def reparameterize(self, mu, logvar):
         return ops.reparameterize(mu, logvar, torch.randn_like(mu))          # :389-399
 
-    def sample(self, y, z=None):
+    def sample(self, y, z=None, *, slot=0):
         """:427-447.  The latent is drawn with torch.randn(n, 32) on the CPU generator exactly as upstream (:441)
-        unless ``z`` is given (parity tests pass it explicitly)."""
+        unless ``z`` is given (parity tests pass it explicitly).  ``slot`` selects a private workspace (ClipPipeline lane)."""
         _eval_only(self)
         if z is None:
             z = torch.randn(*[y.shape[0], 32])
-        return self.engine().sample(y, z.to(y.device))
+        return self.engine().sample(y, z.to(y.device), slot=slot)
 
     def forward(self, Input, y, eps=None):
         """:403-424 (eval-mode BatchNorm)."""

@@ -2,8 +2,9 @@
 
 One step of the path (mel -> CVAE sample -> generator) is ~230 launches whose middle third (transformer GEMMs, attention,
 LayerNorm at M = B*frames = 2176 rows) cannot fill 256 CUs, while the convolution tower can.  Batches are independent
-(SURVEY.md §8e), so `ClipPipeline` keeps `lanes` of them in flight: every lane owns an engine handle, a weights arena, its
-workspaces, static input / output buffers, one captured hipGraph of the whole step and one stream.  Lanes are replayed
+(SURVEY.md §8e), so `ClipPipeline` keeps `lanes` of them in flight: the lanes share the models (one engine handle and one
+read-only weights arena, so the weights stay hot in L2 / Infinity Cache for all of them) and every lane owns its workspaces
+(the engines' `slot` argument), static input / output buffers, one captured hipGraph of the whole step and one stream.  Lanes are replayed
 round-robin; the GPU's workgroup dispatcher then overlaps the low-occupancy phase of one batch with the convolution phase of
 another (measured on MI355X, B=64, bf16x3: 17.5k clips/s with one step in flight, 22.1k with four).
 
@@ -17,27 +18,30 @@ import torch
 
 
 class _Lane:
-    __slots__ = ("gen", "vae", "mel", "stream", "graph", "inputs", "outputs", "done", "busy")
+    __slots__ = ("slot", "stream", "graph", "inputs", "outputs", "done", "busy")
 
 
 class ClipPipeline:
-    """`make_models() -> (generator, vae | None, mel | None)` is called once per lane (modules already on `device`, eval mode).
+    """`models = (generator, vae | None, mel | None)`: modules already on `device`, eval mode; shared by all lanes.
 
     A step takes audio [B, n_samples] (or a ready spectrogram [B,128,T] when `mel is None`), text [B,60] int64,
     pre_pose [B,P,D], and -- when a VAE is present -- label [B,8] and z [B,32]; it returns the generator's 5-tuple."""
 
-    def __init__(self, make_models: Callable[[], Tuple], example_inputs: dict, device, lanes: int = 4, branch_streams: bool = False):
+    def __init__(self, models: Tuple, example_inputs: dict, device, lanes: int = 4, branch_streams: bool = False):
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("ClipPipeline needs a GPU (no CPU fallback)")
+        self.gen, self.vae, self.mel = models
+        if branch_streams and lanes > 1:
+            raise ValueError("branch_streams forks use per-handle side streams: only with lanes == 1")
+        self.gen.concurrent = bool(branch_streams)
         self.lanes: List[_Lane] = []
         self._next = 0
-        for _ in range(lanes):
+        for i in range(lanes):
             ln = _Lane()
-            ln.gen, ln.vae, ln.mel = make_models()
-            ln.gen.concurrent = bool(branch_streams)
+            ln.slot = i
             ln.stream = torch.cuda.Stream(self.device)
             ln.inputs = {k: v.to(self.device).clone() for k, v in example_inputs.items()}
             ln.done = torch.cuda.Event()
@@ -46,13 +50,12 @@ class ClipPipeline:
             self.lanes.append(ln)
 
     # one step on the current stream, reading the lane's static buffers
-    @staticmethod
-    def _step(ln: _Lane):
+    def _step(self, ln: _Lane):
         g = ln.inputs
         with torch.no_grad():
-            spec = ln.mel(g["audio"], out_frames=ln.gen.engine().cfg.spec_len) if ln.mel is not None else g["spec"]
-            sampled = ln.vae.sample(g["label"], z=g["z"]) if ln.vae is not None else g.get("sampled")
-            return ln.gen(spec, g["text"], g["pre_pose"], sampled)
+            spec = self.mel(g["audio"], out_frames=self.gen.engine().cfg.spec_len, slot=ln.slot) if self.mel is not None else g["spec"]
+            sampled = self.vae.sample(g["label"], z=g["z"], slot=ln.slot) if self.vae is not None else g.get("sampled")
+            return self.gen(spec, g["text"], g["pre_pose"], sampled, slot=ln.slot)
 
     def _capture(self, ln: _Lane) -> None:
         cap = torch.cuda.Stream(self.device)

@@ -30,7 +30,7 @@ def test_pipeline_matches_eager_in_order(lanes, branch):
     dev = torch.device("cuda:0")
     B, n_batches = 4, 7
     batches = [_batch(B, 100 + i, dev) for i in range(n_batches)]
-    pipe = ClipPipeline(lambda: _models(dev), batches[0], dev, lanes=lanes, branch_streams=branch)
+    pipe = ClipPipeline(_models(dev), batches[0], dev, lanes=lanes, branch_streams=branch)
     got = list(pipe.run(batches))
     assert len(got) == n_batches
     gen, vae, mel = _models(dev)
@@ -53,4 +53,4 @@ def test_pipeline_matches_eager_in_order(lanes, branch):
 def test_pipeline_refuses_cpu():
     from emotiongestures_amd.pipeline import ClipPipeline
     with pytest.raises(RuntimeError):
-        ClipPipeline(lambda: None, {}, "cpu")
+        ClipPipeline((None, None, None), {}, "cpu")
