@@ -14,17 +14,9 @@
 //                          free for 16 consecutive pixels (plane stride = 0 mod 16 slots, stride 1; odd, stride 2),
 //   D: each lane owns 4 consecutive output channels of one pixel -> one 16-byte NHWC store per tile.
 #include "common.h"
-#include <stdlib.h>
 
-#ifndef EG_CONV_MIDSYNC_ALL
-#define EG_CONV_MIDSYNC_ALL 1
-#endif
-#ifndef EG_CONV_SETPRIO
-#define EG_CONV_SETPRIO 0      // measured: pinning the MFMA cluster with s_setprio costs 20-50 % here (hipcc stops interleaving the LDS reads)
-#endif
-#ifndef EG_CONV_RING
-#define EG_CONV_RING 3
-#endif
+// (Measured and dropped in round 1: s_setprio around the MFMA cluster costs 20-50 % here -- hipcc stops interleaving the LDS
+//  reads; a persistent 32->32 kernel with register-resident weights was 35 % slower than the tiled one.)
 
 namespace {
 
@@ -184,7 +176,8 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 //    [ci/8][pixel][8 bf16] (same 16-byte slot structure as the fp32 image => conflict-free ds_read_b128);
 //  * weights: pre-split on the host into [tap][ci/8][co][8] (hi image, lo image).  The 4 octets of one (tap, 32-channel
 //    chunk) are one contiguous 64*COUTP-byte run, copied by global_load_lds (16 B/lane, no VGPR, no VALU) into a
-//    2-deep LDS ring: the copy of step s+1 is in flight while step s computes; one barrier per step retires it;
+//    3-slot LDS ring two steps ahead; one barrier per step (placed mid-step, counted vmcnt: see the schedule comment
+//    in the kernel) retires the copy of step s+1 while the copy of step s+2 stays in flight;
 //  * waves tile the workgroup's TH x 32 pixels x COUTP channels as WM (pixels) x WN (channels); per step and
 //    (pixel tile, channel tile) pair:  acc += Whi*Xhi + Whi*Xlo + Wlo*Xhi   (3 x v_mfma_f32_16x16x32_bf16).
 // Without the LDS weight ring every wave re-read all weights from L1/L2 (170 B/clk/CU demanded at C=128 vs 64 B/clk
@@ -245,7 +238,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     constexpr int GTOT = NIMG * PIECES;
     constexpr bool COUNTED = (GTOT % 4 == 0);
     constexpr int GW = GTOT / 4;
-    constexpr bool MIDSYNC = EG_CONV_MIDSYNC_ALL || !(MT * NT >= 16);      // see the schedule comment below
     auto issue_weights = [&](int step, int buf) {
         const int chunk = step / 9, tap = step - chunk * 9;
         const size_t gbase = ((size_t)tap * (CIN / 8) + chunk * 4) * COUTP;
@@ -377,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
 #pragma unroll 1
     for (int chunk = 0; chunk < CIN / 32; ++chunk) {
         store_tile();                           // the tile is free: its last reads completed before the barrier of the previous tap 8
-        if (MIDSYNC && COUNTED && chunk > 0) {  // W of this chunk's tap 0 landed at that barrier too; only W of tap 1 is in flight
+        if (COUNTED && chunk > 0) {              // W of this chunk's tap 0 landed at that barrier too; only W of tap 1 is in flight
             wait_vmcnt_imm<GW>();
             wait_lgkmcnt0();                    // tile writes visible
             wg_barrier();
@@ -391,19 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         for (int tap = 0; tap < 9; ++tap) {
             const int step = chunk * 9 + tap;
             if (step + 2 < NSTEP) issue_weights(step + 2, (tap + 2) % 3);
-            if constexpr (MIDSYNC) {
-                mfma_half(fr[tap & 1], 0);
-                mid_sync(step + 2 < NSTEP);
-                if (tap < 8) { read_w(fr[(tap + 1) & 1], tap + 1); read_x(fr[(tap + 1) & 1], tap + 1); }
-                mfma_half(fr[tap & 1], 1);
-            } else {
-                // register-heavy tilings (64 x 64 per wave): fragments of step s+1 are read during the whole of step s and the
-                // barrier (with a full vmcnt drain) sits at the end of the step; the mid-step variant spills there
-                if (tap < 8) { read_w(fr[(tap + 1) & 1], tap + 1); read_x(fr[(tap + 1) & 1], tap + 1); }
-                mfma_half(fr[tap & 1], 0);
-                mfma_half(fr[tap & 1], 1);
-                __syncthreads();
-            }
+            mfma_half(fr[tap & 1], 0);
+            mid_sync(step + 2 < NSTEP);
+            if (tap < 8) { read_w(fr[(tap + 1) & 1], tap + 1); read_x(fr[(tap + 1) & 1], tap + 1); }
+            mfma_half(fr[tap & 1], 1);
         }
     }
 
@@ -465,152 +448,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
             for (int m = 0; m < WM; ++m) s += sred[m * COUTP + tid];
             a.gap[((size_t)b * a.tiles + tile_id) * a.cout + tid] = s;
         }
-    }
-}
-
-// ---- 32 -> 32 channel body conv (stage 1, 6 launches per forward): persistent, weights in registers ------------------
-// This layer moves 2 MB of activations per clip per launch for only 0.29 GFLOP: it is HBM/Infinity-Cache bound, so the
-// kernel is organised around keeping loads in flight instead of around the MFMA pipe:
-//  * persistent workgroups walk a contiguous range of 4x32-pixel tiles; the NEXT tile's halo pixels are loaded to registers
-//    right after the current tile is staged and stay in flight during its 9 taps;
-//  * all 9 taps x 32 x 32 weights (hi, lo) of a wave's fragments live in registers for the whole kernel (36 x 16 B per lane),
-//    so the tap loop has no weight traffic, no LDS-DMA waits and no barriers: 4 LDS reads + 12 MFMAs per tap per wave.
-template <int TERMS>
-__global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(ConvArgs a, const bf8* __restrict__ whi, const bf8* __restrict__ wlo,
-                                                              int total_tiles) {
-    constexpr int TH = 4, IW = 34, NPIX = (TH + 2) * IW, PL = (NPIX + 15) / 16 * 16, MT = 2, NT = 2, CIN = 32;
-    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;
-    __shared__ bf8 tile[NIMG * 4 * PL];
-    __shared__ float sred[4 * 32];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
-
-    bf8 wh[9][NT], wl[9][NT];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            wh[tap][n] = whi[(tap * 4 + kq) * 32 + n * 16 + li];
-            if (TERMS == 3) wl[tap][n] = wlo[(tap * 4 + kq) * 32 + n * 16 + li];
-        }
-    int pbase[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int id = wave * MT + t;
-        pbase[t] = (id >> 1) * IW + (id & 1) * 16 + li;
-    }
-    const int per = (total_tiles + gridDim.x - 1) / gridDim.x;
-    const int t_begin = blockIdx.x * per, t_end = min(total_tiles, t_begin + per);
-    if (t_begin >= t_end) return;
-
-    f4 pv[NIT][2];
-    auto load_tile = [&](int gt) {
-        const int b = gt / a.tiles, tile_id = gt - b * a.tiles;
-        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
-        const int iy0 = ty * TH - 1, ix0 = tx * 32 - 1;
-        const float* xb = a.x + (size_t)b * a.H * a.W * CIN;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256;
-            const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
-            const int iy = p / IW, ix = p - iy * IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            pv[it][0] = pv[it][1] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (p < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const float* src = xb + ((size_t)gy * a.W + gx) * CIN + oc * 8;
-                pv[it][0] = *reinterpret_cast<const f4*>(src);
-                pv[it][1] = *reinterpret_cast<const f4*>(src + 4);
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256;
-            const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
-            if (p < NPIX) {
-                bf8 hi, lo;
-                split_octet<TERMS == 3>(pv[it][0], pv[it][1], hi, lo);
-                tile[oc * PL + p] = hi;
-                if (TERMS == 3) tile[(4 + oc) * PL + p] = lo;
-            }
-        }
-    };
-
-    load_tile(t_begin);
-#pragma unroll 1
-    for (int gt = t_begin; gt < t_end; ++gt) {
-        store_tile();
-        __syncthreads();
-        if (gt + 1 < t_end) load_tile(gt + 1);          // in flight during the 9 taps below (no waits in the tap loop)
-        f4 acc[MT][NT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
-            bf8 xh[MT], xl[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                xh[t] = tile[kq * PL + pbase[t] + toff];
-                if (TERMS == 3) xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
-            }
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    if (TERMS == 3) {
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[tap][n], xh[t], acc[t][n], 0, 0, 0);
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tap][n], xl[t], acc[t][n], 0, 0, 0);
-                    }
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tap][n], xh[t], acc[t][n], 0, 0, 0);
-                }
-        }
-        // epilogue of this tile
-        const int b = gt / a.tiles, tile_id = gt - b * a.tiles;
-        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * 32;
-        f4 gsum[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
-            const int co = n * 16 + kq * 4;
-            const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
-            const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
-            const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int id = wave * MT + t;
-                const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
-                f4 v = acc[t][n] + bi;
-                if (a.relu) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                v = v * sc + sh;
-                if (oy < a.Ho && ox < a.Wo) {
-                    *reinterpret_cast<f4*>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * 32 + co) = v;
-                    gsum[n] += v;
-                }
-            }
-        }
-        if (a.gap) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sgap = gsum[n][r];
-                    sgap += __shfl_xor(sgap, 1, 64); sgap += __shfl_xor(sgap, 2, 64);
-                    sgap += __shfl_xor(sgap, 4, 64); sgap += __shfl_xor(sgap, 8, 64);
-                    if (li == 0) sred[wave * 32 + n * 16 + kq * 4 + r] = sgap;
-                }
-        }
-        __syncthreads();                // every wave is done reading the tile (and sred is complete)
-        if (a.gap && tid < 32)
-            a.gap[((size_t)b * a.tiles + tile_id) * 32 + tid] = (sred[tid] + sred[32 + tid]) + (sred[64 + tid] + sred[96 + tid]);
-        // sred is rewritten only after the next tile's 9 taps, i.e. after the next store_tile barrier: no extra barrier needed
     }
 }
 
@@ -806,17 +643,7 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
     const int coutp = (int)eg_round_up(cout, 16);
     EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + stride * 100 + 1,
                      2.0 * 9 * cin * cout * (double)a.Ho * a.Wo * batch, st);
-    if (cin == 32 && coutp == 32 && stride == 1 && th == 4) {
-        if (precision == EG_PREC_F32 || a.nchw || !getenv("EG_C32_PERSISTENT")) return launch_conv<32, 2, 1, 4, 4, 1>(a, batch, precision, st);
-        const size_t f32_floats = (size_t)9 * 32 * 32;
-        const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
-        const bf8* wlo = whi + (size_t)9 * 4 * 32;
-        const int total = a.tiles * batch;
-        const int grid = total < 512 ? total : 512;          // 2 persistent workgroups per CU
-        if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_c32_kernel<3>), dim3(grid), dim3(256), 0, st, a, whi, wlo, total);
-        else hipLaunchKernelGGL((conv3x3_c32_kernel<1>), dim3(grid), dim3(256), 0, st, a, whi, wlo, total);
-        return eg_check_launch("conv3x3_c32");
-    }
+    if (cin == 32 && coutp == 32 && stride == 1 && th == 4) return launch_conv<32, 2, 1, 4, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2, 2, 2>(a, batch, precision, st);
     if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8, 4, 1>(a, batch, precision, st);
