@@ -214,6 +214,13 @@ def main():
     value = total_clips / elapsed
 
     timed_concurrent = bool(gen.concurrent)
+    # every lane ran the same resident batch: their outputs must agree bit for bit (catches any cross-lane interference)
+    lanes_equal = None
+    if graph is not None and lanes > 1:
+        base = pipe.outputs(0)
+        lanes_equal = all(torch.equal(a, b) for i in range(1, lanes) for a, b in zip(pipe.outputs(i), base))
+        if not lanes_equal:
+            raise SystemExit("bench.py: lanes disagree on the same batch -- results depend on concurrent work (invalid run)")
     # ---- parity spot check on this very batch (first 2 clips) against the CPU oracle ----
     parity = None
     roof = None
@@ -276,7 +283,7 @@ def main():
                        "launch": "eager" if graph is None else f"hipGraph replay, {lanes} step(s) in flight",
                        "branch_streams": timed_concurrent,
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
-            "pose_rel_l2_vs_cpu_oracle": parity, "roofline": roof, "cpu_baseline": cpu,
+            "pose_rel_l2_vs_cpu_oracle": parity, "lanes_bitwise_equal": lanes_equal, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
 

@@ -8,7 +8,6 @@
 // LDS images are k-quad (fp32) / k-octet (bf16) planar: [k/4][row][4] -- 64 rows per plane = 0 mod 16 slots, so the
 // ds_read_b128 of 16 consecutive rows is bank-conflict free.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -419,8 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 // ahead, fragments of step s+1 read from LDS while the MFMAs of step s run (register double buffer), one counted vmcnt and
 // one raw barrier per 32-deep step.
 
-// BK = K elements per barrier interval (32 or 64), RING = LDS slots.  BK 64 halves the barriers / waits per MFMA for the
-// small-grid products (one workgroup per CU anyway); BK 32 x 4 slots keeps two workgroups per CU for the large grids.
+// BK = K elements per barrier interval, RING = LDS slots; shipped as <32, 4> (see the launcher for the variants that lost).
 template <int TERMS, int BK, int RING>
 __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
@@ -459,10 +457,16 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         }
     };
     auto wait_groups = [&](int n) {                 // all but the youngest n step groups of this wave have landed
-        if (n >= 2) wait_vmcnt_imm<2 * G>();
-        else if (n == 1) wait_vmcnt_imm<G>();
-        else wait_vmcnt_imm<0>();
+        switch (n) {
+            case 0: wait_vmcnt_imm<0>(); break;
+            case 1: wait_vmcnt_imm<G>(); break;
+            case 2: wait_vmcnt_imm<2 * G>(); break;
+            case 3: wait_vmcnt_imm<3 * G>(); break;
+            case 4: wait_vmcnt_imm<4 * G>(); break;
+            default: wait_vmcnt_imm<5 * G>(); break;
+        }
     };
+    static_assert(RING <= 8 && 5 * G <= 63, "wait_groups covers RING - 3 <= 5 groups in flight");
     struct Frags { bf8 xh[KG][2], xl[KG][2], wh[KG][2], wl[KG][2]; };
     auto read_frags = [&](Frags& f, int slot) {
         const bf8* S = lds + slot * SLOT + li;
@@ -520,8 +524,43 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) as a real instruction, so the compiler's own wait insertion sees it
         wg_barrier();
     };
+    int s0 = 0;
+    if constexpr (BK == 32) {
+        // Steady state, RING steps per iteration: every step issues a copy (group s+RING-1), so there are no conditionals, the
+        // ring slots are compile-time constants and the source addresses are four running pointers (one 64-bit add each per
+        // step).  A copy has RING-2 steps to land.
+        constexpr int AHEAD = (RING - 1) * 4;                           // octets between this step and the group it issues
+        const bf8* px = xhi + ((size_t)bx * xKO + a.xoct0 + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
+        const bf8* pxl = xlo + ((size_t)bx * xKO + a.xoct0 + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
+        const bf8* pw = reinterpret_cast<const bf8*>(a.whi) + ((size_t)by * KO + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
+        const bf8* pwl = reinterpret_cast<const bf8*>(a.wlo) + ((size_t)by * KO + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
+        auto fast = [&](const int j, Frags& cur, Frags& nxt) {     // j = step index mod RING (static)
+            bf8* S = lds + ((j + RING - 1) % RING) * SLOT + wave * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px, (__attribute__((address_space(3))) void*)S, 16, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pxl, (__attribute__((address_space(3))) void*)(S + 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw, (__attribute__((address_space(3))) void*)(S + OP), 16, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pwl, (__attribute__((address_space(3))) void*)(S + OP + 256), 16, 0, 0);
+            px += 256; pxl += 256; pw += 256; pwl += 256;
+            read_frags(nxt, (j + 1) % RING);
+            mfma_step(cur);
+            wait_vmcnt_imm<(RING - 3) * G>();       // group s+2 landed; the RING-3 younger copies stay in flight
+            wait_lgkmcnt0();
+            wg_barrier();
+        };
+        constexpr int UNR = (RING % 2) ? 2 * RING : RING;               // whole ring turns and an even number of steps (fa / fb)
 #pragma unroll 1
-    for (int s = 0; s < nsteps; s += 2) {
+        for (; s0 + UNR + RING - 1 <= nsteps; s0 += UNR) {
+#pragma unroll
+            for (int j = 0; j < UNR; j += 2) {
+                fast(j % RING, fa, fb);
+                fast((j + 1) % RING, fb, fa);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int s = s0; s < nsteps; s += 2) {          // head of short products and the last steps (copies run out): generic path
         step(s, fa, fb);
         if (s + 1 < nsteps) step(s + 1, fb, fa);
     }
@@ -637,11 +676,11 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
         dim3 grid(mt, eg_cdiv(p.n, 64), 1);
-        // 32-deep steps, 4 slots, two workgroups per CU.  The 64-deep variant (EG_GEMM_BK64=1, small grids only) measured 16 % slower in round 1.
-        const bool deep = (p.k % 64 == 0) && ((long)grid.x * grid.y <= 2 * 256) && getenv("EG_GEMM_BK64");
-        if (p.precision == EG_PREC_BF16X3)
-            return deep ? launch_presplit<3, 64, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st);
-        return deep ? launch_presplit<1, 64, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
+        // 32-deep steps, 4 slots (64 KB: two workgroups per CU).  Measured and dropped in round 1 (2176-row products, bf16x3):
+        // 64-deep steps with 4 slots (16 % slower), 5 slots (no change), 8 slots (one workgroup per CU: the 272-tile grids
+        // then need two passes, 50 % slower), register-staged copies instead of LDS-DMA (30 % slower).
+        if (p.precision == EG_PREC_BF16X3) return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st);
+        return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
     return launch_gemm(a, 1, p.precision, st);
@@ -710,8 +749,6 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
     const bf8* xlo = xhi + (size_t)mt * xko * 64;
     dim3 grid(mt, eg_cdiv(n, 64), 1);
     EgProfScope prof(3, 2.0 * m * (double)n * k, (hipStream_t)stream);
-    const bool deep = (k % 64 == 0) && ((long)grid.x * grid.y <= 2 * 256) && getenv("EG_GEMM_BK64");
-    if (precision == EG_PREC_BF16X3)
-        return deep ? launch_presplit<3, 64, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream) : launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
-    return deep ? launch_presplit<1, 64, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+    if (precision == EG_PREC_BF16X3) return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+    return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
 }

@@ -745,6 +745,12 @@ extern "C" int eg_generator_tap(const EgGenerator* g, int32_t batch, void* ws, c
     else if (n == "fusion") { off = w.fusion; cnt = BFD; }
     else if (n == "enc_out") { off = w.xa; cnt = BFD; }
     else if (n == "audio_map") { off = w.amap; cnt = (int64_t)batch * c.frames * g->HW3; }
+    else if (n == "mha_out") { off = w.xb; cnt = BFD; }                     // last MultiHeadAttention output (post LayerNorm)
+    else if (n == "attn_q") { off = w.q; cnt = BFD; }                       // last cross-attention query projection
+    else if (n == "attn_qkv") { off = w.qkv; cnt = 3 * BFD; }               // last Q|K|V (self) or K|V (cross) projection
+    else if (n == "attn_out") { off = w.ao; cnt = BFD; }                    // last attention output (heads concatenated)
+    else if (n == "proj") { off = w.proj; cnt = BFD; }                      // last pre-LayerNorm sum (fc / w_2 output + residual)
+    else if (n == "dec_out") { off = w.fus_h; cnt = BFD; }
     else if (g->keep_taps && n == "stem") { off = w.tap_stem; cnt = (int64_t)batch * g->H1 * g->W1 * 32; }
     else if (g->keep_taps && n == "layer1") { off = w.tap_l[0]; cnt = (int64_t)batch * g->H1 * g->W1 * 32; }
     else if (g->keep_taps && n == "layer2") { off = w.tap_l[1]; cnt = (int64_t)batch * g->H2 * g->W2 * 64; }

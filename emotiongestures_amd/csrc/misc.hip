@@ -115,8 +115,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     __syncthreads();
     for (int i = tid; i < nq * 16; i += 256) {
         const int r = i >> 4, d4 = i & 15;
-        f4 o = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < Lk; ++c) o += *reinterpret_cast<const f4*>(Vs + c * ATT_P + d4 * 4) * Ss[r * LkP + c];
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        for (int c = 0; c < Lk; ++c) {
+            const f4 vv = *reinterpret_cast<const f4*>(Vs + c * ATT_P + d4 * 4);
+            const float p = Ss[r * LkP + c];
+            // scalar FMAs on purpose (inline asm keeps hipcc from re-forming v_pk_fma_f32): see DESIGN.md "co-residency"
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o0) : "v"(vv[0]), "v"(p));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o1) : "v"(vv[1]), "v"(p));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o2) : "v"(vv[2]), "v"(p));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o3) : "v"(vv[3]), "v"(p));
+        }
+        const f4 o = (f4){o0, o1, o2, o3};
         *reinterpret_cast<f4*>(out + ((size_t)b * Lq + q0 + r) * ldo + h * 64 + d4 * 4) = o;
         if (oimg) {         // also emit the head-concatenated row as bf16 (hi, lo) tile-planar images for the output projection
             const f4 z = (f4){0.f, 0.f, 0.f, 0.f};

@@ -54,3 +54,37 @@ def test_pipeline_refuses_cpu():
     from emotiongestures_amd.pipeline import ClipPipeline
     with pytest.raises(RuntimeError):
         ClipPipeline((None, None, None), {}, "cpu")
+
+
+def test_results_do_not_depend_on_concurrent_work():
+    """A forward must return the same bits whether or not other kernels are resident on the GPU (lanes overlap a batch's
+    transformer phase with another batch's convolutions).  Round 1 caught the attention kernel returning wrong lanes while
+    an MFMA convolution was co-resident (tools/repro_pk_fma_under_mfma.py); this keeps the whole path under that load."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd import ops
+    from emotiongestures_amd.engine import _ptr, _stream
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    gen, vae, mel = _models(dev)
+    gen.concurrent = False
+    b = _batch(4, 300, dev)
+    x = torch.randn(16, 32, 31, 128, device=dev)
+    wp, _ = ops.pack_conv3x3_weight(torch.randn(128, 128, 3, 3) * 0.05, dev)
+    y = torch.empty(16, 32, 31, 128, device=dev)
+    pc = L.precision_code("bf16x3")
+
+    def fwd():
+        with torch.no_grad():
+            return gen(mel(b["audio"], out_frames=124), b["text"], b["pre_pose"], vae.sample(b["label"], z=b["z"]))
+    ref = [t.clone() for t in fwd()]
+    torch.cuda.synchronize()
+    sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    for _ in range(12):
+        with torch.cuda.stream(sB):
+            for _ in range(150):
+                lib.eg_conv3x3(_ptr(x), _ptr(wp), None, None, None, _ptr(y), None, 16, 32, 31, 128, 128, 1, 1, 0, pc, _stream(dev))
+        with torch.cuda.stream(sA):
+            out = fwd()
+        torch.cuda.synchronize()
+        for a, r in zip(out, ref):
+            assert torch.equal(a, r)
