@@ -71,6 +71,24 @@ def test_config_validation_and_status_codes():
     lib = _lib.load()
     assert lib.eg_set_default_precision(7) != 0 and b"precision" in lib.eg_last_error()
     assert lib.eg_conv3x3(None, None, None, None, None, None, None, 1, 8, 8, 32, 32, 1, 0, 0, 0, None) == -1   # EG_ERR_BAD_ARG, no launch
+    # argument validation happens before any HIP call, so these run without a GPU: every entry refuses null operands / bad
+    # shapes with a negative status and a message, and launches nothing
+    one = C.c_void_p(16)                                      # a non-null, 16-byte aligned dummy address that is never dereferenced
+    assert lib.eg_linear(None, 4, None, 4, None, None, None, 0, None, 4, 1, 1, 4, 0, 0, 0, 0, None) < 0
+    assert lib.eg_layernorm(None, None, None, None, 4, 512, 1e-6, None) < 0
+    assert lib.eg_attention(one, 512, one, 512, one, 512, one, 512, None, 1, 8, 4, 4, 32, None) == -2         # d_k 32: EG_ERR_UNSUPPORTED
+    assert b"d_k" in lib.eg_last_error()
+    assert lib.eg_attention(one, 512, one, 512, one, 512, one, 512, None, 1, 8, 4, 300, 64, None) == -2        # Lk > 256
+    assert lib.eg_conv3x3(one, one, None, None, None, one, None, 1, 8, 8, 32, 32, 3, 0, 0, 0, None) == -2      # stride 3
+    assert lib.eg_conv3x3(one, one, None, None, None, one, None, 1, 8, 8, 48, 48, 1, 0, 0, 0, None) == -2      # channel count without a kernel
+    assert lib.eg_conv1d(one, one, one, one, None, one, 1, 4, 4, 8, 3, 1, 1, 1, None) == -1                    # scale without shift
+    assert lib.eg_conv1d(one, one, one, None, None, one, 1, 4, 4, 2, 5, 1, 0, 0, None) == -1                   # kernel longer than the padded input
+    assert lib.eg_contrastive_loss(one, one, 0, 4, None, one, one, one, 64, None) == -1                        # n = 0
+    assert lib.eg_contrastive_loss(one, one, 8, 4, None, one, one, one, 8, None) == -3                         # workspace too small
+    assert lib.eg_multi_head_attention(one, one, one, one, one, one, one, one, one, None, 1, 4, 4, 510, 8, 0, one, 1 << 30, None) == -2   # d_model % 4
+    assert lib.eg_se_gate(one, 4, one, one, one, one, one, 1, 200, 16, None) == -2                              # C = 200
+    assert lib.eg_generator_forward(None, None, 1, None, None, None, None, None, None, None, None, None, None, 0, None) < 0
+    assert lib.eg_mel_workspace_bytes(0, 64000) == 0 and lib.eg_mel_workspace_bytes(2, 64000) == 2 * 128 * 126 * 4
 
 
 def test_conv_pack_layout_roundtrip():
