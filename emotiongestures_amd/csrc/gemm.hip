@@ -8,6 +8,7 @@
 // LDS images are k-quad (fp32) / k-octet (bf16) planar: [k/4][row][4] -- 64 rows per plane = 0 mod 16 slots, so the
 // ds_read_b128 of 16 consecutive rows is bank-conflict free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -584,6 +585,121 @@ int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, 
     return eg_check_launch("gemm_presplit");
 }
 
+// ---- pre-split product, 128 x 128 tile (large M) -----------------------------------------------------------------------
+// The 64 x 64-tile kernel above streams 16 KB from L2 into LDS for every 48 MFMAs of a workgroup; at M = B*draws*frames rows
+// (BASELINE cfg 5: 69 632) that stream, 13-15 TB/s chip-wide, is what bounds it (200-250 TFLOP/s algorithmic).  This variant
+// doubles the reuse: 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 64 x 32 (4 x 2 MFMA tiles, 24 MFMAs per step in bf16x3),
+// workgroup tile 128 x 128 = two 64-row image tiles of X and of W, 32 KB per 32-deep step, 3-slot ring (96 KB: one workgroup
+// = two waves per SIMD).  Schedule as in the convolution: one barrier per step between the two MFMA halves, counted vmcnt
+// (the copy of step s+2 stays in flight), fragments of step s+1 read after the barrier under the second half.
+template <int TERMS>
+__global__ __launch_bounds__(512, 1) void gemm_presplit128_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO,
+                                                                  int m_tiles, int n_tiles) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr int OPI = 8 * 64;                         // bf8 slots of one image of one operand: [tile(2)][octet(4)][64 rows]
+    constexpr int OP = NIMG * OPI, SLOT = 2 * OP, RING = 3;
+    constexpr int G = 2 * NIMG;                         // LDS-DMA instructions per wave per step (one 1-KiB piece each)
+    extern __shared__ __attribute__((aligned(16))) bf8 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * 128, n0 = by * 128;
+    const int wm = wave >> 2, wn = wave & 3;            // wave tile: rows [wm*64, +64), columns [wn*32, +32)
+    const int nsteps = (a.K + 31) / 32;
+    const int KO = a.ldw >> 3;
+    // copy role: wave w moves piece w of each image: tile = w>>2, octet = w&3.  A 128-row workgroup whose second 64-row
+    // tile does not exist (odd tile counts) re-reads the last tile; those rows / columns are never stored.
+    const int pt = wave >> 2, po = wave & 3;
+    const size_t gx = ((size_t)min(bx * 2 + pt, m_tiles - 1) * xKO + a.xoct0 + po) * 64 + lane;
+    const size_t gw = ((size_t)min(by * 2 + pt, n_tiles - 1) * KO + po) * 64 + lane;
+    const bf8* whi = reinterpret_cast<const bf8*>(a.whi);
+    const bf8* wlo = reinterpret_cast<const bf8*>(a.wlo);
+    auto issue = [&](int step, int slot) {
+        bf8* S = lds + slot * SLOT + wave * 64;
+        const size_t o = (size_t)step * 4 * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx + o), (__attribute__((address_space(3))) void*)S, 16, 0, 0);
+        if (TERMS == 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xlo + gx + o), (__attribute__((address_space(3))) void*)(S + OPI), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(whi + gw + o), (__attribute__((address_space(3))) void*)(S + OP), 16, 0, 0);
+        if (TERMS == 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wlo + gw + o), (__attribute__((address_space(3))) void*)(S + OP + OPI), 16, 0, 0);
+    };
+    struct Frags { bf8 xh[4], xl[4], wh[2], wl[2]; };
+    auto read_frags = [&](Frags& f, int slot) {
+        const bf8* X = lds + slot * SLOT + (wm * 4 + kq) * 64 + li;
+        const bf8* W = lds + slot * SLOT + OP + ((wn >> 1) * 4 + kq) * 64 + (wn & 1) * 32 + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f.xh[t] = X[t * 16];
+            if (TERMS == 3) f.xl[t] = X[OPI + t * 16];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f.wh[n] = W[n * 16];
+            if (TERMS == 3) f.wl[n] = W[OPI + n * 16];
+        }
+    };
+    f4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+    auto mfma_half = [&](const Frags& f, int half) {
+#pragma unroll
+        for (int t = half * 2; t < half * 2 + 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (TERMS == 3) {
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[n], f.xh[t], acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[t][n], 0, 0, 0);
+                }
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
+            }
+    };
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    wait_vmcnt_imm<0>();
+    wg_barrier();
+    Frags fa, fb;
+    read_frags(fa, 0);
+    auto step = [&](int s, Frags& cur, Frags& nxt) {
+        const bool ahead = s + 2 < nsteps;
+        if (ahead) issue(s + 2, (s + 2) % RING);        // slot of step s-1: its fragments were read before the barrier of step s-1
+        mfma_half(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ahead) wait_vmcnt_imm<G>(); else wait_vmcnt_imm<0>();       // group s+1 landed
+        wait_lgkmcnt0();
+        wg_barrier();
+        if (s + 1 < nsteps) read_frags(nxt, (s + 1) % RING);
+        mfma_half(cur, 1);
+    };
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, fa, fb);
+        if (s + 1 < nsteps) step(s + 1, fb, fa);
+    }
+    gemm_epilogue<4, 2>(a, acc, m0 + wm * 64 + li, n0 + wn * 32 + kq * 4);
+}
+
+template <int TERMS>
+int launch_presplit128(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int m_tiles, int n_tiles, hipStream_t st) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr size_t LDS_BYTES = (size_t)3 * 2 * NIMG * 8 * 64 * 16;
+    auto kern = gemm_presplit128_kernel<TERMS>;
+    static bool attr_done = false;
+    if (!attr_done && LDS_BYTES > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
+            eg_set_error("gemm_presplit128: cannot reserve %zu B of LDS", LDS_BYTES);
+            return EG_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(eg_cdiv(m_tiles, 2), eg_cdiv(n_tiles, 2), 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, st, a, xhi, xlo, xko, m_tiles, n_tiles);
+    return eg_check_launch("gemm_presplit128");
+}
+
 // fp32 [M, K] (row stride lda) -> bf16 (hi, lo) tile-planar images [ceil(M/64)][Kpad/8][64][8]; rows >= M and k >= K are zero.
 __global__ __launch_bounds__(256) void split_tile_kernel(const float* __restrict__ x, int lda, int M, int K, int KO,
                                                          bf8* __restrict__ hi, bf8* __restrict__ lo) {
@@ -679,6 +795,10 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         // 32-deep steps, 4 slots (64 KB: two workgroups per CU).  Measured and dropped in round 1 (2176-row products, bf16x3):
         // 64-deep steps with 4 slots (16 % slower), 5 slots (no change), 8 slots (one workgroup per CU: the 272-tile grids
         // then need two passes, 50 % slower), register-staged copies instead of LDS-DMA (30 % slower).
+        if ((long)eg_cdiv(p.m, 128) * eg_cdiv(p.n, 128) >= 1024 && !getenv("EG_GEMM_NO128")) {   // >= 4 workgroups per CU, else the 64 x 64 kernel wins (8704 x 512: 23.7 vs 28.7 us)
+            if (p.precision == EG_PREC_BF16X3) return launch_presplit128<3>(a, xhi, xlo, xko, mt, eg_cdiv(p.n, 64), st);
+            return launch_presplit128<1>(a, xhi, xlo, xko, mt, eg_cdiv(p.n, 64), st);
+        }
         if (p.precision == EG_PREC_BF16X3) return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st);
         return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
     }
@@ -749,6 +869,10 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
     const bf8* xlo = xhi + (size_t)mt * xko * 64;
     dim3 grid(mt, eg_cdiv(n, 64), 1);
     EgProfScope prof(3, 2.0 * m * (double)n * k, (hipStream_t)stream);
+    if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 1024 && !getenv("EG_GEMM_NO128")) {
+        if (precision == EG_PREC_BF16X3) return launch_presplit128<3>(a, xhi, xlo, xko, mt, eg_cdiv(n, 64), (hipStream_t)stream);
+        return launch_presplit128<1>(a, xhi, xlo, xko, mt, eg_cdiv(n, 64), (hipStream_t)stream);
+    }
     if (precision == EG_PREC_BF16X3) return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
     return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
 }

@@ -207,3 +207,35 @@ def test_reparameterize_and_add_rows():
     assert rel_l2(z.numpy(), (eps * torch.exp(0.5 * lv) + mu).numpy()) < 2e-6
     a, tab = T("a", (3, 34, 512)), T("tab", (34, 512))
     assert torch.equal(ops.add_rows(a.to(dev()), tab.to(dev()), period=34).cpu(), a + tab)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(136, 512, 512),        # 64 x 64 tiles (one workgroup per CU regime)
+                                   (66500, 192, 96),       # 128 x 128 tiles (>= 1024 of them), odd tile counts on both axes, 3 K-steps
+                                   (26112, 640, 1024)])    # 128 x 128 tiles, full ring turns
+def test_linear_presplit_matches_fp64(prec, M, N, K):
+    """eg_split_tiles + eg_linear_presplit (both tile sizes) vs a float64 product, with bias + residual + ReLU."""
+    import ctypes as C
+
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd import ops
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    x, w = T("px", (M, K)), T("pw", (N, K), -0.1, 0.1)
+    bias, res = T("pb", (N,)), T("pr", (M, N))
+    xd, rd, bd = x.to(dev()), res.to(dev()), bias.to(dev())
+    wp, npad, kpad = ops.pack_linear_weight(w, dev())
+    bp = torch.zeros(npad, device=dev()); bp[:N] = bd
+    kp, mt = (K + 63) // 64 * 64, (M + 63) // 64
+    img = torch.empty(2 * mt * 64 * kp, dtype=torch.int16, device=dev())
+    L.check(lib.eg_split_tiles(_ptr(xd), K, M, K, _ptr(img), _stream(dev())), "eg_split_tiles")
+    y = torch.empty(M, N, device=dev())
+    L.check(lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, _ptr(bp), _ptr(rd), None, N, _ptr(y), N, M, N, K, 1,
+                                   L.precision_code(prec), _stream(dev())), "eg_linear_presplit")
+    ref = torch.relu(x.double() @ w.double().T + bias.double() + res.double())
+    assert rel_l2(y.cpu().numpy(), ref.numpy()) < TOL[prec]
+    # same operands through eg_linear (in-kernel split): identical arithmetic, so identical bits
+    y2 = torch.empty(M, N, device=dev())
+    L.check(lib.eg_linear(_ptr(xd), K, _ptr(wp), kpad, _ptr(bp), _ptr(rd), None, N, _ptr(y2), N, M, N, K, 1, 0, 0,
+                          L.precision_code(prec), _stream(dev())), "eg_linear")
+    assert torch.equal(y, y2)
