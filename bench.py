@@ -234,6 +234,21 @@ def main():
             s_ref = O.cvae_sample(sd_v, t2["label"], t2["z"])
             pose_ref = O.generator_forward(sd_g, O.GenCfg(), spec_ref, t2["text"], t2["pre_pose"], s_ref)[0]
         parity = clip_rel_l2(out[0][:2].cpu().numpy(), pose_ref.numpy())
+    fgd = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and B >= 32:
+        # "FGD vs ref" half of the metric: Frechet distance between the FGD auto-encoder latents (model/FGD.py:26-82, HIP path,
+        # synthetic weights) of the GPU poses and of the CPU oracle's poses for the same 32 clips (34 x 32 = 1088 feature rows)
+        from emotiongestures_amd.harness import MLP_Reconstruct, calculate_frechet_distance
+        from emotiongestures_amd.synth import load_synth_weights
+        with torch.no_grad():
+            n = 32
+            tn = {k: torch.from_numpy(v[:n]) for k, v in inp.items() if k != "audio"}
+            spec_n = torch.from_numpy(O.melspectrogram(inp["audio"][:n], out_frames=124))
+            pose_cpu = O.generator_forward(sd_g, O.GenCfg(), spec_n, tn["text"], tn["pre_pose"], O.cvae_sample(sd_v, tn["label"], tn["z"]))[0]
+            ae = load_synth_weights(MLP_Reconstruct(pose_dim=126), 5).eval().to(dev)
+            fa = ae(out[0][:n].contiguous())[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
+            fb = ae(pose_cpu.to(dev))[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
+        fgd = float(np.real(calculate_frechet_distance(fa.mean(0), np.cov(fa, rowvar=False), fb.mean(0), np.cov(fb, rowvar=False))))
 
     # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
     if rank == 0 and not args.no_roofline:
@@ -283,7 +298,7 @@ def main():
                        "launch": "eager" if graph is None else f"hipGraph replay, {lanes} step(s) in flight",
                        "branch_streams": timed_concurrent,
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
-            "pose_rel_l2_vs_cpu_oracle": parity, "lanes_bitwise_equal": lanes_equal, "roofline": roof, "cpu_baseline": cpu,
+            "pose_rel_l2_vs_cpu_oracle": parity, "fgd_vs_cpu_oracle": fgd, "lanes_bitwise_equal": lanes_equal, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
 
