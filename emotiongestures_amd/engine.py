@@ -6,7 +6,6 @@ allocator) and for the current HIP stream; every FLOP of the path runs in libemo
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Dict, Mapping, Optional
 
 import torch

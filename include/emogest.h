@@ -154,8 +154,10 @@ int eg_generator_forward_draws(const EgGenerator* g, const float* arena, int32_t
 int64_t eg_generator_draws_workspace_bytes(const EgGenerator* g, int32_t batch, int32_t draws);
 
 /* Intermediate taps of the most recent eg_generator_forward on this workspace (for parity tests):
- * returns the device pointer inside `workspace` and the element count; names: "stem", "layer1",
- * "layer2", "layer3" (NHWC), "audio_feat", "prior_enc", "fusion", "enc_out", "dec_out". */
+ * returns the device pointer inside `workspace` and the element count; names: "stem", "layer1", "layer2", "layer3"
+ * (NHWC, only when the generator was created with keep_taps), "audio_map", "audio_feat", "prior_enc", "fusion", "enc_out",
+ * "dec_out", and the buffers the attention blocks reuse -- contents of the LAST block that ran: "attn_q", "attn_qkv",
+ * "attn_out", "mha_out", "proj". */
 int eg_generator_tap(const EgGenerator* g, int32_t batch, void* workspace, const char* name,
                      float** d_ptr, int64_t* numel);
 
