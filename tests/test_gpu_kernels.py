@@ -239,3 +239,28 @@ def test_linear_presplit_matches_fp64(prec, M, N, K):
     L.check(lib.eg_linear(_ptr(xd), K, _ptr(wp), kpad, _ptr(bp), _ptr(rd), None, N, _ptr(y2), N, M, N, K, 1, 0, 0,
                           L.precision_code(prec), _stream(dev())), "eg_linear")
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_linear_random_shapes(prec):
+    """eg_linear over 24 seeded shapes (ragged M / N, K not a multiple of the 32-deep step) vs float64, all epilogue options."""
+    from emotiongestures_amd import ops
+    rng = np.random.RandomState(1234)
+    for case in range(24):
+        M, N = int(rng.randint(1, 300)), int(rng.randint(1, 700))
+        K = 4 * int(rng.randint(1, 280))
+        relu = bool(case & 1)
+        x, w = T(f"rx{case}", (M, K)), T(f"rw{case}", (N, K), -0.2, 0.2)
+        b = T(f"rb{case}", (N,)) if case % 3 else None
+        r1 = T(f"rr{case}", (M, N)) if case % 4 == 0 else None
+        got = ops.linear(x.to(dev()), w, None if b is None else b.to(dev()), res1=None if r1 is None else r1.to(dev()), relu=relu,
+                         precision=prec).cpu()
+        ref = x.double() @ w.double().T
+        if b is not None:
+            ref = ref + b.double()
+        if r1 is not None:
+            ref = ref + r1.double()
+        if relu:
+            ref = torch.relu(ref)
+        assert got.shape == (M, N)
+        assert rel_l2(got.numpy(), ref.numpy()) < TOL[prec] * 2, (case, M, N, K)
