@@ -2,7 +2,8 @@
 """Throughput of the other BASELINE.json configurations on one GPU (informational; the contract line is bench.py):
   cfg 4  BEAT-long: 10 s audio -> mel [128,312] -> CVAE (120 ch) -> generator (120 frames x 282) at B=16 per step
   cfg 5  diversity: B=64 TED clips, 32 CVAE draws per clip; audio tower once per clip, fusion/enc/dec/post per draw
-usage: bench_configs.py [long|draws] [precision]"""
+  h2d    the headline workload through ClipPipeline.run with inputs starting in pinned host memory
+usage: bench_configs.py [long|draws|h2d] [precision]"""
 import os
 import sys
 import time
@@ -65,6 +66,30 @@ def draws(prec):
     print(f"cfg5 diversity {prec}: B={B} clips x {R} draws: {dt * 1e3:.2f} ms/step, {B / dt:.0f} clips/s, {B * R / dt:.0f} pose sequences/s")
 
 
+def host_inputs(prec):
+    """PCIe-inclusive rate of the headline workload: every batch starts in pinned host memory (audio 16 MB + small tensors),
+    ClipPipeline.run copies it into a lane's buffers on the lane's stream and returns the poses to the caller's stream."""
+    import bench
+    from emotiongestures_amd.pipeline import ClipPipeline
+    gen, vae, mel, _, _ = bench.build_models(prec, dev)
+    inp = bench.make_inputs(64, seed=1000)
+    keys = ("audio", "text", "pre_pose", "label", "z")
+    host = {k: torch.from_numpy(inp[k]).pin_memory() for k in keys}
+    g = {k: v.to(dev) for k, v in host.items()}
+    pipe = ClipPipeline((gen, vae, mel), g, dev, lanes=4)
+    for src, label in ((g, "inputs resident in HBM"), (host, "inputs in pinned host memory (H2D inside the timed region)")):
+        n = 60
+        for out in pipe.run(src for _ in range(8)):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for out in pipe.run(src for _ in range(n)):
+            pass
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"ClipPipeline.run, {label}: {dt * 1e3:.3f} ms/step, {64 / dt:.0f} clips/s")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "both"
     prec = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
@@ -72,3 +97,5 @@ if __name__ == "__main__":
         long_clips(prec)
     if what in ("draws", "both"):
         draws(prec)
+    if what == "h2d":
+        host_inputs(prec)
