@@ -171,3 +171,12 @@ def test_install_aliases_resolve_reference_import_lines():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_pipeline_argument_validation_without_gpu():
+    """ClipPipeline refuses a CPU device / bad lane counts before touching any engine (there is no CPU fallback)."""
+    from emotiongestures_amd.pipeline import ClipPipeline
+    with pytest.raises(ValueError):
+        ClipPipeline((None, None, None), {}, "cuda:0", lanes=0)
+    with pytest.raises(RuntimeError):
+        ClipPipeline((None, None, None), {}, "cpu", lanes=2)
