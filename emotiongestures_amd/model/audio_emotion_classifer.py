@@ -44,8 +44,9 @@ class EmotionNet(nn.Module):
         feat = self.emotion_encoder.forward_nhwc(mfcc.contiguous())            # [B,16,16,256]
         B = feat.shape[0]
         lin0 = self.emotion_eocder_fc[0]
-        x = ops.linear(feat.reshape(B, -1), lin0.weight, lin0.bias, relu=True, precision=self.precision,
-                       packed=self._first_fc_packed(feat.device))
+        # 65536-deep product at M = B rows: split K over 8 workgroup slices (64 column tiles x 8 = 512 workgroups), fixed-order reduce
+        x = ops.linear_splitk(feat.reshape(B, -1), lin0.weight, lin0.bias, relu=True, splits=8, precision=self.precision,
+                              packed=self._first_fc_packed(feat.device))
         # ReLU follows each of the five hidden layers (:25-35) and not last_fc (:37,46): one chain, ReLU between its layers
         rest = [self.emotion_eocder_fc[i] for i in (2, 4, 6, 8)] + [self.last_fc]
         return _affine_chain(self._cache, x, rest, True, self.precision)

@@ -176,17 +176,30 @@ class SEBasicBlock(nn.Module):
         self.stride = stride if isinstance(stride, int) else stride[0]
         self.precision = _DEFAULT_PRECISION
 
+    def _packed(self, device):
+        """Packed conv weights / folded BatchNorm vectors, rebuilt only when a parameter or buffer changes."""
+        ver = (str(device),) + tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, "_pack", None) is None or self._pack[0] != ver:
+            s1, t1 = self.bn1.affine()
+            s2, t2 = self.bn2.affine()
+            c1 = ops.conv3x3_pack(self.conv1.weight, None, s1, t1, device)
+            c2 = ops.conv3x3_pack(self.conv2.weight, None, s2, t2, device)
+            ds = None
+            if self.downsample is not None:
+                a, b = self.downsample[1].affine()
+                ds = (a.detach().to(device).contiguous(), b.detach().to(device).contiguous())
+            self._pack = (ver, c1, c2, ds)
+        return self._pack[1:]
+
     def forward_nhwc(self, x):
         _eval_only(self)
-        s1, t1 = self.bn1.affine()
-        s2, t2 = self.bn2.affine()
-        h = ops.conv3x3(x, self.conv1.weight, None, s1, t1, stride=self.stride, relu=True, precision=self.precision)
-        y, gap = ops.conv3x3(h, self.conv2.weight, None, s2, t2, want_gap=True, precision=self.precision)
+        c1, c2, ds = self._packed(x.device)
+        h = ops.conv3x3(x, self.conv1.weight, stride=self.stride, relu=True, precision=self.precision, packed=c1)
+        y, gap = ops.conv3x3(h, self.conv2.weight, want_gap=True, precision=self.precision, packed=c2)
         gate = ops.se_gate(gap, self.se.fc[0].weight, self.se.fc[0].bias, self.se.fc[2].weight, self.se.fc[2].bias,
                            y.shape[1] * y.shape[2])
         if self.downsample is not None:
-            ds, dt = self.downsample[1].affine()
-            return ops.se_residual_relu(y, gate, x, self.downsample[0].weight, ds, dt, stride=self.stride)
+            return ops.se_residual_relu(y, gate, x, self.downsample[0].weight, ds[0], ds[1], stride=self.stride)
         return ops.se_residual_relu(y, gate, x)
 
     def forward(self, x):

@@ -42,15 +42,18 @@ def _padvec(v: Optional[torch.Tensor], npad: int, device, fill=0.0):
 
 
 def conv3x3(x_nhwc, weight_oihw, bias=None, scale=None, shift=None, stride=1, relu=False, nchw_out=False, want_gap=False,
-            precision="f32"):
-    """Conv2d 3x3 pad 1 + fused epilogue (Full_model/ResNetBlocks.py:12,14).  x NHWC [B,H,W,Cin]."""
+            precision="f32", packed=None):
+    """Conv2d 3x3 pad 1 + fused epilogue (Full_model/ResNetBlocks.py:12,14).  x NHWC [B,H,W,Cin].
+    ``packed`` = (weight image, padded bias, padded scale, padded shift) from conv3x3_pack(): skips the per-call host packing."""
     lib = L.load()
     x = _need_cuda(x_nhwc, "x")
     dev = x.device
     B, H, W, Cin = x.shape
     Cout = weight_oihw.shape[0]
-    wp, opad = pack_conv3x3_weight(weight_oihw, dev)
-    bias_p, scale_p, shift_p = _padvec(bias, opad, dev), _padvec(scale, opad, dev), _padvec(shift, opad, dev)
+    if packed is not None:
+        wp, bias_p, scale_p, shift_p = packed
+    else:
+        wp, bias_p, scale_p, shift_p = conv3x3_pack(weight_oihw, bias, scale, shift, dev)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, Ho * Wo) if nchw_out else (B, Ho, Wo, Cout), device=dev)
     gap = None
@@ -60,6 +63,12 @@ def conv3x3(x_nhwc, weight_oihw, bias=None, scale=None, shift=None, stride=1, re
     L.check(lib.eg_conv3x3(_ptr(x), _ptr(wp), _ptr(bias_p), _ptr(scale_p), _ptr(shift_p), _ptr(y), _ptr(gap), B, H, W, Cin, Cout,
                            stride, int(relu), int(nchw_out), L.precision_code(precision), _stream(dev)), "eg_conv3x3")
     return (y, gap) if want_gap else y
+
+
+def conv3x3_pack(weight_oihw, bias, scale, shift, device):
+    """Device-resident operands of conv3x3 (weight images + channel vectors padded to the packed channel count)."""
+    wp, opad = pack_conv3x3_weight(weight_oihw, device)
+    return wp, _padvec(bias, opad, device), _padvec(scale, opad, device), _padvec(shift, opad, device)
 
 
 def stem_conv(x, weight, bias, scale, shift):
@@ -119,13 +128,13 @@ def linear(x, weight, bias=None, res1=None, res2=None, relu=False, a_shift=0, a_
     return y
 
 
-def linear_splitk(x, weight, bias=None, relu=False, splits=8, precision="f32"):
+def linear_splitk(x, weight, bias=None, relu=False, splits=8, precision="f32", packed=None):
     lib = L.load()
     x = _need_cuda(x, "x")
     dev = x.device
     M, K = x.shape
     N = weight.shape[0]
-    wp, npad, kpad = pack_linear_weight(weight, dev)
+    wp, npad, kpad = packed if packed is not None else pack_linear_weight(weight, dev)
     bias_p = _padvec(bias, npad, dev)
     y = torch.empty(M, N, device=dev)
     part = torch.empty(splits + 1, M, N, device=dev)

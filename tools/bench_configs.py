@@ -66,6 +66,18 @@ def draws(prec):
     print(f"cfg5 diversity {prec}: B={B} clips x {R} draws: {dt * 1e3:.2f} ms/step, {B / dt:.0f} clips/s, {B * R / dt:.0f} pose sequences/s")
 
 
+def emotion_net(prec):
+    """EmotionNet (audio emotion classifier) inference throughput, B=64 spectrograms [128,128]."""
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    net = EmotionNet(precision=prec).eval()
+    load_synth_weights(net, 31)
+    net.to(dev)
+    x = (torch.rand(64, 128, 128, device=dev) * -80.0)
+    with torch.no_grad():
+        dt = timeit(lambda: net(x), iters=10, warm=3)
+    print(f"EmotionNet {prec}: B=64, {dt * 1e3:.2f} ms per batch, {64 / dt:.0f} clips/s")
+
+
 def host_inputs(prec):
     """PCIe-inclusive rate of the headline workload: every batch starts in pinned host memory (audio 16 MB + small tensors),
     ClipPipeline.run copies it into a lane's buffers on the lane's stream and returns the poses to the caller's stream."""
@@ -99,3 +111,5 @@ if __name__ == "__main__":
         draws(prec)
     if what == "h2d":
         host_inputs(prec)
+    if what == "emotion":
+        emotion_net(prec)
