@@ -288,8 +288,12 @@ class MultiHeadAttention(nn.Module):
         _eval_only(self)
         if mask is not None or (k is not v and not torch.equal(k, v)):
             raise NotImplementedError("HIP MultiHeadAttention: mask=None and k is v, as on the reference path")
-        return ops.multi_head_attention(q, k, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                                        self.layer_norm.weight, self.layer_norm.bias, self.n_head, self.precision)
+        ws = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight)
+        ver = (str(q.device),) + tuple(w._version for w in ws)
+        if getattr(self, "_pack", None) is None or self._pack[0] != ver:        # packed once per weight version (standalone use)
+            self._pack = (ver, [ops.pack_linear_weight(w, q.device)[0] for w in ws])
+        return ops.multi_head_attention(q, k, *ws, self.layer_norm.weight, self.layer_norm.bias, self.n_head, self.precision,
+                                        packed=self._pack[1])
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -303,8 +307,11 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         _eval_only(self)
+        ver = (str(x.device), self.w_1.weight._version, self.w_2.weight._version)
+        if getattr(self, "_pack", None) is None or self._pack[0] != ver:
+            self._pack = (ver, (ops.pack_linear_weight(self.w_1.weight, x.device)[0], ops.pack_linear_weight(self.w_2.weight, x.device)[0]))
         return ops.positionwise_ffn(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.layer_norm.weight,
-                                    self.layer_norm.bias, self.precision)
+                                    self.layer_norm.bias, self.precision, packed=self._pack[1])
 
 
 class EncoderLayer(nn.Module):

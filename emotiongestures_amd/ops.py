@@ -168,13 +168,14 @@ def attention(q, k, v, heads: int, want_attn=False):
     return (out, attn) if want_attn else out
 
 
-def multi_head_attention(xq, xkv, wq, wk, wv, wo, ln_g, ln_b, heads: int, precision="f32", want_attn=True):
+def multi_head_attention(xq, xkv, wq, wk, wv, wo, ln_g, ln_b, heads: int, precision="f32", want_attn=True, packed=None):
+    """``packed`` = the four pack_linear_weight(...)[0] images of (wq, wk, wv, wo): skips the per-call host packing."""
     lib = L.load()
     xq, xkv = _need_cuda(xq, "q"), _need_cuda(xkv, "kv")
     dev = xq.device
     B, Lq, D = xq.shape
     Lk = xkv.shape[1]
-    packs = [pack_linear_weight(w, dev)[0] for w in (wq, wk, wv, wo)]
+    packs = packed if packed is not None else [pack_linear_weight(w, dev)[0] for w in (wq, wk, wv, wo)]
     nbytes = lib.eg_mha_workspace_bytes(B, Lq, Lk, D, heads)
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     out = torch.empty_like(xq)
@@ -185,14 +186,14 @@ def multi_head_attention(xq, xkv, wq, wk, wv, wo, ln_g, ln_b, heads: int, precis
     return out, attn
 
 
-def positionwise_ffn(x, w1, b1, w2, b2, ln_g, ln_b, precision="f32"):
+def positionwise_ffn(x, w1, b1, w2, b2, ln_g, ln_b, precision="f32", packed=None):
     lib = L.load()
     x = _need_cuda(x, "x")
     dev = x.device
     d = x.shape[-1]
     rows = x.numel() // d
     di = w1.shape[0]
-    p1, p2 = pack_linear_weight(w1, dev)[0], pack_linear_weight(w2, dev)[0]
+    p1, p2 = packed if packed is not None else (pack_linear_weight(w1, dev)[0], pack_linear_weight(w2, dev)[0])
     nbytes = lib.eg_ffn_workspace_bytes(rows, d, di)
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     out = torch.empty_like(x)
