@@ -27,9 +27,32 @@ def _fold(weight, bias, bn: BatchNorm):
     return weight * s.view(shape), bias * s + t
 
 
+def _versions(*mods):
+    return tuple(t._version for m in mods if m is not None for t in list(m.parameters()) + list(m.buffers()))
+
+
 def _dense(x, lin: Linear, bn=None):
-    w, b = (lin.weight, lin.bias) if bn is None else _fold(lin.weight, lin.bias, bn)
-    return ops.linear(x, w, b)
+    """Linear (+ folded BatchNorm1d); the folded, packed weight image is cached on the layer per parameter version."""
+    ver = (str(x.device),) + _versions(lin, bn)
+    hit = getattr(lin, "_eg_pack", None)
+    if hit is None or hit[0] != ver:
+        w, b = (lin.weight, lin.bias) if bn is None else _fold(lin.weight, lin.bias, bn)
+        hit = (ver, w.detach(), b.detach().to(x.device).contiguous(), ops.pack_linear_weight(w, x.device))
+        object.__setattr__(lin, "_eg_pack", hit)
+    return ops.linear(x, hit[1], hit[2], packed=hit[3])
+
+
+def _conv(x, conv, bn=None, weight=None, stride=1, padding=0, leaky=False):
+    """Conv1d (+ folded BatchNorm1d, + LeakyReLU 0.2); folded weights cached on the layer per parameter version.
+    ``weight`` overrides conv.weight (ConvTranspose1d expressed as a convolution)."""
+    ver = (str(x.device),) + _versions(conv, bn)
+    hit = getattr(conv, "_eg_pack", None)
+    if hit is None or hit[0] != ver:
+        w = conv.weight if weight is None else weight(conv)
+        w, b = (w, conv.bias) if bn is None else _fold(w, conv.bias, bn)
+        hit = (ver, w.detach().float().contiguous().to(x.device), b.detach().float().contiguous().to(x.device))
+        object.__setattr__(conv, "_eg_pack", hit)
+    return ops.conv1d(x, hit[1], hit[2], stride=stride, padding=padding, leaky=leaky)
 
 
 class PoseEncoderConv(nn.Module):
@@ -46,9 +69,8 @@ class PoseEncoderConv(nn.Module):
         _eval_only(self)
         x = poses.transpose(1, 2).contiguous()                      # [B, dim, seq]
         for blk in (self.net[0], self.net[1], self.net[2]):
-            w, b = _fold(blk[0].weight, blk[0].bias, blk[1])
-            x = ops.conv1d(x, w, b, stride=blk[0].stride, padding=blk[0].padding, leaky=True)
-        x = ops.conv1d(x, self.net[3].weight, self.net[3].bias)
+            x = _conv(x, blk[0], blk[1], stride=blk[0].stride, padding=blk[0].padding, leaky=True)
+        x = _conv(x, self.net[3])
         x = x.flatten(1).contiguous()
         x = _dense(x, self.out_net[0], self.out_net[1])
         x = _dense(x, self.out_net[3], self.out_net[4])
@@ -77,10 +99,9 @@ class PoseDecoderConv(nn.Module):
         x = _dense(feat.contiguous(), self.pre_net[0], self.pre_net[1])
         x = _dense(x, self.pre_net[3]).view(feat.shape[0], 4, -1).contiguous()
         for ct, bn in ((self.net[0], self.net[1]), (self.net[3], self.net[4])):
-            w, b = _fold(self._as_conv(ct), ct.bias, bn)
-            x = ops.conv1d(x, w, b, padding=2, leaky=True)
-        x = ops.conv1d(x, self.net[6].weight, self.net[6].bias)
-        x = ops.conv1d(x, self.net[7].weight, self.net[7].bias)
+            x = _conv(x, ct, bn, weight=self._as_conv, padding=2, leaky=True)
+        x = _conv(x, self.net[6])
+        x = _conv(x, self.net[7])
         return x.transpose(1, 2)
 
 
