@@ -33,14 +33,19 @@ class _PackCache:
     def __init__(self):
         self._c: Dict[int, tuple] = {}
 
-    def get(self, lin: Linear, device):
+    def get(self, lin: Linear, device, pad_k: int = 0):
+        """pad_k > 0: the weight gets that many zero columns first (K not a multiple of 4, e.g. pose_dim 126 / 282)."""
         key = id(lin)
-        ver = (lin.weight._version, str(device))
+        ver = (lin.weight._version, str(device), pad_k)
         hit = self._c.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_linear_weight(lin.weight, device))
+            w = lin.weight if not pad_k else torch.cat([lin.weight, lin.weight.new_zeros(lin.weight.shape[0], pad_k)], 1)
+            hit = (ver, ops.pack_linear_weight(w, device), w.detach())
             self._c[key] = hit
         return hit[1]
+
+    def padded_weight(self, lin: Linear):
+        return self._c[id(lin)][2]
 
 
 def _affine_chain(cache: _PackCache, x: torch.Tensor, layers, relu_between: bool, precision: str) -> torch.Tensor:
@@ -51,10 +56,11 @@ def _affine_chain(cache: _PackCache, x: torch.Tensor, layers, relu_between: bool
         if k % 4:                         # e.g. pose_dim 282/126: pad K with zero columns (layout plumbing)
             pad = (-k) % 4
             x = torch.cat([x, x.new_zeros(x.shape[0], pad)], 1)
-            w = torch.cat([lin.weight, lin.weight.new_zeros(lin.weight.shape[0], pad)], 1)
-            x = ops.linear(x, w, lin.bias, relu=relu_between and not last, precision=precision)
+            packed = cache.get(lin, x.device, pad_k=pad)
+            x = ops.linear(x, cache.padded_weight(lin), lin.bias, relu=relu_between and not last, precision=precision, packed=packed)
         elif x.shape[0] <= 64 and k >= 8192:
-            x = ops.linear_splitk(x, lin.weight, lin.bias, relu=relu_between and not last, splits=max(1, k // 512), precision=precision)
+            x = ops.linear_splitk(x, lin.weight, lin.bias, relu=relu_between and not last, splits=max(1, k // 512), precision=precision,
+                                  packed=cache.get(lin, x.device))
         else:
             x = ops.linear(x, lin.weight, lin.bias, relu=relu_between and not last, precision=precision, packed=cache.get(lin, x.device))
     return x
