@@ -68,6 +68,8 @@ class ClipPipeline:
         ln.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ln.graph):
             ln.outputs = self._step(ln)
+        ln.graph.replay()                 # capture does not execute: run once so that the lane's outputs are defined from the start
+        torch.cuda.synchronize(self.device)
 
     # ---- low level: the bench drives these directly (inputs already resident in the lanes' buffers) ----
     def launch_next(self) -> int:
