@@ -12,18 +12,22 @@ This is BASELINE.json configs[1] ("Batch=64 synthetic 16 kHz audio -> gesture in
 
 N > 1: one process per GPU, clips sharded across ranks (weak scaling: 64 clips per GPU), no collective on the data
 path (clips are independent); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
-time.  Rank 0 prints ONE JSON line.
+time.  Rank 0 prints ONE JSON line.  Started WITHOUT an outer launcher, `python bench.py --gpus N` launches itself: before
+any HIP call the parent spawns N fresh worker processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1
+rendezvous), waits for them and exits with the worst status; it refuses N greater than the visible GPU count.  This replaces
+the reference's in-process `nn.DataParallel` (test_emotion_gesture_diversity_iterative.py:137-138).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -35,7 +39,7 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}     # MI355X_MICR
 
 
 def build_models(precision, dev, seed=0):
-    from conftest import build_mirror
+    from emotiongestures_amd.builders import build_mirror
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.engine import MelFrontEnd
     from emotiongestures_amd.synth import load_synth_weights
@@ -56,27 +60,28 @@ def make_inputs(batch, seed):
 
 
 def cpu_baseline(sd_g, sd_v, inp, budget_s=20.0):
-    """The CPU oracle (port of the reference's CPU path: same torch fp32 CPU kernels) on the same workload, all host cores."""
+    """The CPU oracle (port of the reference's CPU path: same torch fp32 CPU kernels) on the SAME workload -- whole B=64
+    batches of mel + CVAE sample + generator -- on the host cores of this box, bounded to ~budget_s."""
     from oracle import emogest_oracle as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n = min(16, inp["audio"].shape[0])
+    n = inp["audio"].shape[0]
     t = {k: torch.from_numpy(v[:n]) for k, v in inp.items() if k != "audio"}
     audio = inp["audio"][:n]
 
-    def step():
+    def step(m=n):
         with torch.no_grad():
-            spec = torch.from_numpy(O.melspectrogram(audio, out_frames=124))
-            sampled = O.cvae_sample(sd_v, t["label"], t["z"])
-            return O.generator_forward(sd_g, O.GenCfg(), spec, t["text"], t["pre_pose"], sampled)[0]
+            spec = torch.from_numpy(O.melspectrogram(audio[:m], out_frames=124))
+            sampled = O.cvae_sample(sd_v, t["label"][:m], t["z"][:m])
+            return O.generator_forward(sd_g, O.GenCfg(), spec, t["text"][:m], t["pre_pose"][:m], sampled)[0]
 
-    # pick the thread count that is fastest for this workload (more threads than the small convs can use only adds
-    # synchronisation cost on many-core hosts); `cores` reports the threads actually used
+    # pick the thread count that is fastest for this workload on a 16-clip probe (more threads than the small convs can use only
+    # adds synchronisation cost on many-core hosts); `cores` reports the threads actually used
     best, cores = None, 1
     for th in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
         torch.set_num_threads(th)
-        step()
+        step(16)
         t0 = time.perf_counter()
-        step()
+        step(16)
         el = time.perf_counter() - t0
         if best is None or el < best:
             best, cores = el, th
@@ -91,20 +96,26 @@ def cpu_baseline(sd_g, sd_v, inp, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or iters >= 40:
             break
+    torch.set_num_threads(cores)
+    t1 = time.perf_counter()
+    step(1)                                   # BASELINE configs[0]: single-clip latency of the CPU path
+    lat = time.perf_counter() - t1
     return {"value": round(n * iters / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "b1_latency_ms": round(lat * 1e3, 1),
             "sample": f"{iters} x B={n} passes of oracle mel+cvae_sample+generator_forward (torch fp32 CPU, {cores} threads)"}
 
 
 def measured_traffic(tag, precision):
-    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r01_traffic.json, written by
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/*_traffic.json, written by
     tools/traffic_json.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench command).  Counters
     cannot be read inside the timed process, so this is a lookup, None when the profile does not cover the kernel / precision."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-    if precision != "bf16x3" or not os.path.exists(path):
+    pdir = os.path.join(ROOT, "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json")) if os.path.isdir(pdir) else []
+    if precision != "bf16x3" or not cands:
         return None
-    kern = json.load(open(path))["kernels"]
+    kern = json.load(open(os.path.join(pdir, cands[-1])))["kernels"]      # newest round's file
     if tag in (2, 3, 4):
-        prefix = {2: "gemm_glds_kernel<3>", 3: "gemm_presplit_kernel<3,", 4: "gemm_bf16_kernel<3>"}[tag]
+        prefix = {2: "gemm_glds_kernel<3>", 3: "gemm_presplit", 4: "gemm_bf16_kernel<3>"}[tag]
     elif tag >= 1000:
         cin, cout, s = tag // 1000000, (tag // 1000) % 1000, (tag // 100) % 10
         prefix = f"conv3x3_bf16_kernel<{cin}, {(cout + 15) // 16}, {s},"
@@ -114,7 +125,7 @@ def measured_traffic(tag, precision):
     return hits[0]["bytes"] if hits else None
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -130,19 +141,78 @@ def main():
                     help="independent steps (batches) in flight per GPU: each lane has its own workspaces, I/O buffers, hipGraph and stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32 parity-mode leg and the sustained (>= 2 s) leg")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0)
+    return ap.parse_args()
 
+
+# ---- self-launch: `python bench.py --gpus N` without an outer torchrun ------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """Parent side of `--gpus N`.  Runs BEFORE anything touches the GPU (torch.cuda.device_count() does not initialise it on
+    this image; is_available() would), never re-execs: N fresh children, one per GPU, this process only waits for them."""
+    dry = os.environ.get("EG_BENCH_DRY") == "1"          # CPU test of this launcher (tests/test_bench_launcher.py)
+    if not dry:
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            raise SystemExit(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible; refusing to oversubscribe")
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: worker ranks failed: {bad}")
+    return 0
+
+
+def dry_worker(args, rank, world):
+    """Launcher plumbing only (no GPU): rendezvous over gloo, barrier, max-over-ranks reduce, one JSON line from rank 0."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "gesture clips/sec (34 frames, 43 joints)", "dry_run": True, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "max_elapsed": float(tt.item())}))
+    return 0
+
+
+def main():
+    args = parse_args()
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched and args.gpus > 1:
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("EG_BENCH_DRY") == "1":
+        return dry_worker(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)            # (ranks > GPUs only happens in the single-GPU gloo smoke test of this launcher path)
+    backend = os.environ.get("EG_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    if local >= ndev:
+        if backend == "nccl":
+            raise SystemExit(f"bench.py: local rank {local} has no GPU ({ndev} visible): one process per GPU")
+        local = local % max(ndev, 1)        # several gloo ranks on one GPU: only the single-GPU test of this launcher path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    backend = os.environ.get("EG_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -176,79 +246,106 @@ def main():
                 return gen(spec, g["text"], g["pre_pose"], sampled)
         return step
 
-    side = torch.cuda.Stream(dev) if gen.concurrent else None
-    eager_step = make_step(gen, vae, mel, side)
-    step = eager_step
-    graph = None
-    if not args.no_graph:
-        # One lane = one captured step (all ~230 launches + the fork/join of its side streams) replayed on its own stream.
-        # Steps are independent batches, so `--in-flight` lanes (own workspaces, I/O buffers and outputs each; the models and
-        # their weights arena are shared) are replayed round-robin: the low-occupancy GEMM / attention phase of one batch
-        # overlaps the convolution phase of the next.  The timed region still covers exactly K complete steps.
-        from emotiongestures_amd.pipeline import ClipPipeline
-        pipe = ClipPipeline((gen, vae, mel), g, dev, lanes=lanes, branch_streams=gen.concurrent)
-        graph = pipe.lanes[0].graph
-
-        def step():                         # noqa: F811
-            return pipe.outputs(pipe.launch_next())
-
     def barrier():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def make_runner(gen_, lanes_):
+        """(step callable, pipeline or None) for a generator: hipGraph lanes unless --no-graph."""
+        if args.no_graph:
+            side = torch.cuda.Stream(dev) if gen_.concurrent else None
+            return make_step(gen_, vae, mel, side), None
+        # One lane = one captured step (all launches + the fork/join of its side streams) replayed on its own stream.
+        # Steps are independent batches, so `--in-flight` lanes (own workspaces, I/O buffers and outputs each; the models and
+        # their weights arena are shared) are replayed round-robin: the low-occupancy GEMM / attention phase of one batch
+        # overlaps the convolution phase of the next.  The timed region still covers exactly K complete steps.
+        from emotiongestures_amd.pipeline import ClipPipeline
+        pipe_ = ClipPipeline((gen_, vae, mel), g, dev, lanes=lanes_, branch_streams=gen_.concurrent)
+        return (lambda: pipe_.outputs(pipe_.launch_next())), pipe_
+
+    def timed(step_, steps, warmup):
+        for _ in range(warmup):
+            o = step_()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = step_()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, o
+
+    step, pipe = make_runner(gen, lanes)
+    elapsed, out = timed(step, args.steps, args.warmup)
     total_clips = B * world * args.steps
     value = total_clips / elapsed
 
     timed_concurrent = bool(gen.concurrent)
     # every lane ran the same resident batch: their outputs must agree bit for bit (catches any cross-lane interference)
     lanes_equal = None
-    if graph is not None and lanes > 1:
+    if pipe is not None and lanes > 1:
         base = pipe.outputs(0)
         lanes_equal = all(torch.equal(a, b) for i in range(1, lanes) for a, b in zip(pipe.outputs(i), base))
         if not lanes_equal:
             raise SystemExit("bench.py: lanes disagree on the same batch -- results depend on concurrent work (invalid run)")
-    # ---- parity spot check on this very batch (first 2 clips) against the CPU oracle ----
+
+    # ---- sustained leg: the same step loop for >= 2 s of wall clock, so that clocks / thermals under load are represented ----
+    sustained = None
+    if not args.no_extra_legs:
+        chunk = max(args.steps, 20)
+        done, el_tot = 0, 0.0
+        while el_tot < args.sustain_seconds and done < 200 * chunk:
+            el, _ = timed(step, chunk, 0)
+            el_tot += el
+            done += chunk
+        sustained = {"steps": done, "seconds": round(el_tot, 3), "value": round(B * world * done / el_tot, 2),
+                     "ms_per_step": round(el_tot / done * 1e3, 4)}
+
+    # ---- parity of the WHOLE timed batch against the CPU oracle (rank 0), and the "FGD vs ref" half of the metric ----
     parity = None
+    fgd = None
     roof = None
     cpu = None
+    f32 = None
+    pose_ref = None
     if rank == 0:
-        from conftest import clip_rel_l2
+        from emotiongestures_amd.builders import clip_rel_l2
         from oracle import emogest_oracle as O
         with torch.no_grad():
-            t2 = {k: torch.from_numpy(v[:2]) for k, v in inp.items() if k != "audio"}
-            spec_ref = torch.from_numpy(O.melspectrogram(inp["audio"][:2], out_frames=124))
-            s_ref = O.cvae_sample(sd_v, t2["label"], t2["z"])
-            pose_ref = O.generator_forward(sd_g, O.GenCfg(), spec_ref, t2["text"], t2["pre_pose"], s_ref)[0]
-        parity = clip_rel_l2(out[0][:2].cpu().numpy(), pose_ref.numpy())
-    fgd = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and B >= 32:
-        # "FGD vs ref" half of the metric: Frechet distance between the FGD auto-encoder latents (model/FGD.py:26-82, HIP path,
-        # synthetic weights) of the GPU poses and of the CPU oracle's poses for the same 32 clips (34 x 32 = 1088 feature rows)
+            tn = {k: torch.from_numpy(v) for k, v in inp.items() if k != "audio"}
+            spec_ref = torch.from_numpy(O.melspectrogram(inp["audio"], out_frames=124))
+            s_ref = O.cvae_sample(sd_v, tn["label"], tn["z"])
+            pose_ref = O.generator_forward(sd_g, O.GenCfg(), spec_ref, tn["text"], tn["pre_pose"], s_ref)[0]
+        parity = clip_rel_l2(out[0].cpu().numpy(), pose_ref.numpy())          # max over all B clips of the timed batch
+    if rank == 0 and B >= 32:
+        # Frechet distance between the FGD auto-encoder latents (model/FGD.py:26-82, HIP path, synthetic weights) of the GPU
+        # poses and of the CPU oracle's poses for the same B clips (B x 34 feature rows)
         from emotiongestures_amd.harness import MLP_Reconstruct, calculate_frechet_distance
         from emotiongestures_amd.synth import load_synth_weights
         with torch.no_grad():
-            n = 32
-            tn = {k: torch.from_numpy(v[:n]) for k, v in inp.items() if k != "audio"}
-            spec_n = torch.from_numpy(O.melspectrogram(inp["audio"][:n], out_frames=124))
-            pose_cpu = O.generator_forward(sd_g, O.GenCfg(), spec_n, tn["text"], tn["pre_pose"], O.cvae_sample(sd_v, tn["label"], tn["z"]))[0]
             ae = load_synth_weights(MLP_Reconstruct(pose_dim=126), 5).eval().to(dev)
-            fa = ae(out[0][:n].contiguous())[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
-            fb = ae(pose_cpu.to(dev))[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
+            fa = ae(out[0].contiguous())[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
+            fb = ae(pose_ref.to(dev))[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
         fgd = float(np.real(calculate_frechet_distance(fa.mean(0), np.cov(fa, rowvar=False), fb.mean(0), np.cov(fb, rowvar=False))))
+
+    # ---- f32 parity-mode leg (SURVEY.md §8d cfg 2: perf mode AND fp32 parity mode timed in the same run) ----
+    if not args.no_extra_legs and args.precision != "f32":
+        gen32 = build_models("f32", dev)[0]
+        gen32.concurrent = False
+        step32, pipe32 = make_runner(gen32, lanes)
+        el32, out32 = timed(step32, args.steps, max(2, args.warmup // 2))
+        if rank == 0:
+            f32 = {"value": round(total_clips / el32, 2), "ms_per_step": round(el32 / args.steps * 1e3, 4), "dtype": "f32",
+                   "pose_rel_l2_vs_cpu_oracle": clip_rel_l2(out32[0].cpu().numpy(), pose_ref.numpy()),
+                   "mfma_peak_tflops": PEAK_TFLOPS["f32"],
+                   "frac_of_f32_mfma_peak": round(total_clips / el32 * FLOP_PER_CLIP / 1e12 / PEAK_TFLOPS["f32"] / world, 4)}
+        del step32, pipe32, gen32
+        torch.cuda.empty_cache()
 
     # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
     if rank == 0 and not args.no_roofline:
@@ -263,24 +360,25 @@ def main():
         lib.eg_profile_disable()
         tags = np.zeros(cap, np.int64); fl = np.zeros(cap, np.float64); ms = np.zeros(cap, np.float32)
         n = lib.eg_profile_read(tags.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), cap)
+        if n < 0:
+            _lib.check(n, "eg_profile_read")
         tags, fl, ms = tags[:n], fl[:n], ms[:n]
         groups = {}
         for tg in np.unique(tags):
             sel = tags == tg
             groups[int(tg)] = (float(ms[sel].sum()), float(ms[sel].mean()), float(fl[sel].mean()), int(sel.sum()))
-        dom = max(groups, key=lambda k: groups[k][0])
+        contraction = {k: v for k, v in groups.items() if v[2] > 0}             # tags with FLOPs: GEMM / conv / attention
+        dom = max(contraction, key=lambda k: contraction[k][0])
         tot_ms, avg_ms, flop, cnt = groups[dom]
-        gemm_names = {2: "gemm_glds_kernel (fp32 X via LDS-DMA)", 3: "gemm_presplit_kernel (pre-split X)", 4: "gemm_bf16_kernel (causal shift)",
-                      5: "gemm_kernel (f32 MFMA)"}
-        name = gemm_names[dom] if dom in gemm_names else f"conv3x3<cin={dom // 1000000},cout={(dom // 1000) % 1000},stride={(dom // 100) % 10}>"
         achieved = flop / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         traffic = measured_traffic(dom, args.precision)
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": kernel_name(dom), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                 "launches_per_step": cnt // max(args.steps, 1), "kernel_ms_per_step_isolated": round(tot_ms / args.steps, 4),
                 "flop_per_launch": flop,
-                "by_kernel_ms_per_step": {str(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())}}
+                "by_kernel_ms_per_step": {kernel_name(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())},
+                "by_kernel_tflops": {kernel_name(k): round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in sorted(contraction.items())}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_g, sd_v, inp)
 
@@ -295,13 +393,27 @@ def main():
             "config": {"workload": "TED clips: 4 s 16 kHz audio -> mel(128x124) -> CVAE sample -> generator -> 34x126 pose",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "variant": "Models_spatial_memory",
                        "parallelism": f"clip-sharded x{world}, no data-path collective",
-                       "launch": "eager" if graph is None else f"hipGraph replay, {lanes} step(s) in flight",
-                       "branch_streams": timed_concurrent,
+                       "launch": "eager" if pipe is None else f"hipGraph replay, {lanes} step(s) in flight",
+                       "branch_streams": timed_concurrent, "fold_affine": bool(getattr(gen, "fold_affine", False)),
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
-            "pose_rel_l2_vs_cpu_oracle": parity, "fgd_vs_cpu_oracle": fgd, "lanes_bitwise_equal": lanes_equal, "roofline": roof, "cpu_baseline": cpu,
+            "pose_rel_l2_vs_cpu_oracle": parity, "parity_clips_checked": B, "fgd_vs_cpu_oracle": fgd,
+            "lanes_bitwise_equal": lanes_equal, "sustained": sustained, "f32": f32, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    return 0
+
+
+GEMM_NAMES = {2: "gemm_glds_kernel (fp32 X via LDS-DMA)", 3: "gemm_presplit_kernel (pre-split X)", 4: "gemm_bf16_kernel (causal shift)",
+              5: "gemm_kernel (f32 MFMA)", 6: "attention_mfma_kernel"}
+
+
+def kernel_name(tag):
+    if tag in GEMM_NAMES:
+        return GEMM_NAMES[tag]
+    if tag >= 1000:
+        return f"conv3x3<cin={tag // 1000000},cout={(tag // 1000) % 1000},stride={(tag // 100) % 10}>"
+    return f"tag{tag}"
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -31,6 +31,19 @@ static inline int eg_check_launch(const char* what) {
     return EG_OK;
 }
 
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is per device, so it is tracked per (kernel, device) under a
+// mutex (generator.hip); the HIP status is checked and surfaced as EG_ERR_HIP.  Called from launch functions: cheap after the
+// first call, and the first call happens in the host's warm-up pass, outside any stream capture.
+int eg_ensure_dynamic_lds(const void* kernel, size_t bytes, const char* who);
+#define EG_HIP_TRY(expr, what)                                                         \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            eg_set_error("%s: %s", (what), hipGetErrorString(_e));                     \
+            return EG_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
 static inline bool eg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int64_t eg_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int eg_cdiv(int a, int b) { return (a + b - 1) / b; }

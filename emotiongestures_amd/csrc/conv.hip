@@ -578,14 +578,7 @@ int launch_conv_bf16(const ConvArgs& a, const bf8* whi, const bf8* wlo, dim3 gri
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + RING * NIMG * 4 * NT * 16);
     auto kern = conv3x3_bf16_kernel<CIN, NT, S, TH, WM, WN, TERMS, RING>;
-    static bool attr_done = false;
-    if (!attr_done && LDS_BYTES > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
-            eg_set_error("conv3x3: cannot reserve %zu B of LDS", LDS_BYTES);
-            return EG_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3")) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, whi, wlo);
     return eg_check_launch("conv3x3");
 }
@@ -705,15 +698,7 @@ extern "C" int eg_se_residual_relu(const float* y, const float* gate, const floa
         hipLaunchKernelGGL((se_tail_downsample_kernel<64, 128>), dim3(blocks), dim3(256), 64 * 128 * 4, st, y, gate, x_in, ds_w, ds_scale,
                            ds_shift, out, batch, ho, wo, h_in, w_in, stride);
     else if (cin == 128 && c == 256) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(se_tail_downsample_kernel<128, 256>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4) != hipSuccess) {
-                eg_set_error("eg_se_residual_relu: cannot reserve 128 KiB of LDS");
-                return EG_ERR_HIP;
-            }
-            attr_done = true;
-        }
+        if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(se_tail_downsample_kernel<128, 256>), 128 * 256 * 4, "eg_se_residual_relu")) return rc;
         hipLaunchKernelGGL((se_tail_downsample_kernel<128, 256>), dim3(blocks < 1024 ? blocks : 1024), dim3(256), 128 * 256 * 4, st, y, gate,
                            x_in, ds_w, ds_scale, ds_shift, out, batch, ho, wo, h_in, w_in, stride);
     } else {

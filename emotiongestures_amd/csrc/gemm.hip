@@ -573,14 +573,7 @@ int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, 
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr size_t LDS_BYTES = (size_t)RING * 2 * NIMG * (BK / 32) * 4 * 64 * 16;
     auto kern = gemm_presplit_kernel<TERMS, BK, RING>;
-    static bool attr_done = false;
-    if (!attr_done && LDS_BYTES > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
-            eg_set_error("gemm_presplit: cannot reserve %zu B of LDS", LDS_BYTES);
-            return EG_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_presplit")) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, xhi, xlo, xko);
     return eg_check_launch("gemm_presplit");
 }
@@ -687,14 +680,7 @@ int launch_presplit128(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xk
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr size_t LDS_BYTES = (size_t)3 * 2 * NIMG * 8 * 64 * 16;
     auto kern = gemm_presplit128_kernel<TERMS>;
-    static bool attr_done = false;
-    if (!attr_done && LDS_BYTES > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
-            eg_set_error("gemm_presplit128: cannot reserve %zu B of LDS", LDS_BYTES);
-            return EG_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_presplit128")) return rc;
     dim3 grid(eg_cdiv(m_tiles, 2), eg_cdiv(n_tiles, 2), 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, st, a, xhi, xlo, xko, m_tiles, n_tiles);
     return eg_check_launch("gemm_presplit128");

@@ -9,6 +9,7 @@
 #include <vector>
 #include <string.h>
 #include <map>
+#include <mutex>
 
 // ---- error plumbing ----------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -28,9 +29,29 @@ extern "C" int eg_set_default_precision(int p) {
 }
 extern "C" int eg_get_default_precision(void) { return g_default_precision; }
 
+// ---- per-device kernel attributes -----------------------------------------------------------------------------------
+int eg_ensure_dynamic_lds(const void* kernel, size_t bytes, const char* who) {
+    if (bytes <= 64 * 1024) return EG_OK;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;         // (kernel, device) -> largest size granted so far
+    int dev = 0;
+    EG_HIP_TRY(hipGetDevice(&dev), who);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[std::make_pair(kernel, dev)];
+    if (have >= bytes) return EG_OK;
+    if (bytes > 160 * 1024) { eg_set_error("%s: needs %zu B of LDS (160 KiB per CU)", who, bytes); return EG_ERR_UNSUPPORTED; }
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        eg_set_error("%s: cannot reserve %zu B of LDS on device %d: %s", who, bytes, dev, hipGetErrorString(e));
+        return EG_ERR_HIP;
+    }
+    have = bytes;
+    return EG_OK;
+}
+
 // ---- launch profiler ---------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; int64_t tag; double flops; };
+struct ProfRec { hipEvent_t a, b; int64_t tag; double flops; bool ok; };
 std::vector<ProfRec> g_prof;
 int g_prof_n = 0;
 bool g_prof_on = false;
@@ -40,17 +61,17 @@ EgProfScope::EgProfScope(int64_t tag, double flops, hipStream_t s) : slot(-1), s
     slot = g_prof_n++;
     g_prof[slot].tag = tag;
     g_prof[slot].flops = flops;
-    (void)hipEventRecord(g_prof[slot].a, st);
+    g_prof[slot].ok = hipEventRecord(g_prof[slot].a, st) == hipSuccess;
 }
 EgProfScope::~EgProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+    if (slot >= 0 && hipEventRecord(g_prof[slot].b, st) != hipSuccess) g_prof[slot].ok = false;
 }
 extern "C" int eg_profile_enable(int32_t max_records) {
     EG_REQUIRE(max_records > 0, EG_ERR_BAD_ARG, "eg_profile_enable: max_records=%d", max_records);
     while ((int)g_prof.size() < max_records) {
         ProfRec r;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { eg_set_error("hipEventCreate failed"); return EG_ERR_HIP; }
-        r.tag = 0; r.flops = 0;
+        r.tag = 0; r.flops = 0; r.ok = false;
         g_prof.push_back(r);
     }
     g_prof_n = 0;
@@ -61,9 +82,12 @@ extern "C" int eg_profile_disable(void) { g_prof_on = false; return EG_OK; }
 extern "C" int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacity) {
     int n = g_prof_n < capacity ? g_prof_n : capacity;
     for (int i = 0; i < n; ++i) {
-        (void)hipEventSynchronize(g_prof[i].b);
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+        if (!g_prof[i].ok || hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) {
+            eg_set_error("eg_profile_read: event %d was not recorded / cannot be read", i);
+            g_prof_n = 0;
+            return EG_ERR_HIP;          // negative: no records
+        }
         tags[i] = g_prof[i].tag; flops[i] = g_prof[i].flops; ms[i] = t;
     }
     g_prof_n = 0;
@@ -270,7 +294,17 @@ GenWs carve(const EgGenerator* g, int B, int NB = 0) {
     const int64_t BF = (int64_t)B * c.frames, D = c.d_model, NF = (int64_t)NB * c.frames;
     const int64_t act = (int64_t)B * g->H1 * g->W1 * 32;
     for (int i = 0; i < 3; ++i) w.act[i] = cv.take(act);
-    w.gap = cv.take((int64_t)B * 64 * 128 * 4);
+    {   // SE average-pool partials: conv2 of a block writes tiles * C_out floats per clip -- size for the largest block
+        int64_t gap_per_clip = 0;
+        int h = g->H1, wd = g->W1;
+        for (const BlockW& b : g->blocks) {
+            const int ho = (h + 2 - 3) / b.stride + 1, wo = (wd + 2 - 3) / b.stride + 1;
+            const int64_t need = (int64_t)eg_conv3x3_gap_tiles(ho, wo, b.cout, b.cout, 1) * b.cout;
+            gap_per_clip = need > gap_per_clip ? need : gap_per_clip;
+            h = ho; wd = wo;
+        }
+        w.gap = cv.take((int64_t)B * gap_per_clip);
+    }
     w.gate = cv.take((int64_t)B * 128);
     w.amap = cv.take(BF * g->HW3);
     w.afc1 = cv.take(BF * D); w.afeat = cv.take(BF * D);
@@ -383,7 +417,8 @@ int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec,
     float *gap = P(ws, w.gap), *gate = P(ws, w.gate);
     EG_TRY(eg_stem_conv(spec, arena + g->stem_w, arena + g->stem_b, arena + g->stem_scale, arena + g->stem_shift, bufs[0], B, g->H1,
                         g->W1, 32, st));
-    if (g->keep_taps) hipMemcpyAsync(P(ws, w.tap_stem), bufs[0], sizeof(float) * (size_t)B * g->H1 * g->W1 * 32, hipMemcpyDeviceToDevice, st);
+    if (g->keep_taps)
+        EG_HIP_TRY(hipMemcpyAsync(P(ws, w.tap_stem), bufs[0], sizeof(float) * (size_t)B * g->H1 * g->W1 * 32, hipMemcpyDeviceToDevice, st), "tap copy");
     int xi = 0, h = g->H1, wd = g->W1, bi = 0;
     for (int s = 0; s < 3; ++s) {
         for (int j = 0; j < g->stages[s]; ++j, ++bi) {
@@ -400,7 +435,7 @@ int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec,
             xi = t1; h = ho; wd = wo;
         }
         if (g->keep_taps)
-            hipMemcpyAsync(P(ws, w.tap_l[s]), bufs[xi], sizeof(float) * (size_t)B * h * wd * g->filters[s], hipMemcpyDeviceToDevice, st);
+            EG_HIP_TRY(hipMemcpyAsync(P(ws, w.tap_l[s]), bufs[xi], sizeof(float) * (size_t)B * h * wd * g->filters[s], hipMemcpyDeviceToDevice, st), "tap copy");
     }
     float* amap = P(ws, w.amap);
     EG_TRY(run_conv(arena, g->final_conv, bufs[xi], amap, nullptr, B, h, wd, 0, 1, prec, st));
@@ -668,15 +703,15 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
     if (g->concurrent) {
         EG_TRY(g->ensure_streams());
         s_text = g->side[0]; s_prior = g->side[1];
-        (void)hipEventRecord(g->ev_fork, st);
-        (void)hipStreamWaitEvent(s_text, g->ev_fork, 0);
-        (void)hipStreamWaitEvent(s_prior, g->ev_fork, 0);
+        EG_HIP_TRY(hipEventRecord(g->ev_fork, st), "branch fork");
+        EG_HIP_TRY(hipStreamWaitEvent(s_text, g->ev_fork, 0), "branch fork");
+        EG_HIP_TRY(hipStreamWaitEvent(s_prior, g->ev_fork, 0), "branch fork");
     }
     EG_TRY(run_text(g, arena, text, txt, w, ws, B, s_text));
     EG_TRY(run_prior(g, arena, prior, w, ws, B, s_prior));
     if (g->concurrent) {
-        (void)hipEventRecord(g->ev_join[0], s_text);
-        (void)hipEventRecord(g->ev_join[1], s_prior);
+        EG_HIP_TRY(hipEventRecord(g->ev_join[0], s_text), "branch join");
+        EG_HIP_TRY(hipEventRecord(g->ev_join[1], s_prior), "branch join");
     }
     EG_TRY(run_audio_tower(g, arena, spec, w, ws, B, st));
     const float* feat = P(ws, w.afeat);
@@ -700,8 +735,8 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
     EG_TRY(egi_add(sampled ? sampled : emo, sem, P(ws, w.fus_in), (size_t)rows * D, D, 0, st));
     float* pose_out = pose ? pose : P(ws, w.pose);
     if (g->concurrent) {        // join: the decoder needs the prior encoding; the caller's stream must also cover the text branch
-        (void)hipStreamWaitEvent(st, g->ev_join[1], 0);
-        (void)hipStreamWaitEvent(st, g->ev_join[0], 0);
+        EG_HIP_TRY(hipStreamWaitEvent(st, g->ev_join[1], 0), "branch join");
+        EG_HIP_TRY(hipStreamWaitEvent(st, g->ev_join[0], 0), "branch join");
     }
     return run_transformer(g, arena, P(ws, w.fus_in), act(P(ws, w.prior_enc), D, P(ws, w.im_p[1]), D), pose_out, w, ws, B, st);
 }

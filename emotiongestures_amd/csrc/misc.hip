@@ -512,13 +512,7 @@ int egi_attention(const float* q, int ldq, const float* k, int ldk, const float*
     EG_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, EG_ERR_ALIGN, "eg_attention: row strides must be multiples of 4");
     const size_t smem = sizeof(float) * ((size_t)ATT_QC * ATT_P + 2 * (size_t)lk * ATT_P + (size_t)ATT_QC * ((lk + 3) & ~3));
     dim3 grid(eg_cdiv(lq, ATT_QC), heads, batch);
-    if (smem > 64 * 1024) {
-        static bool once = false;
-        if (!once) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            once = true;
-        }
-    }
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel), smem, "eg_attention")) return rc;
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, st, q, ldq, k, ldk, v, ldv, out, ldo, attn, heads, lq, lk,
                        1.0f / sqrtf((float)dk), reinterpret_cast<unsigned short*>(oimg), batch * lq);
     return eg_check_launch("attention");
@@ -592,11 +586,7 @@ int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float*
     a.stage_w = (base + wbytes <= 160 * 1024) ? 1 : 0;          // conv weights in LDS when they fit, else read through L1
     const size_t smem = base + (a.stage_w ? wbytes : 0);
     if (smem > 160 * 1024) { eg_set_error("prior encoder: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
-    static bool once = false;
-    if (!once) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(prior_pred_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(prior_pred_kernel), smem, "prior encoder")) return rc;
     hipLaunchKernelGGL(prior_pred_kernel, dim3(batch, eg_cdiv(D, dc)), dim3(256), smem, st, a);
     int rc = eg_check_launch("prior_pred");
     if (rc || variant != 1) return rc;
@@ -613,14 +603,10 @@ int egi_conv1d(const float* x, const float* w, const float* bias, const float* s
     const int cog = per_wave <= 4 ? 4 : (per_wave <= 8 ? 8 : 16);
     const size_t smem = sizeof(float) * ((((size_t)cin * (63 * stride + k) + 3) & ~(size_t)3) + (size_t)cin * k * 4 * cog);
     if (smem > 160 * 1024) { eg_set_error("conv1d: LDS need %zu B", smem); return EG_ERR_UNSUPPORTED; }
-    if (smem > 64 * 1024) {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            once = true;
-        }
+    {
+        const void* kp = cog == 4 ? reinterpret_cast<const void*>(conv1d_kernel<4>)
+                                  : (cog == 8 ? reinterpret_cast<const void*>(conv1d_kernel<8>) : reinterpret_cast<const void*>(conv1d_kernel<16>));
+        if (int rc = eg_ensure_dynamic_lds(kp, smem, "conv1d")) return rc;
     }
     dim3 grid(eg_cdiv(lout, 64), n, eg_cdiv(cout, 4 * cog));
     if (cog == 4)

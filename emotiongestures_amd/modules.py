@@ -569,7 +569,8 @@ class Transformer(nn.Module):
 
     # ---- engine management: repack the arena only when weights / device / mode changed ----
     def _weights_version(self):
-        return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+        # (_version, data_ptr): `param.data = new_tensor` keeps or collides version counters but moves the storage
+        return tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers()))
 
     def engine(self) -> GeneratorEngine:
         dev = next(self.parameters()).device
@@ -623,7 +624,7 @@ class MLP_Reconstruct_v3(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise L.EgError("emotiongestures_amd MLP_Reconstruct_v3 runs only on a GPU; there is no CPU fallback")
-        key = (str(dev), tuple(t._version for t in list(self.parameters()) + list(self.buffers())))
+        key = (str(dev), tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers())))
         if self._engine is None or self._engine_key != key:
             if self._engine is None:
                 self._engine = CvaeEngine(self._frames, self._d_model)

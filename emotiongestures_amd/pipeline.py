@@ -18,7 +18,7 @@ import torch
 
 
 class _Lane:
-    __slots__ = ("slot", "stream", "graph", "inputs", "outputs", "done", "busy")
+    __slots__ = ("slot", "stream", "graph", "inputs", "outputs", "done", "busy", "collected", "keep", "key")
 
 
 class ClipPipeline:
@@ -45,6 +45,7 @@ class ClipPipeline:
             ln.stream = torch.cuda.Stream(self.device)
             ln.inputs = {k: v.to(self.device).clone() for k, v in example_inputs.items()}
             ln.done = torch.cuda.Event()
+            ln.collected = None
             ln.busy = False
             self._capture(ln)
             self.lanes.append(ln)
@@ -56,6 +57,12 @@ class ClipPipeline:
             spec = self.mel(g["audio"], out_frames=self.gen.engine().cfg.spec_len, slot=ln.slot) if self.mel is not None else g["spec"]
             sampled = self.vae.sample(g["label"], z=g["z"], slot=ln.slot) if self.vae is not None else g.get("sampled")
             return self.gen(spec, g["text"], g["pre_pose"], sampled, slot=ln.slot)
+
+    def _engine_state(self):
+        """What a captured graph has baked in as raw pointers: the engines, their weight arenas and this lane's workspaces."""
+        eng = self.gen.engine()
+        veng = self.vae.engine() if self.vae is not None else None
+        return eng, eng.arena, veng, (veng.arena if veng is not None else None)
 
     def _capture(self, ln: _Lane) -> None:
         cap = torch.cuda.Stream(self.device)
@@ -70,6 +77,25 @@ class ClipPipeline:
             ln.outputs = self._step(ln)
         ln.graph.replay()                 # capture does not execute: run once so that the lane's outputs are defined from the start
         torch.cuda.synchronize(self.device)
+        # The graph replays raw pointers into the engines' arenas and this lane's workspaces.  Keep those objects alive for as
+        # long as the graph exists (a later repack / precision change builds NEW engines and arenas; the old ones must not be
+        # freed under a graph that may still be replayed), and remember their identity so that a stale graph is detected.
+        st = self._engine_state()
+        ln.key = tuple(id(o) for o in st)
+        ln.keep = st + (dict(st[0]._ws), dict(st[2]._ws) if st[2] is not None else None,
+                        dict(self.mel._ws) if self.mel is not None else None)
+
+    def stale(self) -> bool:
+        """True when the models' engines / weight arenas are no longer the ones the lanes were captured with
+        (weights reloaded, precision / keep_taps / concurrent changed)."""
+        key = tuple(id(o) for o in self._engine_state())
+        return any(ln.key != key for ln in self.lanes)
+
+    def refresh(self) -> None:
+        """Re-capture every lane against the models' current engines (after a weight update or a mode change)."""
+        torch.cuda.synchronize(self.device)
+        for ln in self.lanes:
+            self._capture(ln)
 
     # ---- low level: the bench drives these directly (inputs already resident in the lanes' buffers) ----
     def launch_next(self) -> int:
@@ -77,7 +103,14 @@ class ClipPipeline:
         i = self._next
         self._next = (self._next + 1) % len(self.lanes)
         ln = self.lanes[i]
+        eng = self.gen._engine
+        if eng is None or id(eng) != ln.key[0] or id(eng.arena) != ln.key[1]:
+            raise RuntimeError("ClipPipeline: the generator's engine / weight arena changed after capture (weights reloaded or "
+                               "precision / keep_taps / concurrent flipped); call refresh() before launching")
         with torch.cuda.stream(ln.stream):
+            if ln.collected is not None:      # a caller-stream copy of this lane's previous outputs must finish before they are overwritten
+                ln.stream.wait_event(ln.collected)
+                ln.collected = None
             ln.graph.replay()
             ln.done.record(ln.stream)
         ln.busy = True
@@ -95,6 +128,8 @@ class ClipPipeline:
     def run(self, batches: Iterable[dict]) -> Iterator[Tuple[torch.Tensor, ...]]:
         """Every batch is a dict with the keys of `example_inputs` (same shapes).  Yields a copy of each step's 5-tuple in order;
         up to `lanes` batches are in flight."""
+        if self.stale():                  # full check (parameter versions) once per call; launch_next() re-checks identity cheaply
+            self.refresh()
         pending: List[int] = []
         for b in batches:
             if len(pending) == len(self.lanes):
@@ -108,16 +143,21 @@ class ClipPipeline:
                     if tuple(src.shape) != tuple(buf.shape):
                         raise ValueError(f"ClipPipeline.run: {k} has shape {tuple(src.shape)}, the lanes were captured for {tuple(buf.shape)}")
                     buf.copy_(src, non_blocking=True)
+                    if src.is_cuda:           # the caller may drop `src` right away: its block must not be reused before this copy ran
+                        src.record_stream(ln.stream)
             pending.append(self.launch_next())
         while pending:
             yield self._collect(pending.pop(0))
 
     def _collect(self, lane: int):
-        # copy on the lane's own stream: ordered after its step and before its next replay; the caller's stream then waits
+        # The copies are allocated and run on the CALLER's stream (so the caching allocator orders their reuse with the caller's
+        # later work) after that stream has waited for the lane's step; the lane's next replay waits for the copies (`collected`).
         ln = self.lanes[lane]
-        with torch.cuda.stream(ln.stream):
-            out = tuple(None if t is None else t.clone() for t in ln.outputs)
-        torch.cuda.current_stream(self.device).wait_stream(ln.stream)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ln.done)
+        out = tuple(None if t is None else t.clone() for t in ln.outputs)
+        ln.collected = torch.cuda.Event()
+        ln.collected.record(cur)
         ln.busy = False
         return out
 

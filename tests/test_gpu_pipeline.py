@@ -88,3 +88,83 @@ def test_results_do_not_depend_on_concurrent_work():
         torch.cuda.synchronize()
         for a, r in zip(out, ref):
             assert torch.equal(a, r)
+
+
+def test_pipeline_streams_from_a_generator_without_host_syncs():
+    """Batches come from a generator that drops every tensor right after yielding it, the consumer keeps only the pose and
+    never synchronises the host in between: the allocator may then hand a dropped batch's block to the next batch while the
+    lane's copy is still queued (record_stream / caller-stream clones).  Results must still match eager forwards."""
+    from emotiongestures_amd.pipeline import ClipPipeline
+    dev = torch.device("cuda:0")
+    B, n_batches = 4, 24
+    host = []
+    for i in range(n_batches):
+        inp = synth_inputs(B, 34, 126, 4, seed=500 + i)
+        inp["audio"] = synth_audio(B, 64000, seed=500 + i)
+        host.append({k: torch.from_numpy(inp[k]).pin_memory() for k in ("audio", "text", "pre_pose", "label", "z")})
+    pipe = ClipPipeline(_models(dev), {k: v.to(dev) for k, v in host[0].items()}, dev, lanes=3)
+
+    def produce():
+        for h in host:
+            yield {k: v.to(dev, non_blocking=True) for k, v in h.items()}      # dropped by the consumer loop immediately
+
+    acc = torch.zeros(B, 34, 126, device=dev)
+    poses = []
+    for out in pipe.run(produce()):
+        acc += out[0]                          # caller-stream work on the returned copies, no host sync
+        poses.append(out[0])
+    torch.cuda.synchronize()
+    gen, vae, mel = _models(dev)
+    want = torch.zeros_like(acc)
+    for i, h in enumerate(host):
+        b = {k: v.to(dev) for k, v in h.items()}
+        with torch.no_grad():
+            ref = gen(mel(b["audio"], out_frames=124), b["text"], b["pre_pose"], vae.sample(b["label"], z=b["z"]))[0]
+        assert torch.equal(poses[i], ref), f"batch {i}"
+        want += ref
+    assert torch.equal(acc, want)
+
+
+def test_pipeline_detects_a_stale_graph():
+    """Captured graphs bake in pointers to the weight arena; after a weight update the low-level path must refuse to replay
+    and run() must re-capture."""
+    from emotiongestures_amd.pipeline import ClipPipeline
+    dev = torch.device("cuda:0")
+    gen, vae, mel = _models(dev)
+    b = _batch(2, 900, dev)
+    pipe = ClipPipeline((gen, vae, mel), b, dev, lanes=2)
+    first = [t.clone() for t in next(iter(pipe.run([b])))]
+    with torch.no_grad():
+        gen.post_projector[6].bias.add_(0.25)          # bumps the parameter version -> new arena on the next engine() call
+    assert pipe.stale()
+    with pytest.raises(RuntimeError):
+        pipe.launch_next()
+    second = next(iter(pipe.run([b])))                 # re-captures
+    torch.cuda.synchronize()
+    assert torch.allclose(second[0], first[0] + 0.25, atol=1e-5)
+
+
+def test_headline_batch_b64_matches_oracle():
+    """BASELINE configs[1] at full size: B=64 TED clips from raw audio through ClipPipeline (mel -> CVAE sample -> generator,
+    bf16x3, 2 lanes) against the CPU oracle on every clip.  Tolerance: per-clip relative L2 <= 1e-3 (north-star)."""
+    from emotiongestures_amd.builders import clip_rel_l2
+    from emotiongestures_amd.pipeline import ClipPipeline
+    from oracle import emogest_oracle as O
+    dev = torch.device("cuda:0")
+    B = 64
+    inp = synth_inputs(B, 34, 126, 4, seed=1000)
+    inp["audio"] = synth_audio(B, 64000, seed=1000)
+    gen, vae, mel = _models(dev)
+    sd_g = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+    sd_v = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
+    b = {k: torch.from_numpy(inp[k]).to(dev) for k in ("audio", "text", "pre_pose", "label", "z")}
+    pipe = ClipPipeline((gen, vae, mel), b, dev, lanes=2)
+    outs = list(pipe.run([b, b]))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    t = {k: torch.from_numpy(v) for k, v in inp.items() if k != "audio"}
+    with torch.no_grad():
+        spec = torch.from_numpy(O.melspectrogram(inp["audio"], out_frames=124))
+        ref = O.generator_forward(sd_g, O.GenCfg(), spec, t["text"], t["pre_pose"], O.cvae_sample(sd_v, t["label"], t["z"]))
+    assert clip_rel_l2(outs[0][0].cpu().numpy(), ref[0].numpy()) < 1e-3
+    assert float(np.abs(outs[0][3].cpu().numpy() - ref[3].numpy()).max()) < 1e-3          # emotion logits

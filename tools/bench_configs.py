@@ -9,10 +9,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 
-from conftest import build_mirror, make_args, make_lang
+from emotiongestures_amd.builders import build_mirror, make_args, make_lang
 from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
 from emotiongestures_amd.engine import MelFrontEnd
 from emotiongestures_amd.synth import load_synth_weights, synth_audio, synth_inputs

@@ -13,11 +13,10 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import torch
 
-from conftest import build_mirror
+from emotiongestures_amd.builders import build_mirror
 from emotiongestures_amd import datapath as D
 from emotiongestures_amd import harness as H
 from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
