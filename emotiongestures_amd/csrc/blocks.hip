@@ -36,7 +36,7 @@ extern "C" int eg_multi_head_attention(const float* xq, const float* xkv, const 
     EG_TRY(eg_linear(xq, D, wq, dpad, nullptr, nullptr, nullptr, 0, q, I, rq, I, D, 0, 0, 0, precision, stream));
     EG_TRY(eg_linear(xkv, D, wk, dpad, nullptr, nullptr, nullptr, 0, k, I, rk, I, D, 0, 0, 0, precision, stream));
     EG_TRY(eg_linear(xkv, D, wv, dpad, nullptr, nullptr, nullptr, 0, v, I, rk, I, D, 0, 0, 0, precision, stream));
-    EG_TRY(eg_attention(q, I, k, I, v, I, ao, I, attn, batch, heads, lq, lk, 64, stream));
+    EG_TRY(eg_attention(q, I, k, I, v, I, ao, I, attn, batch, heads, lq, lk, 64, precision, stream));
     EG_TRY(eg_linear(ao, I, wo, ipad, nullptr, xq, nullptr, D, pr, D, rq, D, I, 0, 0, 0, precision, stream));
     return eg_layernorm(pr, ln_g, ln_b, out, rq, D, 1e-6f, stream);
 }

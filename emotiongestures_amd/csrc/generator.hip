@@ -106,7 +106,7 @@ int egi_copy2d(const float* src, int lds_, float* dst, int ldd, int rows, int co
 int egi_linear(const EgiLinear& p, hipStream_t st);
 int egi_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* img, int rows, int d, float eps, hipStream_t st);
 int egi_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, float* attn,
-                  void* oimg, int batch, int heads, int lq, int lk, int dk, hipStream_t st);
+                  void* oimg, int batch, int heads, int lq, int lk, int dk, int precision, hipStream_t st);
 int egi_add_bcast(const float* a, const float* b, float* out, size_t rows, int row_len, int period, int rep, hipStream_t st);
 int egi_prior_encoder(const float* prior, const EgiPriorW& w, float* cat, float* tm_mem, float* tm_pe, float* tm_gram, int batch,
                       int P, int F, int D, int Dpad, int chunk, int variant, hipStream_t st);
@@ -387,12 +387,12 @@ int run_mha(const EgGenerator* g, const float* arena, const MhaW& m, const Act& 
     void* aimg = g->cfg.precision != EG_PREC_F32 ? P(ws, w.im_h) : nullptr;       // attention output images (the FFN hidden slot is free here)
     if (!xkv.f) {
         EG_TRY(lin(g, arena, m.qkv, xq, 0, act(qkv, 3 * D), true, B * Lq, 0, nullptr, 0, st));
-        EG_TRY(egi_attention(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, ao, D, nullptr, aimg, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
+        EG_TRY(egi_attention(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, ao, D, nullptr, aimg, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, g->cfg.precision, st));
     } else {
         float* q = P(ws, w.q);
         EG_TRY(lin(g, arena, m.q, xq, 0, act(q, D), true, B * Lq, 0, nullptr, 0, st));
         EG_TRY(lin(g, arena, m.kv, xkv, 0, act(qkv, 2 * D), true, B * Lk, 0, nullptr, 0, st));
-        EG_TRY(egi_attention(q, D, qkv, 2 * D, qkv + D, 2 * D, ao, D, nullptr, aimg, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, st));
+        EG_TRY(egi_attention(q, D, qkv, 2 * D, qkv + D, 2 * D, ao, D, nullptr, aimg, B, g->cfg.n_head, Lq, Lk, g->cfg.d_k, g->cfg.precision, st));
     }
     EG_TRY(lin(g, arena, m.o, act(ao, D, aimg, D), 0, act(pr, D), true, B * Lq, 0, xq.f, D, st));
     return egi_layernorm(pr, arena + m.ln_g, arena + m.ln_b, out.f, g->cfg.precision != EG_PREC_F32 ? out.img : nullptr, B * Lq, D, 1e-6f, st);

@@ -1,4 +1,4 @@
-// Small kernels of the generator: LayerNorm, single-tile attention, embedding gather, row-periodic add,
+// Small kernels of the generator: LayerNorm, embedding gather, row-periodic add,
 // TCN time-axis Linear, prior/memory encoder, CVAE conv1d / convT1d, reparameterise.
 #include "common.h"
 
@@ -51,93 +51,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 *reinterpret_cast<u32x2*>(img + slot) = (u32x2){hh[0], hh[1]};
                 *reinterpret_cast<u32x2*>(img + lo_off + slot) = (u32x2){ll[0], ll[1]};
             }
-        }
-    }
-}
-
-// ---- attention (Full_model/Modules.py:13-23), one workgroup per (q-chunk, head, clip) --------------------
-// Q (pre-scaled by 1/sqrt(dk), as the reference divides q first), K, V rows live in LDS with a 68-float row pitch
-// (272 B = 17 slots: 16 consecutive rows read with ds_read_b128 hit 16 different slots); every thread works on float4s:
-// scores: 4 FMAs per pair of b128 reads; PV: one b128 of V per broadcast probability.
-constexpr int ATT_QC = 64;      // query rows per workgroup (34- and 60-frame sequences fit one workgroup per head)
-constexpr int ATT_P = 68;       // row pitch in floats
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                                                        const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
-                                                        float* __restrict__ attn, int H, int Lq, int Lk, float inv_temp,
-                                                        unsigned short* __restrict__ oimg, int rows_total) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int qc = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const int q0 = qc * ATT_QC, nq = min(ATT_QC, Lq - q0);
-    float* Qs = sm;                         // [ATT_QC][68]
-    float* Ks = Qs + ATT_QC * ATT_P;        // [Lk][68]
-    float* Vs = Ks + Lk * ATT_P;            // [Lk][68]
-    float* Ss = Vs + Lk * ATT_P;            // [ATT_QC][LkP]
-    const int LkP = (Lk + 3) & ~3;
-    for (int i = tid; i < nq * 16; i += 256) {
-        const int r = i >> 4, c = (i & 15) * 4;
-        const f4 t = *reinterpret_cast<const f4*>(q + ((size_t)b * Lq + q0 + r) * ldq + h * 64 + c);
-        *reinterpret_cast<f4*>(Qs + r * ATT_P + c) = t * inv_temp;       // q / temperature first (Modules.py:15)
-    }
-    for (int i = tid; i < Lk * 16; i += 256) {
-        const int r = i >> 4, c = (i & 15) * 4;
-        *reinterpret_cast<f4*>(Ks + r * ATT_P + c) = *reinterpret_cast<const f4*>(k + ((size_t)b * Lk + r) * ldk + h * 64 + c);
-        *reinterpret_cast<f4*>(Vs + r * ATT_P + c) = *reinterpret_cast<const f4*>(v + ((size_t)b * Lk + r) * ldv + h * 64 + c);
-    }
-    __syncthreads();
-    for (int i = tid; i < nq * Lk; i += 256) {
-        const int r = i / Lk, c = i - r * Lk;
-        const f4* qp = reinterpret_cast<const f4*>(Qs + r * ATT_P);
-        const f4* kp = reinterpret_cast<const f4*>(Ks + c * ATT_P);
-        f4 s4 = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int d = 0; d < 16; ++d) s4 += qp[d] * kp[d];
-        Ss[r * LkP + c] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int r = wave; r < nq; r += 4) {
-        float m = -3.0e38f;
-        for (int c = lane; c < Lk; c += 64) m = fmaxf(m, Ss[r * LkP + c]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane; c < Lk; c += 64) {
-            const float e = expf(Ss[r * LkP + c] - m);
-            Ss[r * LkP + c] = e;
-            s += e;
-        }
-        const float inv = 1.0f / wave_sum(s);
-        for (int c = lane; c < Lk; c += 64) {
-            const float p = Ss[r * LkP + c] * inv;
-            Ss[r * LkP + c] = p;
-            if (attn) attn[(((size_t)b * H + h) * Lq + q0 + r) * Lk + c] = p;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < nq * 16; i += 256) {
-        const int r = i >> 4, d4 = i & 15;
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-        for (int c = 0; c < Lk; ++c) {
-            const f4 vv = *reinterpret_cast<const f4*>(Vs + c * ATT_P + d4 * 4);
-            const float p = Ss[r * LkP + c];
-            // scalar FMAs on purpose (inline asm keeps hipcc from re-forming v_pk_fma_f32): see DESIGN.md "co-residency"
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o0) : "v"(vv[0]), "v"(p));
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o1) : "v"(vv[1]), "v"(p));
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o2) : "v"(vv[2]), "v"(p));
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(o3) : "v"(vv[3]), "v"(p));
-        }
-        const f4 o = (f4){o0, o1, o2, o3};
-        *reinterpret_cast<f4*>(out + ((size_t)b * Lq + q0 + r) * ldo + h * 64 + d4 * 4) = o;
-        if (oimg) {         // also emit the head-concatenated row as bf16 (hi, lo) tile-planar images for the output projection
-            const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
-            bf8 h8, l8;
-            split_octet<true>(o, z, h8, l8);
-            const int row = b * Lq + q0 + r, k = h * 64 + d4 * 4, KO = H * 8;
-            const size_t slot = (((size_t)(row >> 6) * KO + (k >> 3)) * 64 + (row & 63)) * 8 + (k & 7);
-            const size_t lo_off = (size_t)((rows_total + 63) >> 6) * KO * 512;
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            const u32x4_t hh = __builtin_bit_cast(u32x4_t, h8), ll = __builtin_bit_cast(u32x4_t, l8);
-            *reinterpret_cast<u32x2*>(oimg + slot) = (u32x2){hh[0], hh[1]};
-            *reinterpret_cast<u32x2*>(oimg + lo_off + slot) = (u32x2){ll[0], ll[1]};
         }
     }
 }
@@ -504,24 +417,6 @@ extern "C" int eg_layernorm(const float* x, const float* gamma, const float* bet
     return egi_layernorm(x, gamma, beta, y, nullptr, rows, d, eps, (hipStream_t)stream);
 }
 
-int egi_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, float* attn,
-                  void* oimg, int batch, int heads, int lq, int lk, int dk, hipStream_t st) {
-    EG_REQUIRE(q && k && v && out && batch > 0 && heads > 0 && lq > 0 && lk > 0, EG_ERR_BAD_ARG, "eg_attention: null pointer or empty shape");
-    EG_REQUIRE(dk == 64, EG_ERR_UNSUPPORTED, "eg_attention: d_k=%d (64 supported)", dk);
-    EG_REQUIRE(lk <= 256, EG_ERR_UNSUPPORTED, "eg_attention: Lk=%d > 256", lk);
-    EG_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, EG_ERR_ALIGN, "eg_attention: row strides must be multiples of 4");
-    const size_t smem = sizeof(float) * ((size_t)ATT_QC * ATT_P + 2 * (size_t)lk * ATT_P + (size_t)ATT_QC * ((lk + 3) & ~3));
-    dim3 grid(eg_cdiv(lq, ATT_QC), heads, batch);
-    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel), smem, "eg_attention")) return rc;
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, st, q, ldq, k, ldk, v, ldv, out, ldo, attn, heads, lq, lk,
-                       1.0f / sqrtf((float)dk), reinterpret_cast<unsigned short*>(oimg), batch * lq);
-    return eg_check_launch("attention");
-}
-extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
-                            float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
-                            int32_t dk, void* stream) {
-    return egi_attention(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, dk, (hipStream_t)stream);
-}
 
 extern "C" int eg_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream) {
     EG_REQUIRE(mu && logvar && eps && z && n > 0, EG_ERR_BAD_ARG, "eg_reparameterize: null pointer");

@@ -154,8 +154,8 @@ def layernorm(x, gamma, beta, eps=1e-6):
     return y
 
 
-def attention(q, k, v, heads: int, want_attn=False):
-    """q [B,Lq,H*64], k/v [B,Lk,H*64] -> out [B,Lq,H*64] (Full_model/Modules.py:13-23)."""
+def attention(q, k, v, heads: int, want_attn=False, precision="f32"):
+    """q [B,Lq,H*64], k/v [B,Lk,H*64] -> out [B,Lq,H*64] (Full_model/Modules.py:13-23); both products on MFMA in `precision`."""
     lib = L.load()
     q, k, v = _need_cuda(q, "q"), _need_cuda(k, "k"), _need_cuda(v, "v")
     dev = q.device
@@ -164,7 +164,7 @@ def attention(q, k, v, heads: int, want_attn=False):
     out = torch.empty_like(q)
     attn = torch.empty(B, heads, Lq, Lk, device=dev) if want_attn else None
     L.check(lib.eg_attention(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk, D // heads,
-                             _stream(dev)), "eg_attention")
+                             L.precision_code(precision), _stream(dev)), "eg_attention")
     return (out, attn) if want_attn else out
 
 

@@ -272,10 +272,11 @@ int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y
 /* ScaledDotProductAttention (Full_model/Modules.py:13-23) for all heads, mask=None, eval mode:
  * out[b,i,h*dv:(h+1)*dv] = softmax_j((q[b,i,h]/sqrt(dk)) . k[b,j,h]) v[b,j,h].
  * q [B,Lq,H*dk] (row stride ldq), k/v [B,Lk,H*dk] (ldk/ldv), out [B,Lq,H*dk] (ldo).  dk == 64.
- * attn (optional) [B,H,Lq,Lk] receives the probabilities (the reference returns them). */
+ * attn (optional) [B,H,Lq,Lk] receives the probabilities (the reference returns them).
+ * Both products run on MFMA in the arithmetic mode `precision` (EG_PREC_*); pointers 16-byte aligned, Lk <= 256. */
 int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
                  float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
-                 int32_t dk, void* stream);
+                 int32_t dk, int32_t precision, void* stream);
 
 /* MultiHeadAttention.forward (Full_model/SubLayers.py:30-59): LN(fc(attn(q Wq, k Wk, v Wv)) + q).
  * xq [B*Lq, D], xkv [B*Lk, D]; wq/wk/wv packed nn.Linear [heads*64, D], wo packed [D, heads*64] (d_k = d_v = 64; D need not

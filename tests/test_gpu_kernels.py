@@ -139,18 +139,22 @@ def test_layernorm(rows, d):
     assert rel_l2(y.numpy(), F.layer_norm(x, (d,), g, b, 1e-6).numpy()) < 2e-6
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 8, 34, 34), (1, 8, 60, 60), (2, 2, 120, 120), (3, 8, 34, 60), (1, 1, 1, 1)])
-def test_attention(B, H, Lq, Lk):
-    """ScaledDotProductAttention (Full_model/Modules.py:13-23), ragged Lq != Lk and the 1x1 edge case."""
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 8, 34, 34), (1, 8, 60, 60), (2, 2, 120, 120), (3, 8, 34, 60), (1, 1, 1, 1), (1, 2, 70, 200), (2, 1, 17, 49)])
+def test_attention(B, H, Lq, Lk, prec, tol):
+    """ScaledDotProductAttention (Full_model/Modules.py:13-23) on MFMA in every arithmetic mode: ragged Lq != Lk, the 1x1 edge
+    case, more than one 64-row query chunk, every key-tile instantiation (Lk <= 48 / 64 / 128 / 256)."""
     from emotiongestures_amd import ops
     D = H * 64
     q, k, v = T("q", (B, Lq, D), -2, 2), T("k", (B, Lk, D), -2, 2), T("v", (B, Lk, D))
     split = lambda t, L: t.view(B, L, H, 64).transpose(1, 2)
     attn = torch.softmax(torch.matmul(split(q, Lq) / 8.0, split(k, Lk).transpose(2, 3)), dim=-1)
     ref = torch.matmul(attn, split(v, Lk)).transpose(1, 2).reshape(B, Lq, D)
-    out, a = ops.attention(q.to(dev()), k.to(dev()), v.to(dev()), H, want_attn=True)
-    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 3e-6
-    assert rel_l2(a.cpu().numpy(), attn.numpy()) < 3e-6
+    out, a = ops.attention(q.to(dev()), k.to(dev()), v.to(dev()), H, want_attn=True, precision=prec)
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < tol
+    assert rel_l2(a.cpu().numpy(), attn.numpy()) < tol
+    out2 = ops.attention(q.to(dev()), k.to(dev()), v.to(dev()), H, precision=prec)         # without the probability output
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
