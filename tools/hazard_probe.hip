@@ -7,6 +7,10 @@
 //   mode 1  float4 FMAs, unrolled x8, but a full s_waitcnt lgkmcnt(0) in front of the first FMA    (packed ops, no partial waits)
 //   mode 2  scalar v_fmac_f32 (inline asm), unrolled x8: progressive lgkmcnt(N), no packed op      (partial waits, no packed ops)
 //   mode 3  scalar v_fmac_f32, not unrolled, lgkmcnt(0) per iteration                               (the round-1 fix)
+//   mode 4  inline-asm v_pk_fma_f32 WITHOUT op_sel (the probability duplicated into a register pair), lgkmcnt(0) first
+//   mode 5  inline-asm v_pk_fma_f32 WITH op_sel / op_sel_hi broadcast out of a pair, lgkmcnt(0) + s_nop 4 first
+//   mode 6  inline-asm v_pk_mul_f32 (op_sel_hi broadcast) + v_pk_add_f32, lgkmcnt(0) first
+// Aggressors: the library's 128->128 convolution (MFMA + LDS-DMA + LDS), plain LDS traffic, MFMA only (no memory), LDS-DMA only.
 // Each mode is launched alone (quiet reference), then repeatedly while the aggressor -- the library's 128->128 MFMA convolution
 // (LDS-DMA weight ring, 74 KB LDS, raw s_barrier) -- runs on a second stream; every output word is compared with the quiet run.
 //
@@ -21,6 +25,8 @@
 #include "emogest.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef short bf8 __attribute__((ext_vector_type(8)));
 constexpr int P = 68;           // LDS row pitch in floats (round-1 kernel)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
@@ -76,6 +82,43 @@ __global__ __launch_bounds__(256) void pv_kernel(const float* __restrict__ v, co
                 }
             }
             o = (f4){o0, o1, o2, o3};
+        } else if (MODE >= 4) {
+            f2 oa = (f2){0.f, 0.f}, ob = (f2){0.f, 0.f};
+            for (int c = 0; c < LkP; c += 8) {
+                f4 vv[8];
+                const f4 p0 = *reinterpret_cast<const f4*>(pp + c), p1 = *reinterpret_cast<const f4*>(pp + c + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = *reinterpret_cast<const f4*>(vp + (c + j) * P);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f2 va = (f2){vv[j][0], vv[j][1]}, vb = (f2){vv[j][2], vv[j][3]};
+                    const float pj = j < 4 ? p0[j & 3] : p1[j & 3];
+                    if (MODE == 4) {
+                        const f2 pd = (f2){pj, pj};
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(oa) : "v"(va), "v"(pd));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ob) : "v"(vb), "v"(pd));
+                    } else if (MODE == 5) {
+                        // pair (p_j, p_j+1) as the LDS read delivered it; even j: both halves take the low word, odd j: the high word
+                        const f2 pr = (j < 4) ? ((j & 2) ? (f2){p0[2], p0[3]} : (f2){p0[0], p0[1]}) : ((j & 2) ? (f2){p1[2], p1[3]} : (f2){p1[0], p1[1]});
+                        if (j & 1) {
+                            asm volatile("s_nop 4\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(oa) : "v"(va), "v"(pr));
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ob) : "v"(vb), "v"(pr));
+                        } else {
+                            asm volatile("s_nop 4\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(oa) : "v"(va), "v"(pr));
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ob) : "v"(vb), "v"(pr));
+                        }
+                    } else {
+                        const f2 pd = (f2){pj, pj};
+                        f2 ta, tb;
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ta) : "v"(va), "v"(pd));
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(tb) : "v"(vb), "v"(pd));
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(oa) : "v"(ta));
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ob) : "v"(tb));
+                    }
+                }
+            }
+            o = (f4){oa[0], oa[1], ob[0], ob[1]};
         } else {
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 1
@@ -106,6 +149,32 @@ __global__ __launch_bounds__(256) void lds_noise_kernel(float* sink, int iters) 
         buf[(tid + it * 256) & 4095] = acc;
     }
     if (acc[0] == 123.456f) sink[0] = acc[1];
+}
+
+// MFMA only: no LDS, no memory traffic inside the loop
+__global__ __launch_bounds__(256) void mfma_noise_kernel(float* sink, int iters) {
+    f4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    bf8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (short)(0x3C00 + threadIdx.x + j); b[j] = (short)(0x3D00 + j); }
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.456f) sink[0] = 1.f;
+}
+// LDS-DMA only (global_load_lds into a 64 KB LDS array), no MFMA
+__global__ __launch_bounds__(256) void ldsdma_noise_kernel(const float* src, float* sink, int iters) {
+    __shared__ f4 buf[4096];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const f4*>(src) + ((it * 8 + p) & 1023) * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(buf + (wave * 8 + p) * 64), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (buf[threadIdx.x][0] == 123.456f) sink[0] = 1.f;
 }
 
 typedef void (*PvKern)(const float*, const float*, float*, int, int);
@@ -142,10 +211,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&sink, 64));
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    PvKern kerns[4] = {pv_kernel<0>, pv_kernel<1>, pv_kernel<2>, pv_kernel<3>};
+    PvKern kerns[7] = {pv_kernel<0>, pv_kernel<1>, pv_kernel<2>, pv_kernel<3>, pv_kernel<4>, pv_kernel<5>, pv_kernel<6>};
     std::vector<float> href(obytes / 4), hout(obytes / 4);
-    for (int aggr = 0; aggr < 2; ++aggr) {
-        for (int mode = 0; mode < 4; ++mode) {
+    const char* anames[4] = {"conv128_mfma_ldsdma", "plain_lds_traffic", "mfma_only", "ldsdma_only"};
+    for (int aggr = 0; aggr < 4; ++aggr) {
+        for (int mode = 0; mode < 7; ++mode) {
             hipLaunchKernelGGL(kerns[mode], dim3(nblk), dim3(256), smem, sa, dv, dp, dref, Lq, Lk);
             CK(hipStreamSynchronize(sa));
             CK(hipMemcpy(href.data(), dref, obytes, hipMemcpyDeviceToHost));
@@ -158,8 +228,12 @@ int main(int argc, char** argv) {
                             fprintf(stderr, "conv: %s\n", eg_last_error());
                             return 2;
                         }
-                    } else {
+                    } else if (aggr == 1) {
                         hipLaunchKernelGGL(lds_noise_kernel, dim3(512), dim3(256), 0, sb, sink, 200);
+                    } else if (aggr == 2) {
+                        hipLaunchKernelGGL(mfma_noise_kernel, dim3(512), dim3(256), 0, sb, sink, 2000);
+                    } else {
+                        hipLaunchKernelGGL(ldsdma_noise_kernel, dim3(512), dim3(256), 0, sb, cx, sink, 200);
                     }
                 }
                 for (int i = 0; i < 40; ++i)
@@ -174,7 +248,7 @@ int main(int argc, char** argv) {
                     ++total;
                 }
             }
-            printf("aggressor=%s mode=%d: %d/%d launches differ from the quiet run (%ld words)\n", aggr == 0 ? "conv128_mfma_ldsdma" : "plain_lds_traffic",
+            printf("aggressor=%s mode=%d: %d/%d launches differ from the quiet run (%ld words)\n", anames[aggr],
                    mode, bad, total, words_bad);
             fflush(stdout);
         }

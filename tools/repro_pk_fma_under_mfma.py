@@ -39,7 +39,7 @@ qkv = torch.randn(B_ * Lq, 1536, device=dev)
 
 def att():
     o = torch.empty(B_ * Lq, 512, device=dev)
-    lib.eg_attention(_ptr(qkv), 1536, _ptr(qkv[:, 512:]), 1536, _ptr(qkv[:, 1024:]), 1536, _ptr(o), 512, None, B_, 8, Lq, Lq, 64, _stream(dev))
+    lib.eg_attention(_ptr(qkv), 1536, _ptr(qkv[:, 512:]), 1536, _ptr(qkv[:, 1024:]), 1536, _ptr(o), 512, None, B_, 8, Lq, Lq, 64, L.precision_code("bf16x3"), _stream(dev))
     return o
 
 
