@@ -98,6 +98,26 @@ SIGNATURES = {
     "eg_conv1d": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_contrastive_workspace_bytes": (C.c_int64, [_I]),
     "eg_contrastive_loss": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _L, _P]),
+    # ---- training-path primitives (csrc/train.hip)
+    "eg_transpose": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
+    "eg_gemm_tn_workspace_floats": (_L, [_I, _I, _L]),
+    "eg_gemm_tn": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _L, _P, _L, _I, _P]),
+    "eg_im2col3x3": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_subsample": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_im2col1d": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_colreduce_workspace_floats": (_L, [_I]),
+    "eg_bn_train_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
+    "eg_bn_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "eg_colsum": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P]),
+    "eg_elementwise": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, _P]),
+    "eg_seg_mean": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, _P]),
+    "eg_seg_dot": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "eg_se_scale": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "eg_layernorm_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
+    "eg_attention_backward": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_smooth_l1": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, _P, _P]),
+    "eg_cross_entropy": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, _P, _P, _I, _I, _P, _P]),
+    "eg_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
 }
 
 _lib = None

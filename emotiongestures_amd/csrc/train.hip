@@ -1,0 +1,715 @@
+// Training-path primitives (fp32, deterministic: fixed-order two-level reductions, no atomics).
+//
+// The reference trains with autograd over ATen (train_audio_classifier_K_fold.py:155-175 is its one loop; the generator's
+// training script is not in the repo).  These are the backward-side kernels the forward library lacks:
+//   * TN GEMM  C[m,n] = sum_k A[k,m] B[k,n]  on v_mfma_f32_16x16x4_f32 (weight gradients: dW = dY^T X, conv wgrad over im2col rows),
+//   * transpose (dX = dY W runs on the forward NT GEMM with W^T), im2col / col2im for 3x3 NHWC and for 1-D channels-last convs,
+//   * BatchNorm with batch statistics (forward, running-stat update, backward), LayerNorm backward, attention backward,
+//   * SE pooling / gating forward+backward pieces, ReLU / LeakyReLU / sigmoid masks, losses (smooth-L1, cross-entropy / focal),
+//   * fused Adam with torch.optim.Adam's exact update order (L2 weight decay folded into the gradient).
+// Every entry is a plain C-ABI launcher on caller-owned memory; the host sequences them (emotiongestures_amd/train/).
+#include "common.h"
+
+namespace {
+
+constexpr int TB = 256;
+inline dim3 grid1(size_t n, int cap = 8192) { const size_t b = (n + TB - 1) / TB; return dim3((unsigned)(b < (size_t)cap ? (b ? b : 1) : cap)); }
+
+// ---- transpose: y[c][r] = x[r][c] ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int ldx, int rows, int cols, float* __restrict__ y, int ldy) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        t[j][tx] = (r < rows && c < cols) ? x[(size_t)r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) y[(size_t)c * ldy + r] = t[tx][j];
+    }
+}
+
+// ---- TN GEMM on fp32 MFMA: C[m,n] (+)= sum_k A[k,m] B[k,n];  workgroup tile 64 x 64, K-step 32, split-K over blockIdx.z ----
+// LDS images [32 k][80] (pitch 80 floats: the two 16-lane halves of a ds_read_b32 hit disjoint bank halves).
+// Operands are swapped (MFMA A = B-tile rows, MFMA B = A-tile rows) so that a lane owns 4 consecutive n of one m.
+constexpr int TN_P = 80;
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      float* __restrict__ c, int ldc, int M, int N, long K, long k_per_split,
+                                                      float* __restrict__ partial) {
+    __shared__ float As[32 * TN_P], Bs[32 * TN_P];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const long kbeg = (long)blockIdx.z * k_per_split, kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    f4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = (f4){0.f, 0.f, 0.f, 0.f};
+    const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    for (long k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();
+        // stage 32 rows x 64 columns of each operand: thread -> (row = i / 16, column quad = i % 16), two passes
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = tid + p * 256, r = i >> 4, cq = (i & 15) * 4;
+            const long k = k0 + r;
+            f4 va = (f4){0.f, 0.f, 0.f, 0.f}, vb = va;
+            if (k < kend) {
+                const float* ap = a + (size_t)k * lda + m0 + cq;
+                const float* bp = b + (size_t)k * ldb + n0 + cq;
+                if (a_vec && m0 + cq + 3 < M) va = *reinterpret_cast<const f4*>(ap);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (m0 + cq + j < M) va[j] = ap[j];
+                if (b_vec && n0 + cq + 3 < N) vb = *reinterpret_cast<const f4*>(bp);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n0 + cq + j < N) vb[j] = bp[j];
+            }
+            *reinterpret_cast<f4*>(As + r * TN_P + cq) = va;
+            *reinterpret_cast<f4*>(Bs + r * TN_P + cq) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = As[(kk * 4 + g) * TN_P + wm + t * 16 + li];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bv[u] = Bs[(kk * 4 + g) * TN_P + wn + u * 16 + li];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[u], av[t], acc[t][u], 0, 0, 0);
+        }
+    }
+    // D[row = n index (4g + r)][col = m index (li)]: lane owns C[m = li][n = 4g .. 4g+3]
+    float* out = partial ? partial + (size_t)blockIdx.z * M * N : c;
+    const int ldo = partial ? N : ldc;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + wm + t * 16 + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn + u * 16 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < N) out[(size_t)m * ldo + n + r] = acc[t][u][r];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ c, int ldc, int M, int N,
+                                                        int splits, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * M * N + i];
+    float* o = c + (size_t)m * ldc + n;
+    *o = accumulate ? *o + s : s;
+}
+
+// ---- im2col / col2im, 3x3 pad 1, NHWC: col[p][tap*C + c] = x[b, oy*s + kh - 1, ox*s + kw - 1, c] -------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int C,
+                                                        int Ho, int Wo, int S) {
+    const size_t total = (size_t)B * Ho * Wo * 9 * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho), b = (int)(r / Ho);
+        const int iy = oy * S + tap / 3 - 1, ix = ox * S + tap % 3 - 1;
+        col[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * H + iy) * W + ix) * C + c] : 0.f;
+    }
+}
+// gather form of the transpose: dx[b,y,x,c] = sum over taps of dcol[(b,oy,ox)][tap*C + c] with oy*s + kh - 1 == y, ox*s + kw - 1 == x
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ col, float* __restrict__ dx, int B, int H, int W, int C,
+                                                        int Ho, int Wo, int S) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int xx = (int)(r % W);
+        r /= W;
+        const int yy = (int)(r % H), b = (int)(r / H);
+        float s = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ty = yy + 1 - kh;
+            if (ty < 0 || ty % S) continue;
+            const int oy = ty / S;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tx = xx + 1 - kw;
+                if (tx < 0 || tx % S) continue;
+                const int ox = tx / S;
+                if (ox >= Wo) continue;
+                s += col[(((size_t)b * Ho + oy) * Wo + ox) * 9 * C + (kh * 3 + kw) * C + c];
+            }
+        }
+        dx[i] = s;
+    }
+}
+// strided pixel subsample (1x1 stride-s conv input) and its transpose
+__global__ __launch_bounds__(256) void subsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int Ho,
+                                                        int Wo, int S, int backward) {
+    const size_t total = backward ? (size_t)B * H * W * C : (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        if (!backward) {
+            const int ox = (int)(r % Wo);
+            r /= Wo;
+            const int oy = (int)(r % Ho), b = (int)(r / Ho);
+            y[i] = x[(((size_t)b * H + oy * S) * W + ox * S) * C + c];
+        } else {            // x = dy [B,Ho,Wo,C], y = dx [B,H,W,C]
+            const int xx = (int)(r % W);
+            r /= W;
+            const int yy = (int)(r % H), b = (int)(r / H);
+            const bool hit = (yy % S == 0) && (xx % S == 0) && (yy / S < Ho) && (xx / S < Wo);
+            y[i] = hit ? x[(((size_t)b * Ho + yy / S) * Wo + xx / S) * C + c] : 0.f;
+        }
+    }
+}
+// 1-D channels-last: x [B, L, C] -> col [B*Lout, k*C], position l*stride + j*dil - pad_left
+__global__ __launch_bounds__(256) void im2col1d_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int L, int C, int Lout,
+                                                       int k, int stride, int pad_left, int dil) {
+    const size_t total = (size_t)B * Lout * k * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int j = (int)(r % k);
+        r /= k;
+        const int lo = (int)(r % Lout), b = (int)(r / Lout);
+        const int l = lo * stride + j * dil - pad_left;
+        col[i] = (l >= 0 && l < L) ? x[((size_t)b * L + l) * C + c] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__ col, float* __restrict__ dx, int B, int L, int C, int Lout,
+                                                       int k, int stride, int pad_left, int dil) {
+    const size_t total = (size_t)B * L * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int l = (int)(r % L), b = (int)(r / L);
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int t = l + pad_left - j * dil;
+            if (t < 0 || t % stride) continue;
+            const int lo = t / stride;
+            if (lo >= Lout) continue;
+            s += col[(((size_t)b * Lout + lo) * k + j) * C + c];
+        }
+        dx[i] = s;
+    }
+}
+
+// ---- column reductions over rows: two deterministic levels ---------------------------------------------------------------
+// level 1: block (bx, by) sums rows [by*rows_per, ...) of 64 columns -> part[by][2][C]; mode 0: (sum x, sum x*x); mode 1: (sum a, sum a*b)
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                          long rows, int C, long rows_per, int mode) {
+    __shared__ float s0[4][64], s1[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per, r1 = (r0 + rows_per < rows) ? r0 + rows_per : rows;
+    float u = 0.f, v = 0.f;
+    if (c < C)
+        for (long r = r0 + w; r < r1; r += 4) {
+            const float x = a[(size_t)r * C + c];
+            u += x;
+            v += mode ? x * b[(size_t)r * C + c] : x * x;
+        }
+    s0[w][threadIdx.x & 63] = u;
+    s1[w][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = (s0[0][l] + s0[1][l]) + (s0[2][l] + s0[3][l]);
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+    }
+}
+// level 2 for BatchNorm forward: mean, rstd (biased variance), running statistics (unbiased variance, momentum)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long rows, float eps, float momentum,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nblk; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    const double m = s / (double)rows;
+    double var = q / (double)rows - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0,
+                                                           float* __restrict__ o1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nblk; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    if (o0) o0[c] = (float)s;
+    if (o1) o1[c] = (float)q;
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                       size_t total, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        y[i] = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    }
+}
+// dx = gamma*rstd * (dy - sum_dy/R - xhat * sum_dy_xhat/R);  sums arrive as (sum dy, sum dy*x): sum dy*xhat = rstd*(sum dy*x - mean*sum dy)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, size_t total, int C, float inv_rows) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float xh = (x[i] - mean[c]) * rstd[c];
+        const float sdyxh = rstd[c] * (sum_dyx[c] - mean[c] * sum_dy[c]);
+        dx[i] = gamma[c] * rstd[c] * (dy[i] - sum_dy[c] * inv_rows - xh * sdyxh * inv_rows);
+        if (dgamma && i < (size_t)C) dgamma[i] = rstd[i] * (sum_dyx[i] - mean[i] * sum_dy[i]);
+    }
+}
+
+// ---- elementwise ----------------------------------------------------------------------------------------------------------
+// op 0: y = max(x,0)            op 1: dx = dy * (x > 0)            op 2: y = x > 0 ? x : s*x        op 3: dx = dy * (x > 0 ? 1 : s)
+// op 4: y = a + b               op 5: y = a * s                    op 6: y = sigmoid(x)             op 7: dx = dy * y * (1 - y)  (a = dy, b = y)
+// op 8: y = a * b               op 9: y = a + s*b
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n, int op,
+                                                 float s) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float u = a[i], v = b ? b[i] : 0.f;
+        float r;
+        switch (op) {
+            case 0: r = fmaxf(u, 0.f); break;
+            case 1: r = v > 0.f ? u : 0.f; break;               // a = dy, b = x
+            case 2: r = u > 0.f ? u : s * u; break;
+            case 3: r = v > 0.f ? u : s * u; break;             // a = dy, b = x
+            case 4: r = u + v; break;
+            case 5: r = u * s; break;
+            case 6: r = 1.f / (1.f + expf(-u)); break;
+            case 7: r = u * v * (1.f - v); break;
+            case 8: r = u * v; break;
+            default: r = u + s * v; break;
+        }
+        y[i] = r;
+    }
+}
+
+// ---- SE pieces: x [B, HW, C] --------------------------------------------------------------------------------------------
+// segment mean over HW (two-level through col_partial per clip would need B launches; one block per (clip, 64 channels) instead)
+__global__ __launch_bounds__(256) void seg_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C, float scale) {
+    __shared__ float s[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float u = 0.f;
+    if (c < C)
+        for (int p = w; p < HW; p += 4) u += x[((size_t)b * HW + p) * C + c];
+    s[w][threadIdx.x & 63] = u;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int l = threadIdx.x;
+        out[(size_t)b * C + c] = ((s[0][l] + s[1][l]) + (s[2][l] + s[3][l])) * scale;
+    }
+}
+// mode 0: y = x * gate[b,c];  mode 1: y = a * gate[b,c] + dgap[b,c]  (a = dy: dx of the scaled map plus the pooled branch's gradient);
+__global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__ a, const float* __restrict__ gate, const float* __restrict__ add,
+                                                       float* __restrict__ y, size_t total, int HW, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t b = i / ((size_t)HW * C);
+        const float g = gate[b * C + c];
+        y[i] = a[i] * g + (add ? add[b * C + c] : 0.f);
+    }
+}
+// dgate[b,c] = sum_hw dy * x
+__global__ __launch_bounds__(256) void seg_dot_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ out, int HW,
+                                                      int C) {
+    __shared__ float s[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float u = 0.f;
+    if (c < C)
+        for (int p = w; p < HW; p += 4) {
+            const size_t i = ((size_t)b * HW + p) * C + c;
+            u += dy[i] * x[i];
+        }
+    s[w][threadIdx.x & 63] = u;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int l = threadIdx.x;
+        out[(size_t)b * C + c] = (s[0][l] + s[1][l]) + (s[2][l] + s[3][l]);
+    }
+}
+
+// ---- LayerNorm backward: one wave per row ----------------------------------------------------------------------------------
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  also writes t = dy * xhat (for dgamma = colsum(t)); dbeta = colsum(dy)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                     float* __restrict__ dx, float* __restrict__ t, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    const float* dr = dy + (size_t)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float xh = (xr[i] - mean) * rstd, gd = gamma[i] * dr[i];
+        a += gd;
+        b += gd * xh;
+    }
+    a = wave_sum(a) / (float)D;
+    b = wave_sum(b) / (float)D;
+    for (int i = lane; i < D; i += 64) {
+        const float xh = (xr[i] - mean) * rstd;
+        dx[(size_t)row * D + i] = rstd * (gamma[i] * dr[i] - a - xh * b);
+        t[(size_t)row * D + i] = dr[i] * xh;
+    }
+}
+
+// ---- attention backward (Full_model/Modules.py:13-23), one workgroup per (head, clip), Lq, Lk <= 64 -------------------------
+// given P (the forward's probabilities) and dO:  dV = P^T dO;  dP = dO V^T;  dS = P * (dP - rowsum(dP * P));
+// dQ = dS K / temp;  dK = dS^T Q / temp
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                            const float* __restrict__ v, int ldv, const float* __restrict__ p,
+                                                            const float* __restrict__ dout, int ldo, float* __restrict__ dq, int lddq,
+                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, int H, int Lq,
+                                                            int Lk, float inv_temp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float* Qs = sm;                     // [Lq][65]
+    float* Ks = Qs + Lq * 65;           // [Lk][65]
+    float* Vs = Ks + Lk * 65;           // [Lk][65]
+    float* Ds = Vs + Lk * 65;           // dO [Lq][65]
+    float* Ps = Ds + Lq * 65;           // P  [Lq][Lk+1]
+    float* Ss = Ps + Lq * (Lk + 1);     // dS [Lq][Lk+1]
+    for (int i = tid; i < Lq * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        Qs[r * 65 + c] = q[((size_t)b * Lq + r) * ldq + h * 64 + c];
+        Ds[r * 65 + c] = dout[((size_t)b * Lq + r) * ldo + h * 64 + c];
+    }
+    for (int i = tid; i < Lk * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        Ks[r * 65 + c] = k[((size_t)b * Lk + r) * ldk + h * 64 + c];
+        Vs[r * 65 + c] = v[((size_t)b * Lk + r) * ldv + h * 64 + c];
+    }
+    for (int i = tid; i < Lq * Lk; i += 256) {
+        const int r = i / Lk, c = i - r * Lk;
+        Ps[r * (Lk + 1) + c] = p[(((size_t)b * H + h) * Lq + r) * Lk + c];
+    }
+    __syncthreads();
+    // dP
+    for (int i = tid; i < Lq * Lk; i += 256) {
+        const int r = i / Lk, c = i - r * Lk;
+        float s = 0.f;
+        for (int d = 0; d < 64; ++d) s += Ds[r * 65 + d] * Vs[c * 65 + d];
+        Ss[r * (Lk + 1) + c] = s;
+    }
+    __syncthreads();
+    // dS = P * (dP - sum_k dP*P), one wave per row
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < Lq; r += 4) {
+        float s = 0.f;
+        for (int c = lane; c < Lk; c += 64) s += Ss[r * (Lk + 1) + c] * Ps[r * (Lk + 1) + c];
+        s = wave_sum(s);
+        for (int c = lane; c < Lk; c += 64) Ss[r * (Lk + 1) + c] = Ps[r * (Lk + 1) + c] * (Ss[r * (Lk + 1) + c] - s);
+    }
+    __syncthreads();
+    for (int i = tid; i < Lq * 64; i += 256) {           // dQ
+        const int r = i >> 6, d = i & 63;
+        float s = 0.f;
+        for (int c = 0; c < Lk; ++c) s += Ss[r * (Lk + 1) + c] * Ks[c * 65 + d];
+        dq[((size_t)b * Lq + r) * lddq + h * 64 + d] = s * inv_temp;
+    }
+    for (int i = tid; i < Lk * 64; i += 256) {           // dK, dV
+        const int c = i >> 6, d = i & 63;
+        float s = 0.f, t = 0.f;
+        for (int r = 0; r < Lq; ++r) {
+            s += Ss[r * (Lk + 1) + c] * Qs[r * 65 + d];
+            t += Ps[r * (Lk + 1) + c] * Ds[r * 65 + d];
+        }
+        dk[((size_t)b * Lk + c) * lddk + h * 64 + d] = s * inv_temp;
+        dv[((size_t)b * Lk + c) * lddv + h * 64 + d] = t;
+    }
+}
+
+// ---- losses (one workgroup; sums in fixed order) -----------------------------------------------------------------------------
+// smooth-L1 (nn.SmoothL1Loss / F.smooth_l1_loss, mean reduction, beta): loss = mean(|d|<beta ? 0.5 d^2/beta : |d| - 0.5 beta)
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ dpred,
+                                                        float* __restrict__ partial, size_t n, float beta, float scale) {
+    __shared__ float s[256];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = pred[i] - target[i], ad = fabsf(d);
+        acc += ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta;
+        if (dpred) dpred[i] = scale * (ad < beta ? d / beta : (d > 0.f ? 1.f : -1.f));
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+__global__ void sum_small_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        out[0] = (float)(s * scale);
+    }
+}
+// cross entropy on logits [B, C] with integer labels; focal: alpha[label] * (1 - pt)^gamma * ce (train_audio_classifier_K_fold.py:95-105),
+// gamma < 0 selects plain CE.  per-sample loss -> rowloss; dlogits = d(mean loss * scale)/dlogits
+__global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ alpha,
+                                                float gamma, float scale, int B, int C, float* __restrict__ rowloss, float* __restrict__ dlogits) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    const float* z = logits + (size_t)b * C;
+    float m = -3.0e38f;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, z[c]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(z[c] - m);
+    se = wave_sum(se);
+    const int y = (int)labels[b];
+    const float logp = z[y] - m - logf(se), ce = -logp, pt = expf(logp);
+    float loss = ce, dce = 1.f;      // d loss / d ce (through pt = exp(-ce) as well)
+    if (gamma >= 0.f) {
+        const float a = alpha ? alpha[y] : 1.f, om = 1.f - pt;
+        const float w = powf(om, gamma);
+        loss = a * w * ce;
+        // d/dce [a (1-e^{-ce})^g ce] = a [ (1-pt)^g + g (1-pt)^{g-1} pt ce ]
+        dce = a * (w + (gamma > 0.f ? gamma * powf(om, gamma - 1.f) * pt * ce : 0.f));
+    }
+    if (lane == 0) rowloss[b] = loss;
+    if (dlogits)
+        for (int c = lane; c < C; c += 64) {
+            const float sm = expf(z[c] - m) / se;
+            dlogits[(size_t)b * C + c] = scale * dce * (sm - (c == y ? 1.f : 0.f)) / (float)B;
+        }
+}
+
+// ---- Adam (torch.optim.Adam: grad += wd * p; m, v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)) ---------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] + wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int eg_transpose(const float* x, int32_t ldx, int32_t rows, int32_t cols, float* y, int32_t ldy, void* stream) {
+    EG_REQUIRE(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= rows, EG_ERR_BAD_ARG, "eg_transpose: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3(eg_cdiv(cols, 32), eg_cdiv(rows, 32)), dim3(256), 0, ST, x, ldx, rows, cols, y, ldy);
+    return eg_check_launch("transpose");
+}
+
+extern "C" int64_t eg_gemm_tn_workspace_floats(int32_t m, int32_t n, int64_t k) {
+    const long tiles = (long)eg_cdiv(m, 64) * eg_cdiv(n, 64);
+    long splits = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
+    const long max_splits = (k + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    return splits <= 1 ? 0 : splits * (int64_t)m * n;
+}
+extern "C" int eg_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int32_t m, int32_t n, int64_t k,
+                          float* workspace, int64_t workspace_floats, int32_t accumulate, void* stream) {
+    EG_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && lda >= m && ldb >= n && ldc >= n, EG_ERR_BAD_ARG, "eg_gemm_tn: bad argument");
+    const int64_t need = eg_gemm_tn_workspace_floats(m, n, k);
+    EG_REQUIRE(need == 0 || (workspace && workspace_floats >= need), EG_ERR_WORKSPACE, "eg_gemm_tn: workspace %lld < %lld floats",
+               (long long)workspace_floats, (long long)need);
+    const int splits = need ? (int)(need / ((int64_t)m * n)) : 1;
+    const long kps = ((k + splits - 1) / splits + 31) / 32 * 32;
+    const int nz = (int)((k + kps - 1) / kps);
+    EgProfScope prof(7, 2.0 * m * (double)n * (double)k, ST);
+    if (nz <= 1 && !accumulate) {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(eg_cdiv(m, 64), eg_cdiv(n, 64), 1), dim3(256), 0, ST, a, lda, b, ldb, c, ldc, m, n, (long)k, (long)k,
+                           (float*)nullptr);
+        return eg_check_launch("gemm_tn");
+    }
+    float* part = workspace;
+    EG_REQUIRE(part && workspace_floats >= (int64_t)nz * m * n, EG_ERR_WORKSPACE, "eg_gemm_tn: accumulate / split-K needs a workspace");
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(eg_cdiv(m, 64), eg_cdiv(n, 64), nz), dim3(256), 0, ST, a, lda, b, ldb, c, ldc, m, n, (long)k, kps, part);
+    if (int rc = eg_check_launch("gemm_tn")) return rc;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(eg_cdiv(m * n, 256)), dim3(256), 0, ST, part, c, ldc, m, n, nz, accumulate);
+    return eg_check_launch("gemm_tn_reduce");
+}
+
+extern "C" int eg_im2col3x3(const float* x, float* col, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, int32_t backward,
+                            void* stream) {
+    EG_REQUIRE(x && col && batch > 0 && h > 0 && w > 0 && c > 0 && (stride == 1 || stride == 2), EG_ERR_BAD_ARG, "eg_im2col3x3: bad argument");
+    const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
+    if (!backward)
+        hipLaunchKernelGGL(im2col3x3_kernel, grid1((size_t)batch * ho * wo * 9 * c, 65536), dim3(256), 0, ST, x, col, batch, h, w, c, ho, wo, stride);
+    else        // x = dcol [B*Ho*Wo, 9C], col = dx [B,H,W,C]
+        hipLaunchKernelGGL(col2im3x3_kernel, grid1((size_t)batch * h * w * c, 65536), dim3(256), 0, ST, x, col, batch, h, w, c, ho, wo, stride);
+    return eg_check_launch("im2col3x3");
+}
+extern "C" int eg_subsample(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, int32_t backward, void* stream) {
+    EG_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && c > 0 && stride >= 1, EG_ERR_BAD_ARG, "eg_subsample: bad argument");
+    const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    const size_t total = backward ? (size_t)batch * h * w * c : (size_t)batch * ho * wo * c;
+    hipLaunchKernelGGL(subsample_kernel, grid1(total, 65536), dim3(256), 0, ST, x, y, batch, h, w, c, ho, wo, stride, backward);
+    return eg_check_launch("subsample");
+}
+extern "C" int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t len, int32_t c, int32_t k, int32_t stride, int32_t pad_left,
+                           int32_t dilation, int32_t lout, int32_t backward, void* stream) {
+    EG_REQUIRE(x && col && batch > 0 && len > 0 && c > 0 && k > 0 && stride > 0 && dilation > 0 && lout > 0, EG_ERR_BAD_ARG, "eg_im2col1d: bad argument");
+    if (!backward)
+        hipLaunchKernelGGL(im2col1d_kernel, grid1((size_t)batch * lout * k * c, 65536), dim3(256), 0, ST, x, col, batch, len, c, lout, k, stride,
+                           pad_left, dilation);
+    else
+        hipLaunchKernelGGL(col2im1d_kernel, grid1((size_t)batch * len * c, 65536), dim3(256), 0, ST, x, col, batch, len, c, lout, k, stride, pad_left,
+                           dilation);
+    return eg_check_launch("im2col1d");
+}
+
+namespace {
+int col_reduce(const float* a, const float* b, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st) {
+    long nblk = (rows + 2047) / 2048;
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    const long rows_per = (rows + nblk - 1) / nblk;
+    nblk = (rows + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a, b, part, (long)rows, c, rows_per, mode);
+    *nblk_out = (int)nblk;
+    return eg_check_launch("col_partial");
+}
+}  // namespace
+
+// workspace for the column reductions below: partials [<= 512][2][C] + one scratch column
+extern "C" int64_t eg_colreduce_workspace_floats(int32_t c) { return (int64_t)(2 * 512 + 1) * c; }
+
+extern "C" int eg_bn_train_forward(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_rstd,
+                                   float* running_mean, float* running_var, int64_t rows, int32_t c, float momentum, float eps, float* workspace,
+                                   void* stream) {
+    EG_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_bn_train_forward: bad argument");
+    int nblk = 0;
+    if (int rc = col_reduce(x, nullptr, rows, c, 0, workspace, &nblk, ST)) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var);
+    if (int rc = eg_check_launch("bn_finalize")) return rc;
+    hipLaunchKernelGGL(bn_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, save_mean, save_rstd, gamma, beta, y, (size_t)rows * c, c);
+    return eg_check_launch("bn_apply");
+}
+extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, const float* save_mean, const float* save_rstd, float* dx,
+                                    float* dgamma, float* dbeta, int64_t rows, int32_t c, float* workspace, void* stream) {
+    EG_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG,
+               "eg_bn_train_backward: bad argument");
+    int nblk = 0;
+    if (int rc = col_reduce(dy, x, rows, c, 1, workspace, &nblk, ST)) return rc;        // (sum dy, sum dy*x)
+    float* sum_dyx = workspace + (size_t)2 * 512 * c;           // scratch column behind the partials
+    // dbeta receives sum dy directly; sum dy*x goes to the scratch column
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx);
+    if (int rc = eg_check_launch("col_finalize")) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, dbeta, sum_dyx, dx, dgamma,
+                       (size_t)rows * c, c, 1.0f / (float)rows);
+    return eg_check_launch("bn_bwd_apply");
+}
+// o0[c] = sum_r a[r][c];  o1[c] = sum_r a[r][c]*b[r][c] (b optional: then o1 = sum a^2)
+extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream) {
+    EG_REQUIRE(a && (o0 || o1) && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_colsum: bad argument");
+    int nblk = 0;
+    if (int rc = col_reduce(a, b, rows, c, b ? 1 : 0, workspace, &nblk, ST)) return rc;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, o0, o1);
+    return eg_check_launch("col_finalize");
+}
+
+extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream) {
+    EG_REQUIRE(a && y && n > 0 && op >= 0 && op <= 9, EG_ERR_BAD_ARG, "eg_elementwise: bad argument");
+    EG_REQUIRE(b || op == 0 || op == 2 || op == 5 || op == 6, EG_ERR_BAD_ARG, "eg_elementwise: op %d needs a second operand", op);
+    hipLaunchKernelGGL(ew_kernel, grid1((size_t)n), dim3(256), 0, ST, a, b, y, (size_t)n, op, s);
+    return eg_check_launch("elementwise");
+}
+
+extern "C" int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, void* stream) {
+    EG_REQUIRE(x && out && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_seg_mean: bad argument");
+    hipLaunchKernelGGL(seg_mean_kernel, dim3(eg_cdiv(c, 64), batch), dim3(256), 0, ST, x, out, hw, c, scale);
+    return eg_check_launch("seg_mean");
+}
+extern "C" int eg_seg_dot(const float* dy, const float* x, float* out, int32_t batch, int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(dy && x && out && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_seg_dot: bad argument");
+    hipLaunchKernelGGL(seg_dot_kernel, dim3(eg_cdiv(c, 64), batch), dim3(256), 0, ST, dy, x, out, hw, c);
+    return eg_check_launch("seg_dot");
+}
+extern "C" int eg_se_scale(const float* a, const float* gate, const float* add, float* y, int32_t batch, int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(a && gate && y && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_se_scale: bad argument");
+    hipLaunchKernelGGL(se_scale_kernel, grid1((size_t)batch * hw * c), dim3(256), 0, ST, a, gate, add, y, (size_t)batch * hw * c, hw, c);
+    return eg_check_launch("se_scale");
+}
+
+extern "C" int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* dy_xhat, int32_t rows, int32_t d, float eps,
+                                     void* stream) {
+    EG_REQUIRE(x && dy && gamma && dx && dy_xhat && rows > 0 && d > 0, EG_ERR_BAD_ARG, "eg_layernorm_backward: bad argument");
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(eg_cdiv(rows, 4)), dim3(256), 0, ST, x, dy, gamma, dx, dy_xhat, rows, d, eps);
+    return eg_check_launch("layernorm_backward");
+}
+
+extern "C" int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
+                                     const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
+                                     int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t dk_dim, void* stream) {
+    EG_REQUIRE(q && k && v && attn && dout && dq && dk && dv && batch > 0 && heads > 0 && lq > 0 && lk > 0, EG_ERR_BAD_ARG,
+               "eg_attention_backward: bad argument");
+    EG_REQUIRE(dk_dim == 64, EG_ERR_UNSUPPORTED, "eg_attention_backward: d_k=%d", dk_dim);
+    const size_t smem = sizeof(float) * ((size_t)2 * lq * 65 + (size_t)2 * lk * 65 + (size_t)2 * lq * (lk + 1));
+    EG_REQUIRE(smem <= 160 * 1024, EG_ERR_UNSUPPORTED, "eg_attention_backward: Lq=%d Lk=%d needs %zu B of LDS", lq, lk, smem);
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_bwd_kernel), smem, "eg_attention_backward")) return rc;
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(heads, batch), dim3(256), smem, ST, q, ldq, k, ldk, v, ldv, attn, dout, ldo, dq, lddq, dk, lddk, dv,
+                       lddv, heads, lq, lk, 1.0f / sqrtf((float)dk_dim));
+    return eg_check_launch("attention_backward");
+}
+
+// loss[0] = scale * mean smooth_l1(pred, target; beta);  dpred (optional) = d loss / d pred.  workspace >= 1024 floats.
+extern "C" int eg_smooth_l1(const float* pred, const float* target, float* loss, float* dpred, int64_t n, float beta, float scale, float* workspace,
+                            void* stream) {
+    EG_REQUIRE(pred && target && loss && workspace && n > 0 && beta > 0.f, EG_ERR_BAD_ARG, "eg_smooth_l1: bad argument");
+    const int nb = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(nb), dim3(256), 0, ST, pred, target, dpred, workspace, (size_t)n, beta, scale / (float)n);
+    if (int rc = eg_check_launch("smooth_l1")) return rc;
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, ST, workspace, nb, (double)scale / (double)n, loss);
+    return eg_check_launch("smooth_l1_sum");
+}
+// loss[0] = scale * mean_b L_b;  L_b = CE (gamma < 0) or focal alpha[y] (1-pt)^gamma CE.  workspace >= B floats.
+extern "C" int eg_cross_entropy(const float* logits, const int64_t* labels, const float* alpha, float gamma, float scale, float* loss, float* dlogits,
+                                int32_t batch, int32_t classes, float* workspace, void* stream) {
+    EG_REQUIRE(logits && labels && loss && workspace && batch > 0 && classes > 0, EG_ERR_BAD_ARG, "eg_cross_entropy: bad argument");
+    hipLaunchKernelGGL(ce_kernel, dim3(batch), dim3(64), 0, ST, logits, labels, alpha, gamma, scale, batch, classes, workspace, dlogits);
+    if (int rc = eg_check_launch("cross_entropy")) return rc;
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, ST, workspace, batch, (double)scale / (double)batch, loss);
+    return eg_check_launch("cross_entropy_sum");
+}
+
+extern "C" int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t step, void* stream) {
+    EG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, EG_ERR_BAD_ARG, "eg_adam_step: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, grid1((size_t)n, 16384), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    return eg_check_launch("adam_step");
+}

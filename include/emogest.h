@@ -324,6 +324,59 @@ int64_t eg_contrastive_workspace_bytes(int32_t n);
 int eg_contrastive_loss(const float* face, const float* audio, int32_t n, int32_t d, float* cross, float* loss, float* acc,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+
+/* ===================== training-path primitives (fp32, deterministic reductions) =====================
+ * The reference trains through autograd over ATen (its one loop: train_audio_classifier_K_fold.py:155-175; generator
+ * hints: test_emotion_gesture_diversity_iterative.py:64-127,355-366).  These are the backward-side kernels; the host
+ * (emotiongestures_amd/train/) sequences them.  All buffers caller-owned, row-major, fp32. */
+
+/* y[c*ldy + r] = x[r*ldx + c] */
+int eg_transpose(const float* x, int32_t ldx, int32_t rows, int32_t cols, float* y, int32_t ldy, void* stream);
+/* C[m,n] (+)= sum_k A[k,m] B[k,n] on v_mfma_f32_16x16x4_f32 (dW = dY^T X; conv wgrad over im2col rows); split-K through
+ * `workspace` (eg_gemm_tn_workspace_floats; at least m*n floats when accumulate != 0). */
+int64_t eg_gemm_tn_workspace_floats(int32_t m, int32_t n, int64_t k);
+int eg_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int32_t m, int32_t n, int64_t k,
+               float* workspace, int64_t workspace_floats, int32_t accumulate, void* stream);
+/* 3x3 / pad 1 / stride s, NHWC: forward  col[(b,oy,ox)][tap*C + c] = x[b, oy*s+kh-1, ox*s+kw-1, c];
+ * backward (x = dcol, col = dx [B,H,W,C]): the transpose in gather form (F.conv2d's input gradient after the GEMM). */
+int eg_im2col3x3(const float* x, float* col, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, int32_t backward, void* stream);
+/* pixel subsample of a 1x1 stride-s conv (ResNetSE34V2.py:43-47) and its transpose */
+int eg_subsample(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, int32_t backward, void* stream);
+/* 1-D channels-last im2col: x [B,L,C] -> col [B*Lout, k*C] at l*stride + j*dilation - pad_left; backward = transpose */
+int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t len, int32_t c, int32_t k, int32_t stride, int32_t pad_left,
+                int32_t dilation, int32_t lout, int32_t backward, void* stream);
+/* nn.BatchNorm{1,2}d in train() mode over channels-last rows [rows, C]: batch statistics (biased variance for the
+ * normalisation, unbiased for running_var, momentum as torch), saved mean / rstd for the backward. */
+int64_t eg_colreduce_workspace_floats(int32_t c);
+int eg_bn_train_forward(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_rstd,
+                        float* running_mean, float* running_var, int64_t rows, int32_t c, float momentum, float eps, float* workspace,
+                        void* stream);
+int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, const float* save_mean, const float* save_rstd, float* dx,
+                         float* dgamma, float* dbeta, int64_t rows, int32_t c, float* workspace, void* stream);
+/* o0[c] = sum_r a[r,c]; o1[c] = sum_r a[r,c]*b[r,c] (b NULL: sum a^2).  bias / LayerNorm affine gradients. */
+int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
+/* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b */
+int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream);
+/* SELayer pieces (ResNetBlocks.py:92-96) on x [B, HW, C]: pooled mean (x scale), per-(clip, channel) dot, gate scaling (+ add[b,c]) */
+int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, void* stream);
+int eg_seg_dot(const float* dy, const float* x, float* out, int32_t batch, int32_t hw, int32_t c, void* stream);
+int eg_se_scale(const float* a, const float* gate, const float* add, float* y, int32_t batch, int32_t hw, int32_t c, void* stream);
+/* LayerNorm backward (SubLayers.py:55-57,80-82): dx and dy*xhat (dgamma = colsum(dy*xhat), dbeta = colsum(dy)) */
+int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* dy_xhat, int32_t rows, int32_t d, float eps,
+                          void* stream);
+/* ScaledDotProductAttention backward (Modules.py:13-23) from the forward's probabilities; Lq, Lk <= 64-ish (LDS-resident) */
+int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
+                          const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
+                          int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t dk_dim, void* stream);
+/* losses: scale * mean smooth-L1 (beta); scale * mean CE / focal(alpha, gamma >= 0) (train_audio_classifier_K_fold.py:95-105) */
+int eg_smooth_l1(const float* pred, const float* target, float* loss, float* dpred, int64_t n, float beta, float scale, float* workspace,
+                 void* stream);
+int eg_cross_entropy(const float* logits, const int64_t* labels, const float* alpha, float gamma, float scale, float* loss, float* dlogits,
+                     int32_t batch, int32_t classes, float* workspace, void* stream);
+/* torch.optim.Adam step on a flat buffer (L2 weight decay added to the gradient; train_audio_classifier_K_fold.py:128) */
+int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

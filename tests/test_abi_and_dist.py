@@ -76,9 +76,9 @@ def test_config_validation_and_status_codes():
     one = C.c_void_p(16)                                      # a non-null, 16-byte aligned dummy address that is never dereferenced
     assert lib.eg_linear(None, 4, None, 4, None, None, None, 0, None, 4, 1, 1, 4, 0, 0, 0, 0, None) < 0
     assert lib.eg_layernorm(None, None, None, None, 4, 512, 1e-6, None) < 0
-    assert lib.eg_attention(one, 512, one, 512, one, 512, one, 512, None, 1, 8, 4, 4, 32, None) == -2         # d_k 32: EG_ERR_UNSUPPORTED
+    assert lib.eg_attention(one, 512, one, 512, one, 512, one, 512, None, 1, 8, 4, 4, 32, 0, None) == -2         # d_k 32: EG_ERR_UNSUPPORTED
     assert b"d_k" in lib.eg_last_error()
-    assert lib.eg_attention(one, 512, one, 512, one, 512, one, 512, None, 1, 8, 4, 300, 64, None) == -2        # Lk > 256
+    assert lib.eg_attention(one, 512, one, 512, one, 512, one, 512, None, 1, 8, 4, 300, 64, 0, None) == -2        # Lk > 256
     assert lib.eg_conv3x3(one, one, None, None, None, one, None, 1, 8, 8, 32, 32, 3, 0, 0, 0, None) == -2      # stride 3
     assert lib.eg_conv3x3(one, one, None, None, None, one, None, 1, 8, 8, 48, 48, 1, 0, 0, 0, None) == -2      # channel count without a kernel
     assert lib.eg_conv1d(one, one, one, one, None, one, 1, 4, 4, 8, 3, 1, 1, 1, None) == -1                    # scale without shift
