@@ -475,7 +475,8 @@ __global__ void sum_small_kernel(const float* __restrict__ partial, int n, float
         out[0] = (float)(s * scale);
     }
 }
-// cross entropy on logits [B, C] with integer labels; focal: alpha[label] * (1 - pt)^gamma * ce (train_audio_classifier_K_fold.py:95-105),
+// cross entropy on logits [B, C] with integer labels; focal: alpha[b] * (1 - pt)^gamma * ce with a PER-SAMPLE weight vector, as
+// `self.alpha * (1-pt)**self.gamma * ce_loss` broadcasts it (train_audio_classifier_K_fold.py:95-105),
 // gamma < 0 selects plain CE.  per-sample loss -> rowloss; dlogits = d(mean loss * scale)/dlogits
 __global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ alpha,
                                                 float gamma, float scale, int B, int C, float* __restrict__ rowloss, float* __restrict__ dlogits) {
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits
     const float logp = z[y] - m - logf(se), ce = -logp, pt = expf(logp);
     float loss = ce, dce = 1.f;      // d loss / d ce (through pt = exp(-ce) as well)
     if (gamma >= 0.f) {
-        const float a = alpha ? alpha[y] : 1.f, om = 1.f - pt;
+        const float a = alpha ? alpha[b] : 1.f, om = 1.f - pt;
         const float w = powf(om, gamma);
         loss = a * w * ce;
         // d/dce [a (1-e^{-ce})^g ce] = a [ (1-pt)^g + g (1-pt)^{g-1} pt ce ]

@@ -1,7 +1,8 @@
 """Mirror of model/audio_emotion_classifer.py:17-49: EmotionNet, the audio emotion classifier, inference
 forward on the HIP kernels: 4-stage ResNetSE ([3,4,6,3] SE blocks at 32/64/128/256 channels) on a [B,128,128] spectrogram
--> [B,256,16,16] -> 6-layer ReLU MLP -> 8 logits.  Training of this network (train_audio_classifier_K_fold.py:109-200) needs
-backward kernels and is not built."""
+-> [B,256,16,16] -> 6-layer ReLU MLP -> 8 logits.  In train() mode the forward runs on the differentiable HIP operators of
+emotiongestures_amd/train (batch-statistics BatchNorm); tools/train_emotion_net.py is the training loop of
+train_audio_classifier_K_fold.py:109-200 on synthetic data."""
 from __future__ import annotations
 
 import torch
@@ -35,7 +36,9 @@ class EmotionNet(nn.Module):
         return self._fc0[1]
 
     def forward(self, mfcc):
-        _eval_only(self)
+        if self.training:           # train() mode (train_audio_classifier_K_fold.py:155-175): differentiable HIP operators
+            from ..train import nets
+            return nets.emotion_net_forward(self, mfcc)
         if mfcc.dim() != 3 or tuple(mfcc.shape[1:]) != (128, 128):
             raise ValueError(f"EmotionNet.forward: expected [B,128,128] (-> 256x16x16 features), got {tuple(mfcc.shape)}")
         for m in self.emotion_encoder.modules():

@@ -7,7 +7,8 @@ HIP kernels through libemogest_hip.so instead of calling ATen.  Parameter-holdin
 (``Linear``, ``Conv2d`` ...) deliberately have no ``forward``: nothing here can silently fall back
 to an eager PyTorch op.
 
-Only eval-mode inference is built so far; calling a module in ``train()`` mode raises.
+``Transformer`` (spatial variant) and ``EmotionNet`` also run in ``train()`` mode (emotiongestures_amd/train/: fp32 HIP forward
+and backward operators under torch.autograd); the other modules are eval-only and raise in ``train()`` mode.
 """
 from __future__ import annotations
 
@@ -585,7 +586,9 @@ class Transformer(nn.Module):
         return self._engine
 
     def forward(self, input_spectrum, text, prior_seq, sampled_emotion_feature=None, *, slot=0):
-        _eval_only(self)
+        if self.training:           # train() mode: differentiable HIP operators, BatchNorm on batch statistics (train/nets.py)
+            from .train import nets
+            return nets.generator_forward(self, input_spectrum, text, prior_seq, sampled_emotion_feature)
         return self.engine().forward(input_spectrum, text, prior_seq, sampled_emotion_feature, slot=slot)
 
     def forward_draws(self, input_spectrum, prior_seq, sampled_emotion_features):

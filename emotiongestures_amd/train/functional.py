@@ -1,0 +1,556 @@
+"""Differentiable operators of the training path: every forward AND backward is a HIP kernel of libemogest_hip.so.
+
+torch.autograd only sequences the backward (the reference trains through autograd too: train_audio_classifier_K_fold.py:155-175);
+it performs no arithmetic here: fan-outs go through `fork` (its backward adds on the HIP elementwise kernel), losses scale their
+own gradients.  torch is used for device memory and for pure data movement (zero fill, strided copies, permutes of weights).
+Everything is fp32 (EG_PREC_F32: v_mfma_f32_16x16x4_f32) -- gradient parity with the reference's fp32 autograd is the bar
+(tests/test_gpu_training.py, tolerance 1e-4 per-parameter relative L2).  No CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+from ..engine import _ptr, _stream
+
+F32 = L.EG_PREC_F32
+_WS = {}
+
+
+def _lib():
+    return L.load()
+
+
+def _chk(t: torch.Tensor, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise L.EgError(f"{name}: the training path runs only on a GPU (got {t.device}); there is no CPU fallback")
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _scratch(dev, floats: int, tag="ws") -> torch.Tensor:
+    """Reusable scratch (partials of split-K / column reductions).  Stream-ordered use only."""
+    key = (str(dev), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(int(floats), 1 << 16), dtype=torch.float32, device=dev)
+        _WS[key] = buf
+    return buf
+
+
+def _pad_cols(t: torch.Tensor, mult=4) -> torch.Tensor:
+    """[R, K] -> [R, Kp] zero padded to a multiple of `mult` (pure data movement)."""
+    k = t.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return t
+    out = torch.zeros(t.shape[0], kp, dtype=torch.float32, device=t.device)
+    out[:, :k].copy_(t)
+    return out
+
+
+# ---- raw (non-autograd) kernels ---------------------------------------------------------------------------------------------
+def raw_linear(x, w, bias=None, relu=False, res=None):
+    """y[M,N] = x[M,K] w[N,K]^T (+bias) (+res) (relu) on the fp32 MFMA GEMM (eg_linear)."""
+    lib = _lib()
+    x, w = _pad_cols(x), _pad_cols(w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    L.check(lib.eg_linear(_ptr(x), K, _ptr(w), K, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), 0, 0, F32, _stream(x.device)),
+            "eg_linear")
+    return y
+
+
+def raw_transpose(x):
+    lib = _lib()
+    r, c = x.shape
+    y = torch.empty(c, r, dtype=torch.float32, device=x.device)
+    L.check(lib.eg_transpose(_ptr(x), c, r, c, _ptr(y), r, _stream(x.device)), "eg_transpose")
+    return y
+
+
+def raw_gemm_tn(a, b, out=None, accumulate=False):
+    """c[m,n] = sum_k a[k,m] b[k,n]"""
+    lib = _lib()
+    k, m = a.shape
+    n = b.shape[1]
+    c = out if out is not None else torch.empty(m, n, dtype=torch.float32, device=a.device)
+    need = max(lib.eg_gemm_tn_workspace_floats(m, n, k), m * n if accumulate else 0)
+    ws = _scratch(a.device, need, "tn") if need else None
+    L.check(lib.eg_gemm_tn(_ptr(a), m, _ptr(b), n, _ptr(c), n, m, n, k, _ptr(ws), ws.numel() if ws is not None else 0, int(accumulate),
+                           _stream(a.device)), "eg_gemm_tn")
+    return c
+
+
+def raw_colsum(a, b=None, want0=True, want1=False):
+    lib = _lib()
+    rows, c = a.shape
+    ws = _scratch(a.device, lib.eg_colreduce_workspace_floats(c), "col")
+    o0 = torch.empty(c, dtype=torch.float32, device=a.device) if want0 else None
+    o1 = torch.empty(c, dtype=torch.float32, device=a.device) if want1 else None
+    L.check(lib.eg_colsum(_ptr(a), _ptr(b), _ptr(o0), _ptr(o1), rows, c, _ptr(ws), _stream(a.device)), "eg_colsum")
+    return o0, o1
+
+
+def raw_ew(op, a, b=None, s=0.0):
+    lib = _lib()
+    y = torch.empty_like(a)
+    L.check(lib.eg_elementwise(_ptr(a), _ptr(b), _ptr(y), a.numel(), op, float(s), _stream(a.device)), "eg_elementwise")
+    return y
+
+
+EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY = range(10)
+
+
+def raw_linear_backward(x, w, dy, need_dx=True):
+    """dx = dy w;  dw = dy^T x;  db = colsum(dy)"""
+    dw = raw_gemm_tn(dy, x)
+    db, _ = raw_colsum(dy)
+    dx = raw_linear(dy, raw_transpose(w)) if need_dx else None          # [M,N] x ([K,N])^T
+    return dx, dw, db
+
+
+# ---- autograd Functions -------------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        xs = x.shape
+        x2 = _chk(x, "x").reshape(-1, xs[-1])
+        wd = _chk(w, "weight")
+        y = raw_linear(x2, wd, _chk(b) if b is not None else None, relu)
+        ctx.save_for_backward(x2, wd, y if relu else None)
+        ctx.has_b, ctx.xs, ctx.need_dx = b is not None, xs, x.requires_grad
+        return y.view(*xs[:-1], wd.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dy2 = _chk(dy).reshape(-1, w.shape[0])
+        if y is not None:
+            dy2 = raw_ew(EW_RELU_BWD, dy2, y)
+        dx, dw, db = raw_linear_backward(x2, w, dy2, ctx.need_dx)
+        return (dx.view(ctx.xs) if dx is not None else None), dw, (db if ctx.has_b else None), None
+
+
+def linear(x, w, b=None, relu=False):
+    """nn.Linear (+ fused ReLU)"""
+    return _Linear.apply(x, w, b, relu)
+
+
+class _Fork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None:
+            return gb
+        if gb is None:
+            return ga
+        return raw_ew(EW_ADD, _chk(ga), _chk(gb))
+
+
+def fork(x):
+    """Two uses of one tensor; the backward sums the two gradients on the HIP elementwise kernel (not torch's accumulate)."""
+    return _Fork.apply(x)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return raw_ew(EW_ADD, _chk(a), _chk(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        xd = _chk(x)
+        ctx.save_for_backward(xd)
+        ctx.slope = slope
+        return raw_ew(EW_RELU, xd) if slope == 0.0 else raw_ew(EW_LEAKY, xd, None, slope)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return (raw_ew(EW_RELU_BWD, _chk(dy), x) if ctx.slope == 0.0 else raw_ew(EW_LEAKY_BWD, _chk(dy), x, ctx.slope)), None
+
+
+def relu(x):
+    return _Act.apply(x, 0.0)
+
+
+def leaky_relu(x, slope=0.2):
+    return _Act.apply(x, float(slope))
+
+
+def _pack_conv_f32(w, coutp):
+    """OIHW -> the conv kernel's fp32 image [tap][ci/4][co_pad][4] (data movement only)."""
+    co, ci = w.shape[:2]
+    t = torch.zeros(9, ci, coutp, dtype=torch.float32, device=w.device)
+    t[:, :, :co].copy_(w.permute(2, 3, 1, 0).reshape(9, ci, co))
+    return t.view(9, ci // 4, 4, coutp).permute(0, 1, 3, 2).contiguous()
+
+
+class _Conv3x3(torch.autograd.Function):
+    """nn.Conv2d(k=3, pad=1, stride s) on NHWC activations; weight OIHW as in the reference's state_dict."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, relu):
+        lib = _lib()
+        xd, wd = _chk(x, "x"), _chk(w, "weight")
+        B, H, W, Ci = xd.shape
+        Co = wd.shape[0]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        dev = xd.device
+        if Ci % 32 == 0:
+            coutp = (Co + 15) // 16 * 16
+            wp = _pack_conv_f32(wd, coutp)
+            bp = None
+            if b is not None:
+                bp = torch.zeros(coutp, dtype=torch.float32, device=dev)
+                bp[:Co].copy_(_chk(b))
+            if Co % 4 == 0:
+                y = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev)
+                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), None, B, H, W, Ci, Co, stride, int(relu), 0, F32,
+                                       _stream(dev)), "eg_conv3x3")
+            else:           # ragged channel count (final_conv1: 128 -> frames): channel-major epilogue, then back to NHWC
+                yc = torch.empty(B, Co, Ho * Wo, dtype=torch.float32, device=dev)
+                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(yc), None, B, H, W, Ci, Co, stride, int(relu), 1, F32,
+                                       _stream(dev)), "eg_conv3x3")
+                y = yc.view(B, Co, Ho, Wo).permute(0, 2, 3, 1).contiguous()
+        else:               # the stem (1 input channel): im2col rows through the GEMM
+            col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
+            L.check(lib.eg_im2col3x3(_ptr(xd), _ptr(col), B, H, W, Ci, stride, 0, _stream(dev)), "eg_im2col3x3")
+            wm = wd.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+            y = raw_linear(col, wm, _chk(b) if b is not None else None, relu).view(B, Ho, Wo, Co)
+        ctx.save_for_backward(xd, wd, y if relu else None)
+        ctx.stride, ctx.has_b, ctx.need_dx = stride, b is not None, x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, w, y = ctx.saved_tensors
+        B, H, W, Ci = x.shape
+        Co = w.shape[0]
+        dyd = _chk(dy)
+        if y is not None:
+            dyd = raw_ew(EW_RELU_BWD, dyd, y)
+        Ho, Wo = dyd.shape[1], dyd.shape[2]
+        dev = x.device
+        dy2 = dyd.view(B * Ho * Wo, Co)
+        col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
+        L.check(lib.eg_im2col3x3(_ptr(x), _ptr(col), B, H, W, Ci, ctx.stride, 0, _stream(dev)), "eg_im2col3x3")
+        dwm = raw_gemm_tn(dy2, col)                                         # [Co, (kh,kw,ci)]
+        dw = dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+        db = raw_colsum(dy2)[0] if ctx.has_b else None
+        dx = None
+        if ctx.need_dx:
+            wmat_t = w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()   # [(kh,kw,ci), co] = Wmat^T
+            dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
+            dx = torch.empty_like(x)
+            L.check(lib.eg_im2col3x3(_ptr(dcol), _ptr(dx), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_col2im3x3")
+        return dx, dw, db, None, None
+
+
+def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False):
+    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu)
+
+
+class _Subsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        lib = _lib()
+        xd = _chk(x)
+        B, H, W, Cc = xd.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(B, Ho, Wo, Cc, dtype=torch.float32, device=xd.device)
+        L.check(lib.eg_subsample(_ptr(xd), _ptr(y), B, H, W, Cc, stride, 0, _stream(xd.device)), "eg_subsample")
+        ctx.shape, ctx.stride = (B, H, W, Cc), stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        B, H, W, Cc = ctx.shape
+        dyd = _chk(dy)
+        dx = torch.empty(B, H, W, Cc, dtype=torch.float32, device=dyd.device)
+        L.check(lib.eg_subsample(_ptr(dyd), _ptr(dx), B, H, W, Cc, ctx.stride, 1, _stream(dyd.device)), "eg_subsample")
+        return dx, None
+
+
+def conv1x1(x_nhwc, w_oi11, stride=1):
+    """nn.Conv2d(k=1, stride s, bias=False): the downsample shortcut (ResNetSE34V2.py:43-47)."""
+    xs = _Subsample.apply(x_nhwc, stride) if stride != 1 else x_nhwc
+    return linear(xs, w_oi11.view(w_oi11.shape[0], -1))
+
+
+class _BatchNorm(torch.autograd.Function):
+    """nn.BatchNorm{1,2}d in train() mode over the last (channel) axis; updates the running buffers in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps):
+        lib = _lib()
+        xd, g, b = _chk(x), _chk(gamma), _chk(beta)
+        Cc = xd.shape[-1]
+        rows = xd.numel() // Cc
+        dev = xd.device
+        y = torch.empty_like(xd)
+        mean, rstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        L.check(lib.eg_bn_train_forward(_ptr(xd), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(run_mean), _ptr(run_var), rows, Cc,
+                                        float(momentum), float(eps), _ptr(ws), _stream(dev)), "eg_bn_train_forward")
+        ctx.save_for_backward(xd, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, g, mean, rstd = ctx.saved_tensors
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dev = x.device
+        dyd = _chk(dy)
+        dx, dg, db = torch.empty_like(x), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        L.check(lib.eg_bn_train_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, Cc, _ptr(ws),
+                                         _stream(dev)), "eg_bn_train_backward")
+        return dx, dg, db, None, None, None, None
+
+
+def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5):
+    """`bn` = a BatchNorm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked)."""
+    y = _BatchNorm.apply(x_channels_last, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, eps)
+    bn.num_batches_tracked += 1
+    return y
+
+
+class _SELayer(torch.autograd.Function):
+    """SELayer.forward (ResNetBlocks.py:92-96): y * sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2), y NHWC."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, w2, b2):
+        lib = _lib()
+        yd = _chk(y)
+        B, H, W, Cc = yd.shape
+        dev = yd.device
+        gap = torch.empty(B, Cc, device=dev)
+        L.check(lib.eg_seg_mean(_ptr(yd), _ptr(gap), B, H * W, Cc, 1.0 / (H * W), _stream(dev)), "eg_seg_mean")
+        w1d, b1d, w2d, b2d = _chk(w1), _chk(b1), _chk(w2), _chk(b2)
+        h = raw_linear(gap, w1d, b1d, relu=True)
+        gate = raw_ew(EW_SIGMOID, raw_linear(h, w2d, b2d))
+        out = torch.empty_like(yd)
+        L.check(lib.eg_se_scale(_ptr(yd), _ptr(gate), None, _ptr(out), B, H * W, Cc, _stream(dev)), "eg_se_scale")
+        ctx.save_for_backward(yd, gap, h, gate, w1d, w2d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib()
+        y, gap, h, gate, w1, w2 = ctx.saved_tensors
+        B, H, W, Cc = y.shape
+        dev = y.device
+        do = _chk(dout)
+        dgate = torch.empty(B, Cc, device=dev)
+        L.check(lib.eg_seg_dot(_ptr(do), _ptr(y), _ptr(dgate), B, H * W, Cc, _stream(dev)), "eg_seg_dot")
+        dz2 = raw_ew(EW_SIGMOID_BWD, dgate, gate)
+        dh, dw2, db2 = raw_linear_backward(h, w2, dz2)
+        dz1 = raw_ew(EW_RELU_BWD, dh, h)
+        dgap, dw1, db1 = raw_linear_backward(gap, w1, dz1)
+        dgap = raw_ew(EW_SCALE, dgap, None, 1.0 / (H * W))
+        dy = torch.empty_like(y)
+        L.check(lib.eg_se_scale(_ptr(do), _ptr(gate), _ptr(dgap), _ptr(dy), B, H * W, Cc, _stream(dev)), "eg_se_scale")
+        return dy, dw1, db1, dw2, db2
+
+
+def se_layer(y_nhwc, fc0, fc2):
+    return _SELayer.apply(y_nhwc, fc0.weight, fc0.bias, fc2.weight, fc2.bias)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        lib = _lib()
+        xd, gd, bd = _chk(x), _chk(g), _chk(b)
+        D = xd.shape[-1]
+        rows = xd.numel() // D
+        y = torch.empty_like(xd)
+        L.check(lib.eg_layernorm(_ptr(xd), _ptr(gd), _ptr(bd), _ptr(y), rows, D, float(eps), _stream(xd.device)), "eg_layernorm")
+        ctx.save_for_backward(xd, gd)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, g = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dyd = _chk(dy)
+        dx, t = torch.empty_like(x), torch.empty_like(x)
+        L.check(lib.eg_layernorm_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(dx), _ptr(t), rows, D, float(ctx.eps), _stream(x.device)),
+                "eg_layernorm_backward")
+        dg, _ = raw_colsum(t.view(rows, D))
+        db, _ = raw_colsum(dyd.view(rows, D))
+        return dx, dg, db, None
+
+
+def layer_norm(x, ln):
+    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class _Attention(torch.autograd.Function):
+    """ScaledDotProductAttention (Modules.py:13-23) on [B, L, H*64] projections; forward on the MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        lib = _lib()
+        qd, kd, vd = _chk(q), _chk(k), _chk(v)
+        B, Lq, D = qd.shape
+        Lk = kd.shape[1]
+        dev = qd.device
+        out = torch.empty_like(qd)
+        attn = torch.empty(B, heads, Lq, Lk, device=dev)
+        L.check(lib.eg_attention(_ptr(qd), D, _ptr(kd), D, _ptr(vd), D, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk, D // heads, F32, _stream(dev)),
+                "eg_attention")
+        ctx.save_for_backward(qd, kd, vd, attn)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib()
+        q, k, v, attn = ctx.saved_tensors
+        B, Lq, D = q.shape
+        Lk = k.shape[1]
+        do = _chk(dout)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        L.check(lib.eg_attention_backward(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(attn), _ptr(do), D, _ptr(dq), D, _ptr(dk), D, _ptr(dv), D, B,
+                                          ctx.heads, Lq, Lk, D // ctx.heads, _stream(q.device)), "eg_attention_backward")
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, heads):
+    return _Attention.apply(q, k, v, heads)
+
+
+class _Conv1dCL(torch.autograd.Function):
+    """nn.Conv1d on channels-last activations x [B, L, Cin] with the reference's weight [Cout, Cin, k]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, dilation):
+        lib = _lib()
+        xd, wd = _chk(x), _chk(w)
+        B, Ln, Ci = xd.shape
+        Co, _, k = wd.shape
+        Lout = (Ln + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+        dev = xd.device
+        col = torch.empty(B * Lout, k * Ci, device=dev)
+        L.check(lib.eg_im2col1d(_ptr(xd), _ptr(col), B, Ln, Ci, k, stride, pad, dilation, Lout, 0, _stream(dev)), "eg_im2col1d")
+        wm = wd.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()            # [co][(j, ci)]
+        y = raw_linear(col, wm, _chk(b) if b is not None else None)
+        ctx.save_for_backward(xd, wd, col, wm)
+        ctx.cfg = (stride, pad, dilation, Lout, b is not None, x.requires_grad)
+        return y.view(B, Lout, Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, w, col, wm = ctx.saved_tensors
+        stride, pad, dilation, Lout, has_b, need_dx = ctx.cfg
+        B, Ln, Ci = x.shape
+        Co, _, k = w.shape
+        dy2 = _chk(dy).reshape(B * Lout, Co)
+        dcol, dwm, db = raw_linear_backward(col, wm, dy2, need_dx)
+        dw = dwm.view(Co, k, Ci).permute(0, 2, 1).contiguous()
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(x)
+            L.check(lib.eg_im2col1d(_ptr(dcol), _ptr(dx), B, Ln, Ci, k, stride, pad, dilation, Lout, 1, _stream(x.device)), "eg_col2im1d")
+        return dx, dw, (db if has_b else None), None, None, None
+
+
+def conv1d_cl(x_blc, w, b=None, stride=1, pad=0, dilation=1):
+    return _Conv1dCL.apply(x_blc, w, b, stride, pad, dilation)
+
+
+class _SmoothL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, beta, scale):
+        lib = _lib()
+        p, t = _chk(pred), _chk(target)
+        dev = p.device
+        loss, dp = torch.empty(1, device=dev), torch.empty_like(p)
+        ws = _scratch(dev, 1024, "loss")
+        L.check(lib.eg_smooth_l1(_ptr(p), _ptr(t), _ptr(loss), _ptr(dp), p.numel(), float(beta), float(scale), _ptr(ws), _stream(dev)), "eg_smooth_l1")
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        s = float(g.reshape(-1)[0])
+        return (dp if s == 1.0 else raw_ew(EW_SCALE, dp, None, s)), None, None, None
+
+
+def smooth_l1_loss(pred, target, beta=1.0, scale=1.0):
+    """scale * F.smooth_l1_loss(pred, target, beta=beta) -- nn.HuberLoss(delta=1) has the same values."""
+    return _SmoothL1.apply(pred, target, beta, scale)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, alpha, gamma, scale):
+        lib = _lib()
+        z = _chk(logits)
+        B, Cc = z.shape
+        dev = z.device
+        lab = labels.to(dev, torch.int64).contiguous()
+        loss, dz = torch.empty(1, device=dev), torch.empty_like(z)
+        ws = _scratch(dev, max(B, 64), "loss")
+        a = _chk(alpha) if alpha is not None else None
+        L.check(lib.eg_cross_entropy(_ptr(z), _ptr(lab), _ptr(a), float(gamma), float(scale), _ptr(loss), _ptr(dz), B, Cc, _ptr(ws), _stream(dev)),
+                "eg_cross_entropy")
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        s = float(g.reshape(-1)[0])
+        return (dz if s == 1.0 else raw_ew(EW_SCALE, dz, None, s)), None, None, None, None
+
+
+def cross_entropy(logits, labels, scale=1.0):
+    """scale * nn.CrossEntropyLoss()(logits, labels)"""
+    return _CrossEntropy.apply(logits, labels, None, -1.0, scale)
+
+
+def focal_loss(logits, labels, alpha, gamma=2.0, scale=1.0):
+    """scale * FocalLoss(alpha, gamma, 'mean') of train_audio_classifier_K_fold.py:89-105.  `alpha` multiplies the per-sample
+    loss vector exactly as upstream's `self.alpha * (1-pt)**self.gamma * ce_loss` does: a scalar, or one weight per SAMPLE
+    (upstream passes a list of 8 class weights, which only broadcasts at batch size 8 -- position-wise, not by label)."""
+    B = logits.shape[0]
+    if not torch.is_tensor(alpha):
+        alpha = torch.tensor([float(alpha)] * B if not isinstance(alpha, (list, tuple)) else [float(a) for a in alpha])
+    alpha = alpha.to(logits.device, torch.float32).reshape(-1)
+    if alpha.numel() == 1:
+        alpha = alpha.expand(B).contiguous()
+    if alpha.numel() != B:
+        raise ValueError(f"focal_loss: alpha has {alpha.numel()} entries for a batch of {B} (it multiplies the per-sample losses)")
+    return _CrossEntropy.apply(logits, labels, alpha, float(gamma), scale)

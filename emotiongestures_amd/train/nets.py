@@ -1,0 +1,176 @@
+"""Train-mode forwards of the reference's networks, composed from the HIP operators of `functional.py`.
+
+* `emotion_net_forward`  -- EmotionNet (model/audio_emotion_classifer.py:17-49), the one network the reference ships a training
+  loop for (train_audio_classifier_K_fold.py:109-200).
+* `generator_forward`    -- Transformer.forward of Full_model/Models_spatial_memory.py:566-616 in train() mode: BatchNorm on
+  batch statistics (running buffers updated), every other layer as in eval.  Dropout layers act with p = 0 (the
+  gradient-parity configuration); stochastic dropout masks are not implemented.
+
+The modules are the parameter trees of `emotiongestures_amd.modules` (same names / shapes as the reference's state_dict);
+activations are NHWC in the audio tower and row-major [rows, features] elsewhere.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from . import functional as F
+
+
+def _fork_n(x, n):
+    """n uses of x, gradients summed pairwise on the HIP add kernel."""
+    outs = []
+    cur = x
+    for _ in range(n - 1):
+        a, cur = F.fork(cur)
+        outs.append(a)
+    outs.append(cur)
+    return outs
+
+
+# ---- audio tower (Full_model/ResNetSE34V2.py:62-74, ResNetBlocks.py:21-37) -------------------------------------------------
+def se_basic_block(blk, x):
+    xa, xb = F.fork(x)
+    out = F.conv3x3(xa, blk.conv1.weight, None, blk.stride, relu=True)          # conv1 -> ReLU -> bn1 (ReLU precedes BN, :24-26)
+    out = F.batch_norm(out, blk.bn1)
+    out = F.batch_norm(F.conv3x3(out, blk.conv2.weight), blk.bn2)
+    out = F.se_layer(out, blk.se.fc[0], blk.se.fc[2])
+    if blk.downsample is not None:
+        res = F.batch_norm(F.conv1x1(xb, blk.downsample[0].weight, blk.stride), blk.downsample[1])
+    else:
+        res = xb
+    return F.relu(F.add(out, res))
+
+
+def resnetse_forward(enc, spec):
+    """spec [B,H,W] -> NHWC feature map."""
+    x = spec.unsqueeze(-1).contiguous()
+    x = F.batch_norm(F.conv3x3(x, enc.conv1.weight, enc.conv1.bias, 1, relu=True), enc.bn1)
+    for layer in (enc.layer1, enc.layer2, enc.layer3, getattr(enc, "layer4", ())):
+        for blk in layer:
+            x = se_basic_block(blk, x)
+    return x
+
+
+def emotion_net_forward(model, mfcc):
+    """EmotionNet.forward in train() mode -> logits [B, 8]."""
+    feat = resnetse_forward(model.emotion_encoder, mfcc)                        # [B,16,16,256]
+    h = feat.permute(0, 3, 1, 2).reshape(feat.shape[0], -1)                     # feature.view(B,-1) of the NCHW map (:44)
+    for i in (0, 2, 4, 6, 8):
+        lin = model.emotion_eocder_fc[i]
+        h = F.linear(h, lin.weight, lin.bias, relu=True)
+    return F.linear(h, model.last_fc.weight, model.last_fc.bias)
+
+
+# ---- transformer blocks (Full_model/SubLayers.py:30-59,74-84; Layers.py:18-22,50-58) --------------------------------------
+def mha_forward(m, xq, xk, xv):
+    """MultiHeadAttention.forward: LN(fc(attention(q Wq, k Wk, v Wv)) + q).  xq / xk / xv are separate uses of the inputs."""
+    xq_p, xq_r = F.fork(xq)
+    q = F.linear(xq_p, m.w_qs.weight)
+    k = F.linear(xk, m.w_ks.weight)
+    v = F.linear(xv, m.w_vs.weight)
+    o = F.attention(q, k, v, m.n_head)
+    return F.layer_norm(F.add(F.linear(o, m.fc.weight), xq_r), m.layer_norm)
+
+
+def ffn_forward(f, x):
+    xa, xr = F.fork(x)
+    h = F.linear(xa, f.w_1.weight, f.w_1.bias, relu=True)
+    return F.layer_norm(F.add(F.linear(h, f.w_2.weight, f.w_2.bias), xr), f.layer_norm)
+
+
+class _AddRows(torch.autograd.Function):
+    """x + table[row % period] (positional table is a buffer: gradient passes straight through)."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        return ops.add_rows(x.detach().contiguous(), table, period=x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def encoder_forward(enc, x):
+    x = _AddRows.apply(x, enc.position_enc.pos_table[0, :x.shape[1]].contiguous())
+    for layer in enc.layer_stack:
+        a, b, c = _fork_n(x, 3)
+        x = ffn_forward(layer.pos_ffn, mha_forward(layer.slf_attn, a, b, c))
+    return x
+
+
+def decoder_forward(dec, trg, enc_out):
+    uses = _fork_n(enc_out, 2 * len(dec.layer_stack))
+    x = trg
+    for i, layer in enumerate(dec.layer_stack):                                  # enc_attn + pos_ffn only (Layers.py:50-58)
+        x = ffn_forward(layer.pos_ffn, mha_forward(layer.enc_attn, x, uses[2 * i], uses[2 * i + 1]))
+    return x
+
+
+def _seq_linear(seq, idx, x, relu_between=False):
+    for j, i in enumerate(idx):
+        x = F.linear(x, seq[i].weight, seq[i].bias, relu=relu_between and j + 1 < len(idx))
+    return x
+
+
+def prior_encoder_forward(pe, prior):
+    """Prior_MemoryEncoder.forward (Models_spatial_memory.py:378-390), spatial variant: SP_Memory_Net_v2 returns its input
+    (:276-295), so its parameters receive no gradient and it is not evaluated here (its BatchNorm running buffers stay untouched)."""
+    x = prior.transpose(1, 2).contiguous()                                       # [B, L = pose_dim, C = prior frames]
+    c0, b0, c1, b1 = pe.pred_conv[0], pe.pred_conv[2], pe.pred_conv[3], pe.pred_conv[5]
+    h = F.batch_norm(F.relu(F.conv1d_cl(x, c0.weight, c0.bias, 1, 1, 1)), b0)
+    h = F.batch_norm(F.relu(F.conv1d_cl(h, c1.weight, c1.bias, 1, 1, 1)), b1)
+    out = torch.cat((prior, h.transpose(1, 2)), 1)                               # [B, frames, pose_dim]
+    return _seq_linear(pe.post_header, (0, 2), out.contiguous())
+
+
+def audio_encoder_forward(ae, spec):
+    """Audio_ResNetEncoder.forward (Models_spatial_memory.py:118-133)."""
+    x = resnetse_forward(ae.feat_extractor, spec)                                # [B,32,31,128]
+    x = F.batch_norm(F.conv3x3(x, ae.final_conv1.weight, ae.final_conv1.bias), ae.bn1)          # [B,H,W,F]
+    B, H, W, Fr = x.shape
+    x = x.permute(0, 3, 1, 2).reshape(B, Fr, H * W)                              # channel c becomes time step c (:124)
+    return F.linear(F.linear(x, ae.fc1.weight, ae.fc1.bias), ae.fc2.weight, ae.fc2.bias)
+
+
+def text_encoder_forward_nograd(te, text):
+    """TextEncoderTCN.forward (Models_spatial_memory.py:171-179) on the inference kernels, without gradient: the returned
+    text_embedding feeds neither the pose nor the emotion head, so the reference's loss never reaches these parameters."""
+    with torch.no_grad():
+        lv = [(b.conv1.weight_v, b.conv1.weight_g, b.conv1.bias, b.conv2.weight_v, b.conv2.weight_g, b.conv2.bias) for b in te.tcn.network]
+        ver = tuple(t._version for tup in lv for t in tup) + (str(text.device),)
+        cache = getattr(te, "_train_pack", None)
+        if cache is None or cache[0] != ver:
+            cache = (ver, ops.pack_tcn_weights(lv, text.device))
+            te._train_pack = cache
+        emb = te.embedding.weight.detach()[text].contiguous()                   # gather (data movement)
+        y = ops.tcn_forward(emb, cache[1], len(lv), "f32")                       # [B, L, C]
+        B, Ln, Cc = y.shape
+        fc = te.fc1[0]
+        z = F.raw_linear(y.transpose(1, 2).reshape(B * Cc, Ln).contiguous(), fc.weight.detach(), fc.bias.detach())       # Linear over time
+        z = z.view(B, Cc, Ln).transpose(1, 2).reshape(B * Ln, Cc).contiguous()
+        return F.raw_linear(z, te.decoder.weight.detach(), te.decoder.bias.detach()).view(B, Ln, -1)
+
+
+def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_feature=None):
+    """Transformer.forward in train() mode (spatial variant).  The text branch does not feed the pose or the emotion head
+    (:577,616), so it is evaluated without gradient on the inference kernels."""
+    if model._variant != "spatial":
+        raise NotImplementedError("train-mode forward: Models_spatial_memory variant only (TM_Memory_Net couples the batch)")
+    text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
+    spectrum_feature = audio_encoder_forward(model.audio_encoder, input_spectrum)
+    prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
+    sa, sb = F.fork(spectrum_feature)
+    emotion_feature = _seq_linear(model.emotion_proj, (0, 2), sa)
+    semantic_feature = _seq_linear(model.semantic_proj, (0, 2), sb)
+    B = emotion_feature.shape[0]
+    if sampled_emotion_feature is None:
+        e_cls, e_fus = F.fork(emotion_feature)
+    else:
+        e_cls, e_fus = emotion_feature, sampled_emotion_feature
+    emotion_prediction = _seq_linear(model.emotion_classifer_header, (0, 2, 4, 6), e_cls.reshape(B, -1), relu_between=True)
+    fusion = _seq_linear(model.fusion_proj, (0, 2), F.add(e_fus, semantic_feature), relu_between=True)
+    enc_out = encoder_forward(model.encoder, fusion)
+    dec_out = decoder_forward(model.decoder, prior, enc_out)
+    pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out)
+    return pose, emotion_feature, semantic_feature, emotion_prediction, text_embedding

@@ -1,0 +1,228 @@
+"""Optimiser state and data-parallel gradient reduction for the training path.
+
+* `flatten_parameters(model)`: every trainable parameter becomes a view of ONE contiguous fp32 buffer, and its `.grad` a view of
+  a second one (same offsets, 16-byte aligned slices), so that the optimiser is one kernel launch and the gradient all-reduce
+  runs on a few large contiguous buckets (RCCL over xGMI is per-link bound: few large messages, MI355X-first).
+* `FlatAdam`: torch.optim.Adam's update (betas, eps, L2 weight decay added to the gradient; train_audio_classifier_K_fold.py:128
+  uses lr, betas=(0.5, 0.999), weight_decay=1e-5) as one fused HIP kernel over the flat buffers (eg_adam_step).
+* `GradBuckets`: clip-level data parallelism: gradients are summed across ranks with `all_reduce` on ~25 MB
+  contiguous buckets of the flat gradient buffer, launched from the LAST parameters backwards (the order backward produces
+  them) on a side stream so that the reduction of finished buckets overlaps the rest of the backward pass; the result is
+  divided by the world size in the Adam kernel's gradient (the `grad_scale` argument).  BatchNorm statistics stay per replica,
+  as with the reference's plain nn.BatchNorm under nn.DataParallel.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import _lib as L
+from ..engine import _ptr, _stream
+
+
+class FlatParams:
+    def __init__(self, params: List[torch.nn.Parameter], flat: torch.Tensor, grad: torch.Tensor, offsets: List[int]):
+        self.params, self.flat, self.grad, self.offsets = params, flat, grad, offsets
+        self.index = {id(p): i for i, p in enumerate(params)}
+        self.has_grad = [False] * len(params)       # set by collect_one: parameters autograd produced a gradient for
+
+    def zero_grad(self):
+        """Gradients start from None: autograd then hands each parameter a fresh gradient tensor (no torch add into an old one);
+        `collect` / the bucket hooks copy it into the flat buffer."""
+        for p in self.params:
+            p.grad = None
+
+    def collect_one(self, p: torch.nn.Parameter):
+        o = self.offsets[self.index[id(p)]]
+        n = p.numel()
+        sl = self.grad[o:o + n]
+        i = self.index[id(p)]
+        if p.grad is None:
+            sl.zero_()                                   # keeps the flat buffer (and the all-reduce) well defined
+            self.has_grad[i] = False
+            return
+        self.has_grad[i] = True
+        if p.grad.data_ptr() != sl.data_ptr():
+            sl.copy_(p.grad.reshape(-1))                 # data movement into the flat buffer
+            p.grad = sl.view(p.shape)
+
+    def collect(self):
+        for p in self.params:
+            self.collect_one(p)
+
+
+def flatten_parameters(model: torch.nn.Module) -> FlatParams:
+    """Re-home every trainable parameter inside one contiguous buffer (values preserved) and allocate the matching flat
+    gradient buffer (same offsets, 16-byte aligned slices)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    if not params:
+        raise ValueError("no trainable parameters")
+    dev = params[0].device
+    offsets, total = [], 0
+    for p in params:
+        offsets.append(total)
+        total += (p.numel() + 3) // 4 * 4                 # 16-byte aligned slices
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    grad = torch.zeros(total, dtype=torch.float32, device=dev)
+    for p, o in zip(params, offsets):
+        n = p.numel()
+        flat[o:o + n].copy_(p.detach().reshape(-1))
+        p.data = flat[o:o + n].view(p.shape)
+        p.grad = None
+    return FlatParams(params, flat, grad, offsets)
+
+
+class FlatAdam:
+    def __init__(self, fp: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if not fp.flat.is_cuda:
+            raise L.EgError("FlatAdam: the optimiser kernel runs only on a GPU (no CPU fallback)")
+        self.fp, self.lr, self.betas, self.eps, self.weight_decay = fp, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(fp.flat)
+        self.exp_avg_sq = torch.zeros_like(fp.flat)
+        self.t = 0
+
+    def step(self, collected: bool = False):
+        fp = self.fp
+        if not collected:
+            fp.collect()
+        self.t += 1
+        lib = L.load()
+        # torch.optim.Adam skips parameters whose .grad is None (no weight decay, no moment update): one launch per contiguous
+        # run of parameters that did receive a gradient (a handful: the text branch / unused decoder self-attention are skipped)
+        runs, lo = [], None
+        for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
+            if fp.has_grad[i]:
+                if lo is None:
+                    lo = o
+                hi = o + (p.numel() + 3) // 4 * 4
+            elif lo is not None:
+                runs.append((lo, hi))
+                lo = None
+        if lo is not None:
+            runs.append((lo, hi))
+        for lo, hi in runs:
+            hi = min(hi, fp.flat.numel())
+            sl = slice(lo, hi)
+            L.check(lib.eg_adam_step(_ptr(fp.flat[sl]), _ptr(fp.grad[sl]), _ptr(self.exp_avg[sl]), _ptr(self.exp_avg_sq[sl]), hi - lo,
+                                     float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                     self.t, _stream(fp.flat.device)), "eg_adam_step")
+
+    def zero_grad(self):
+        self.fp.zero_grad()
+
+
+class GradBuckets:
+    """Bucketed gradient all-reduce over the flat gradient buffer (sum across ranks, then scale by 1/world)."""
+
+    def __init__(self, fp: FlatParams, bucket_mb: float = 25.0, group=None):
+        import torch.distributed as dist
+        self.fp, self.group = fp, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        per = max(1, int(bucket_mb * (1 << 20) / 4))
+        n = fp.grad.numel()
+        # bucket boundaries on parameter boundaries, walking from the LAST parameter (whose gradient is ready first) backwards
+        self.buckets = []
+        end = n
+        for o in reversed(fp.offsets):
+            if end - o >= per:
+                self.buckets.append((o, end))
+                end = o
+        if end > 0:
+            self.buckets.append((0, end))
+        self.param_bucket = [self.bucket_of(o) for o in fp.offsets]
+        self.members = [sum(1 for b in self.param_bucket if b == i) for i in range(len(self.buckets))]
+        self.stream = torch.cuda.Stream(fp.grad.device) if fp.grad.is_cuda else None
+        self._pending: Optional[List[int]] = None
+        self._handles = []
+        self._unused: Optional[set] = None      # parameters that received no gradient in the first backward (static graph)
+        self.launched: List[int] = []           # bucket launch order of the last backward (tests)
+
+    def bucket_of(self, offset: int) -> int:
+        for i, (lo, hi) in enumerate(self.buckets):
+            if lo <= offset < hi:
+                return i
+        raise IndexError(offset)
+
+    # ---- overlapped mode: hooks launch a bucket's all-reduce as soon as its last gradient has been produced ----
+    def attach(self):
+        """Register post-accumulate-grad hooks: each parameter's fresh gradient is copied into the flat buffer; when a bucket
+        is complete its all-reduce starts on the side stream while backward continues (call `begin()` before every backward
+        and `finish()` after it)."""
+        for p in self.fp.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+        return self
+
+    def begin(self):
+        self._pending = list(self.members)
+        self._seen = set()
+        self._handles = []
+        self.launched = []
+        if self._unused:            # known from the first step: their (zero) slices are ready before backward starts
+            for i in self._unused:
+                self.fp.collect_one(self.fp.params[i])
+                self._seen.add(i)
+                self._pending[self.param_bucket[i]] -= 1
+
+    def _hook(self, p):
+        if self._pending is None:
+            return
+        self.fp.collect_one(p)
+        i = self.fp.index[id(p)]
+        self._seen.add(i)
+        b = self.param_bucket[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        import torch.distributed as dist
+        self.launched.append(b)
+        if self.world == 1:
+            return
+        lo, hi = self.buckets[b]
+        g = self.fp.grad[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(g.device))
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self._handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """After backward: parameters that received no gradient are zero-filled, their buckets reduced, everything scaled by
+        1/world; the caller's stream then owns a complete averaged flat gradient (`FlatAdam.step(collected=True)`)."""
+        missing = [i for i in range(len(self.fp.params)) if i not in self._seen]
+        if self._unused is None:
+            self._unused = set(missing)                 # the networks here have a static graph (e.g. the text branch never gets a gradient)
+        for i in missing:
+            self.fp.collect_one(self.fp.params[i])      # p.grad is None here: zero slice
+            self._pending[self.param_bucket[i]] -= 1
+        for b, left in enumerate(self._pending):
+            if left == 0 and b not in self.launched:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream(self.fp.grad.device).wait_stream(self.stream)
+        self._pending = None
+        self._scale()
+
+    # ---- simple mode: everything after backward ----
+    def all_reduce(self):
+        import torch.distributed as dist
+        self.fp.collect()
+        if self.world > 1:
+            for lo, hi in self.buckets:
+                dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self._scale()
+
+    def _scale(self):
+        if self.world == 1:
+            return
+        g = self.fp.grad
+        if g.is_cuda:
+            lib = L.load()
+            L.check(lib.eg_elementwise(_ptr(g), None, _ptr(g), g.numel(), 5, 1.0 / self.world, _stream(g.device)), "eg_elementwise")
+        else:
+            g.mul_(1.0 / self.world)                    # CPU only exists for the gloo test of the bucket logic

@@ -368,7 +368,8 @@ int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, f
 int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
                           const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
                           int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t dk_dim, void* stream);
-/* losses: scale * mean smooth-L1 (beta); scale * mean CE / focal(alpha, gamma >= 0) (train_audio_classifier_K_fold.py:95-105) */
+/* losses: scale * mean smooth-L1 (beta); scale * mean CE / focal(alpha[b] per sample or NULL, gamma >= 0)
+ * (train_audio_classifier_K_fold.py:95-105: `alpha * (1-pt)**gamma * ce` broadcasts alpha over the batch axis) */
 int eg_smooth_l1(const float* pred, const float* target, float* loss, float* dpred, int64_t n, float beta, float scale, float* workspace,
                  void* stream);
 int eg_cross_entropy(const float* logits, const int64_t* labels, const float* alpha, float gamma, float scale, float* loss, float* dlogits,

@@ -52,8 +52,26 @@ class GenCfg:
 # small helpers
 # --------------------------------------------------------------------------------------------
 
+_BN_TRAINING = False
+
+
+class bn_training:
+    """Context: BatchNorm layers use BATCH statistics, as nn.BatchNorm does in train() mode (the configuration of the gradient
+    goldens: model.train() with every Dropout p forced to 0).  Running buffers are not updated by the oracle."""
+
+    def __enter__(self):
+        global _BN_TRAINING
+        self.prev, _BN_TRAINING = _BN_TRAINING, True
+
+    def __exit__(self, *a):
+        global _BN_TRAINING
+        _BN_TRAINING = self.prev
+
+
 def _bn(sd: SD, p: str, x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """Eval-mode BatchNorm{1,2}d: running statistics, affine (torch default eps 1e-5)."""
+    """BatchNorm{1,2}d: eval mode = running statistics + affine (torch default eps 1e-5); inside `bn_training()` = batch statistics."""
+    if _BN_TRAINING:
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
     shape = [1, -1] + [1] * (x.dim() - 2)
     inv = torch.rsqrt(sd[p + ".running_var"] + eps)
     return (x - sd[p + ".running_mean"].view(shape)) * (inv * sd[p + ".weight"]).view(shape) \
@@ -276,6 +294,25 @@ def generator_forward(sd: SD, cfg: GenCfg, spec: torch.Tensor, text: torch.Tenso
     if taps is not None:
         taps.update(audio_feat=feat, prior_enc=pr, fusion=fusion)
     return pose, emo, sem, emo_pred, text_embedding
+
+
+def generator_train_loss(sd: SD, cfg: GenCfg, spec, text, prior, target_pose, label):
+    """One training objective of BASELINE configs[2] (SURVEY.md §8d cfg 3): 100 * SmoothL1/Huber(pose, target) + CE(emotion
+    logits, label), model in train() mode (batch-statistics BatchNorm), dropout p = 0.  Returns (loss, pose, emotion logits)."""
+    with bn_training():
+        pose, _emo, _sem, pred, _txt = generator_forward(sd, cfg, spec, text, prior, None)
+    loss = 100.0 * F.smooth_l1_loss(pose, target_pose) + F.cross_entropy(pred, label)
+    return loss, pose, pred
+
+
+def emotion_net_train_loss(sd: SD, mfcc, label, alpha, gamma: float = 2.0):
+    """train_audio_classifier_K_fold.py:163-168 with FocalLoss :89-105: 100 * mean(alpha * (1 - pt)^gamma * CE), alpha a
+    per-sample weight vector (that is how `self.alpha * ...` broadcasts), EmotionNet in train() mode."""
+    with bn_training():
+        logits = emotion_net(sd, mfcc)
+    ce = F.cross_entropy(logits, label, reduction="none")
+    pt = torch.exp(-ce)
+    return 100.0 * torch.mean(alpha * (1 - pt) ** gamma * ce), logits
 
 
 # --------------------------------------------------------------------------------------------

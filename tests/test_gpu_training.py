@@ -1,0 +1,264 @@
+"""Training path on the GPU: every forward and backward kernel of emotiongestures_amd/train against the CPU oracle's autograd
+(oracle/emogest_oracle.py, pinned to the reference's gradients by tests/test_training_oracle.py + tests/golden/grads.npz).
+Tolerance: per-parameter relative L2 of the gradient <= 1e-4 (fp32 MFMA path)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import GOLDEN, ROOT
+from emotiongestures_amd.builders import build_mirror
+from emotiongestures_amd.synth import hash_unit, load_synth_weights, synth_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def T(key, shape, lo=-1.0, hi=1.0, seed=0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((lo + (hi - lo) * hash_unit(key, n, seed)).astype(np.float32).reshape(shape))
+
+
+# ---- operator level ---------------------------------------------------------------------------------------------------------
+def _grad_check(fn_hip, fn_ref, inputs, tol=2e-5):
+    """fn(*tensors) -> output; compares outputs and gradients w.r.t. every input for upstream gradient = fixed pseudo-random."""
+    xs = [t.clone().to(DEV).requires_grad_(True) for t in inputs]
+    rs = [t.clone().requires_grad_(True) for t in inputs]
+    y, r = fn_hip(*xs), fn_ref(*rs)
+    assert rel(y, r) < tol, f"forward {rel(y, r):.2e}"
+    g = T("upstream", tuple(r.shape), seed=9)
+    y.backward(g.to(DEV))
+    r.backward(g)
+    for i, (a, b) in enumerate(zip(xs, rs)):
+        assert a.grad is not None, f"input {i} has no gradient"
+        assert rel(a.grad, b.grad) < tol, f"grad of input {i}: {rel(a.grad, b.grad):.2e}"
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(68, 512, 512, False), (7, 126, 126, True), (5, 17408, 512, True), (300, 992, 34, False)])
+def test_linear_forward_backward(M, K, N, relu):
+    from emotiongestures_amd.train import functional as F
+    x, w, b = T("x", (M, K)), T("w", (N, K), -0.05, 0.05), T("b", (N,))
+    _grad_check(lambda x, w, b: F.linear(x, w, b, relu=relu), lambda x, w, b: (TF.relu if relu else (lambda t: t))(TF.linear(x, w, b)), [x, w, b])
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s,bias,relu", [(2, 16, 20, 32, 32, 1, False, True), (2, 17, 13, 32, 64, 2, False, False),
+                                                      (1, 12, 12, 64, 64, 1, False, False), (2, 8, 8, 128, 128, 1, False, True),
+                                                      (2, 9, 11, 128, 34, 1, True, False), (2, 24, 20, 1, 32, 1, True, True),
+                                                      (1, 8, 8, 128, 256, 2, False, False), (1, 6, 6, 256, 256, 1, False, False)])
+def test_conv3x3_forward_backward(B, H, W, Ci, Co, s, bias, relu):
+    from emotiongestures_amd.train import functional as F
+    x, w = T("x", (B, H, W, Ci)), T("w", (Co, Ci, 3, 3), -0.1, 0.1)
+    ins = [x, w] + ([T("b", (Co,))] if bias else [])
+
+    def ref(x, w, b=None):
+        y = TF.conv2d(x.permute(0, 3, 1, 2), w, b, stride=s, padding=1)
+        return (TF.relu(y) if relu else y).permute(0, 2, 3, 1)
+    _grad_check(lambda x, w, b=None: F.conv3x3(x, w, b, s, relu), ref, ins)
+
+
+def test_conv1x1_stride2_and_conv1d():
+    from emotiongestures_amd.train import functional as F
+    x, w = T("x", (2, 9, 12, 32)), T("w", (64, 32, 1, 1), -0.2, 0.2)
+    _grad_check(lambda x, w: F.conv1x1(x, w, 2), lambda x, w: TF.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2).permute(0, 2, 3, 1), [x, w])
+    for (Ci, Co, k, st, pad, L) in [(4, 30, 3, 1, 1, 126), (30, 30, 3, 1, 1, 126), (16, 8, 5, 2, 2, 64)]:
+        x, w, b = T("x", (3, L, Ci)), T("w", (Co, Ci, k), -0.3, 0.3), T("b", (Co,))
+        _grad_check(lambda x, w, b: F.conv1d_cl(x, w, b, st, pad, 1),
+                    lambda x, w, b: TF.conv1d(x.transpose(1, 2), w, b, stride=st, padding=pad).transpose(1, 2), [x, w, b])
+
+
+def test_batchnorm_layernorm_se_attention():
+    from emotiongestures_amd.train import functional as F
+    from types import SimpleNamespace as NS
+    # BatchNorm (train mode) incl. running statistics
+    x, g, b = T("x", (3, 10, 12, 64), -2, 3), T("g", (64,), 0.5, 1.5), T("b", (64,))
+    bn = NS(weight=None, bias=None, running_mean=T("rm", (64,)).to(DEV), running_var=T("rv", (64,), 0.5, 1.5).to(DEV),
+            num_batches_tracked=torch.tensor(0))
+    rm, rv = bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()
+
+    def hip(x, g, b):
+        bn.weight, bn.bias = g, b
+        return F.batch_norm(x, bn)
+    _grad_check(hip, lambda x, g, b: TF.batch_norm(x.permute(0, 3, 1, 2), rm, rv, g, b, True, 0.1, 1e-5).permute(0, 2, 3, 1), [x, g, b])
+    assert rel(bn.running_mean, rm) < 1e-6 and rel(bn.running_var, rv) < 1e-6 and int(bn.num_batches_tracked) == 1
+    # LayerNorm
+    x, g, b = T("x", (68, 512), -3, 3), T("g", (512,), 0.5, 1.5), T("b", (512,))
+    ln = NS(weight=None, bias=None, eps=1e-6)
+
+    def hip_ln(x, g, b):
+        ln.weight, ln.bias = g, b
+        return F.layer_norm(x, ln)
+    _grad_check(hip_ln, lambda x, g, b: TF.layer_norm(x, (512,), g, b, 1e-6), [x, g, b])
+    # SE layer
+    y, w1, b1, w2, b2 = T("y", (2, 6, 7, 64)), T("w1", (8, 64), -0.3, 0.3), T("b1", (8,)), T("w2", (64, 8), -0.3, 0.3), T("b2", (64,))
+
+    def ref_se(y, w1, b1, w2, b2):
+        s = torch.sigmoid(TF.linear(TF.relu(TF.linear(y.mean(dim=(1, 2)), w1, b1)), w2, b2))
+        return y * s[:, None, None, :]
+    _grad_check(lambda y, w1, b1, w2, b2: F._SELayer.apply(y, w1, b1, w2, b2), ref_se, [y, w1, b1, w2, b2])
+    # attention (ragged Lq != Lk)
+    for (B, Hh, Lq, Lk) in [(2, 8, 34, 34), (1, 2, 20, 60)]:
+        q, k, v = T("q", (B, Lq, Hh * 64), -2, 2), T("k", (B, Lk, Hh * 64), -2, 2), T("v", (B, Lk, Hh * 64))
+
+        def ref_att(q, k, v):
+            sp = lambda t, L_: t.view(B, L_, Hh, 64).transpose(1, 2)
+            a = torch.softmax(torch.matmul(sp(q, Lq) / 8.0, sp(k, Lk).transpose(2, 3)), dim=-1)
+            return torch.matmul(a, sp(v, Lk)).transpose(1, 2).reshape(B, Lq, Hh * 64)
+        _grad_check(lambda q, k, v: F.attention(q, k, v, Hh), ref_att, [q, k, v])
+
+
+def test_losses_and_fork():
+    from emotiongestures_amd.train import functional as F
+    p, t = T("p", (2, 34, 126), -3, 3), T("t", (2, 34, 126))
+    _grad_check(lambda p: F.smooth_l1_loss(p, t.to(DEV), 1.0, 100.0), lambda p: (100.0 * TF.smooth_l1_loss(p, t)).reshape(1), [p])
+    z = T("z", (6, 8), -4, 4)
+    lab = torch.tensor([0, 7, 3, 3, 1, 5])
+    _grad_check(lambda z: F.cross_entropy(z, lab), lambda z: TF.cross_entropy(z, lab).reshape(1), [z])
+    alpha = torch.tensor([0.2, 1.0, 2.0, 0.7, 1.0, 3.0])
+
+    def focal(z):
+        ce = TF.cross_entropy(z, lab, reduction="none")
+        return (100.0 * torch.mean(alpha * (1 - torch.exp(-ce)) ** 2 * ce)).reshape(1)
+    _grad_check(lambda z: F.focal_loss(z, lab, alpha, 2.0, 100.0), focal, [z])
+    x = T("x", (5, 16))
+
+    def f_hip(x):
+        a, b = F.fork(x)
+        return F.add(F.relu(a), F.leaky_relu(b, 0.2))
+    _grad_check(f_hip, lambda x: TF.relu(x) + TF.leaky_relu(x, 0.2), [x])
+
+
+def test_adam_matches_torch_optim():
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+    r = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+    r.load_state_dict(m.state_dict())
+    m.to(DEV)
+    fp = flatten_parameters(m)
+    opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)            # train_audio_classifier_K_fold.py:128
+    ropt = torch.optim.Adam(r.parameters(), lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    for step in range(5):
+        x = T("x", (4, 33), seed=step)
+        opt.zero_grad(); ropt.zero_grad()
+        (m(x.to(DEV)) ** 2).sum().backward()        # torch ops only to PRODUCE gradients for this optimiser test
+        (r(x) ** 2).sum().backward()
+        opt.step(); ropt.step()
+    for a, b in zip(m.parameters(), r.parameters()):
+        assert rel(a, b) < 1e-6
+
+
+# ---- network level -----------------------------------------------------------------------------------------------------------
+def _compare_param_grads(model, sd_ref, tol, skip_none=True):
+    worst, n = 0.0, 0
+    for k, p in model.named_parameters():
+        gr = sd_ref[k].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k}: oracle has no gradient, the HIP path does"
+            continue
+        assert p.grad is not None, f"{k}: no gradient on the HIP path"
+        e = rel(p.grad, gr)
+        worst = max(worst, e)
+        n += 1
+        assert e < tol, f"{k}: gradient rel-L2 {e:.2e}"
+    return worst, n
+
+
+def test_generator_train_step_gradients_match_oracle():
+    """One training step of BASELINE configs[2] at B = 2 (TED shapes): loss = 100 smooth_l1(pose) + CE(emotion), train-mode
+    BatchNorm, dropout p = 0.  Every parameter gradient against the oracle's autograd; loss / outputs against the reference golden."""
+    from emotiongestures_amd.train import functional as F
+    from oracle import emogest_oracle as O
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    batch, seed = [int(v) for v in z["gen/meta"]]
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=seed, precision="f32")
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    target = torch.from_numpy((hash_unit("train.target_pose", batch * 34 * 126, seed) - 0.5).astype(np.float32).reshape(batch, 34, 126))
+    label = torch.from_numpy(inp["label"]).argmax(1)
+    loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                                          torch.from_numpy(inp["pre_pose"]), target, label)
+    loss_ref.backward()
+    model.to(DEV).train()
+    pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
+                                      torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+    loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
+    loss.backward()
+    assert abs(float(loss) - float(z["gen/loss"])) / float(z["gen/loss"]) < 1e-5            # vs the REFERENCE's loss
+    assert np.abs(pose.detach().cpu().numpy() - z["gen/pose"]).max() < 1e-4
+    assert np.abs(pred.detach().cpu().numpy() - z["gen/emotion_prediction"]).max() < 1e-4
+    bn = model.audio_encoder.feat_extractor.layer2[0].bn1                                   # running statistics after one train forward
+    assert np.abs(bn.running_mean.cpu().numpy() - z["gen/bn_running_mean"]).max() < 1e-5
+    assert np.abs(bn.running_var.cpu().numpy() - z["gen/bn_running_var"]).max() < 1e-5 * max(1.0, float(z["gen/bn_running_var"].max()))
+    worst, n = _compare_param_grads(model, sd, 1e-4)
+    assert n == 260
+    print(f"generator: {n} parameter gradients, worst rel-L2 vs oracle {worst:.2e}")
+    assert txt is not None and tuple(txt.shape) == (batch, 60, 512)
+
+
+def test_emotion_net_train_step_and_adam():
+    """The one training loop the reference ships (train_audio_classifier_K_fold.py:155-175): EmotionNet in train() mode,
+    100 x FocalLoss, Adam(lr, betas=(0.5, 0.999), weight_decay=1e-5) -- gradients and the updated parameters vs the oracle / torch."""
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    from oracle import emogest_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_emotion_net import emotion_input
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    net = load_synth_weights(EmotionNet(precision="f32"), 31)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    x = torch.from_numpy(emotion_input(2, 31))
+    label, alpha = torch.from_numpy(z["emo/label"]), torch.from_numpy(z["emo/alpha"])
+    loss_ref, _ = O.emotion_net_train_loss(sd, x, label, alpha, 2.0)
+    loss_ref.backward()
+    net.to(DEV).train()
+    fp = flatten_parameters(net)
+    opt = FlatAdam(fp, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    opt.zero_grad()
+    logits = net(x.to(DEV))
+    loss = F.focal_loss(logits, label.to(DEV), alpha, 2.0, 100.0)
+    loss.backward()
+    assert abs(float(loss) - float(z["emo/loss"])) / float(z["emo/loss"]) < 1e-5            # vs the REFERENCE's loss
+    assert np.abs(logits.detach().cpu().numpy() - z["emo/logits"]).max() < 1e-4
+    worst, n = _compare_param_grads(net, sd, 1e-4)
+    print(f"EmotionNet: {n} parameter gradients, worst rel-L2 vs oracle {worst:.2e}")
+    # one Adam step vs torch.optim.Adam on the oracle's tensors
+    params = [sd[k] for k, _ in net.named_parameters()]
+    ropt = torch.optim.Adam(params, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    ropt.step()
+    opt.step()
+    for (k, p), r in zip(net.named_parameters(), params):
+        assert float((p.detach().cpu() - r.detach()).abs().max()) < 2e-6, k          # steps are ~lr = 1e-4 in size
+    # a second step runs (loss finite, parameters still views of the flat buffer)
+    opt.zero_grad()
+    loss2 = F.focal_loss(net(x.to(DEV)), label.to(DEV), alpha, 2.0, 100.0)
+    loss2.backward()
+    opt.step()
+    assert np.isfinite(float(loss2))
+    assert all(p.data_ptr() == fp.flat.data_ptr() + 4 * o for p, o in zip(fp.params, fp.offsets))
+
+
+def test_train_mode_is_refused_elsewhere_and_cpu_is_refused():
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.train import functional as F
+    with pytest.raises(L.EgError):
+        F.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    m = build_mirror("memory", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+    inp = synth_inputs(4, 34, 126, 4, seed=0)
+    with pytest.raises(NotImplementedError):
+        m(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV), torch.from_numpy(inp["pre_pose"]).to(DEV), None)

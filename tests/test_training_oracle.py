@@ -1,0 +1,161 @@
+"""CPU side of the training path: the oracle's autograd (oracle/emogest_oracle.py in bn_training mode) against the gradient
+goldens produced by the reference's own classes (tests/golden/make_golden_grad.py), and the data-parallel bucket logic on
+two gloo ranks.  No GPU, no HIP compute."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from emotiongestures_amd.synth import hash_unit, synth_inputs, synth_state_dict
+
+NS = 64
+
+
+def _sd_with_grad(shapes, seed):
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(shapes, seed).items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    return sd
+
+
+def _check_fingerprints(z, case, sd, tol):
+    nograd = set(z[f"{case}/nograd"].tolist())
+    keys = sorted({k.split("/g/")[1].rsplit("/", 1)[0] for k in z.files if k.startswith(f"{case}/g/")})
+    assert len(keys) > 50
+    worst = 0.0
+    for k in keys:
+        g = sd[k].grad
+        assert g is not None, f"{k}: the reference has a gradient, the oracle none"
+        g = g.reshape(-1).double().numpy()
+        stride = max(1, g.size // NS)
+        ref_norm = float(z[f"{case}/g/{k}/norm"])
+        err = np.linalg.norm(g[::stride][:NS] - z[f"{case}/g/{k}/sample"]) / max(np.linalg.norm(z[f"{case}/g/{k}/sample"]), 1e-30)
+        nerr = abs(np.linalg.norm(g) - ref_norm) / max(ref_norm, 1e-30)
+        worst = max(worst, err, nerr)
+        assert err < tol and nerr < tol, f"{k}: sample rel err {err:.2e}, norm rel err {nerr:.2e}"
+    for k in nograd:
+        if k in sd and sd[k].grad is not None:
+            assert float(sd[k].grad.abs().max()) == 0.0, f"{k}: reference has no gradient"
+    return worst
+
+
+def test_generator_gradients_oracle_vs_reference_golden():
+    from oracle import emogest_oracle as O
+    from emotiongestures_amd.builders import build_mirror
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    batch, seed = [int(v) for v in z["gen/meta"]]
+    sd = {k: v.detach().clone() for k, v in build_mirror("spatial", 34, 126, 4, 4, seed=seed).state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    target = torch.from_numpy((hash_unit("train.target_pose", batch * 34 * 126, seed) - 0.5).astype(np.float32).reshape(batch, 34, 126))
+    label = torch.from_numpy(inp["label"]).argmax(1)
+    loss, pose, pred = O.generator_train_loss(sd, O.GenCfg(), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                              torch.from_numpy(inp["pre_pose"]), target, label)
+    loss.backward()
+    assert abs(loss.item() - float(z["gen/loss"])) / float(z["gen/loss"]) < 1e-5
+    assert np.abs(pose.detach().numpy() - z["gen/pose"]).max() < 1e-4
+    worst = _check_fingerprints(z, "gen", sd, 2e-4)
+    print("generator gradients: worst relative error vs the reference", worst)
+
+
+def test_emotion_net_gradients_oracle_vs_reference_golden():
+    from oracle import emogest_oracle as O
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_emotion_net import emotion_input
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    shapes = {k: tuple(s) for k, s in json.load(open(os.path.join(GOLDEN, "emotion_net_schema.json")))}
+    sd = _sd_with_grad(shapes, 31)
+    x = torch.from_numpy(emotion_input(2, 31))
+    loss, logits = O.emotion_net_train_loss(sd, x, torch.from_numpy(z["emo/label"]), torch.from_numpy(z["emo/alpha"]), 2.0)
+    loss.backward()
+    assert abs(loss.item() - float(z["emo/loss"])) / float(z["emo/loss"]) < 1e-5
+    assert np.abs(logits.detach().numpy() - z["emo/logits"]).max() < 1e-4
+    _check_fingerprints(z, "emo", sd, 2e-4)
+
+
+_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, os.environ["EG_ROOT"])
+    import torch, torch.distributed as dist
+    import torch.nn as nn
+    from emotiongestures_amd.train.optim import GradBuckets, flatten_parameters
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(300, 500), nn.ReLU(), nn.Linear(500, 700), nn.ReLU(), nn.Linear(700, 10))
+    unused = nn.Linear(5, 5)                      # a parameter group that never receives a gradient
+    model.add_module("unused", unused)
+    ref = [p.detach().clone() for p in model.parameters()]
+    fp = flatten_parameters(model)
+    assert all(torch.equal(a, b) for a, b in zip(ref, model.parameters()))          # values preserved, now views of one buffer
+    assert all(p.data_ptr() == fp.flat.data_ptr() + 4 * o for p, o in zip(fp.params, fp.offsets))
+    gb = GradBuckets(fp, bucket_mb=0.5).attach()
+    assert len(gb.buckets) >= 2 and gb.buckets[0][1] == fp.grad.numel() and gb.buckets[-1][0] == 0
+    assert all(lo < hi for lo, hi in gb.buckets) and all(gb.buckets[i][0] == gb.buckets[i + 1][1] for i in range(len(gb.buckets) - 1))
+    x = torch.full((4, 300), float(rank + 1))
+    seq = nn.Sequential(*list(model.children())[:5])
+    for it in range(2):
+        fp.zero_grad()
+        gb.begin()
+        seq(x).sum().backward()
+        gb.finish()
+        # every bucket is reduced exactly once; from the second step on (unused parameters known) in backward order:
+        # the bucket holding the last layers first
+        assert sorted(gb.launched) == list(range(len(gb.buckets))), gb.launched
+        if it == 1:
+            assert gb.launched[0] == 0, gb.launched
+        # expected: mean over ranks of the per-rank gradients
+        mine = [p.grad.detach().clone() if p.grad is not None else None for p in fp.params]
+        assert fp.has_grad == [True] * 6 + [False, False]
+        for p, o in zip(fp.params[:6], fp.offsets):
+            assert p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o            # gradients now live in the flat buffer
+    # reference: recompute both ranks' gradients locally and average
+    acc = None
+    for r in range(world):
+        m2 = nn.Sequential(nn.Linear(300, 500), nn.ReLU(), nn.Linear(500, 700), nn.ReLU(), nn.Linear(700, 10))
+        with torch.no_grad():
+            for a, b in zip(m2.parameters(), ref):
+                a.copy_(b)
+        m2(torch.full((4, 300), float(r + 1))).sum().backward()
+        g = [p.grad for p in m2.parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    for got, want in zip(mine[:6], acc):
+        assert torch.allclose(got, want / world, rtol=1e-5, atol=1e-6)
+    assert mine[6] is None and mine[7] is None and float(fp.grad[fp.offsets[6]:].abs().max()) == 0.0      # unused layer: zero slice, still reduced
+    # simple (non-overlapped) mode gives the same result
+    fp.zero_grad()
+    seq(x).sum().backward()
+    gb._pending = None
+    gb.all_reduce()
+    for p, want in zip(fp.params[:6], acc):
+        assert torch.allclose(p.grad, want / world, rtol=1e-5, atol=1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+def test_gradient_buckets_two_gloo_ranks(tmp_path):
+    """Flat parameter / gradient buffers + bucketed all-reduce (backward order, hooks, unused parameters) on 2 CPU ranks."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{o[-3000:]}"
