@@ -213,19 +213,26 @@ __global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__
 }
 
 // ---- column reductions over rows: two deterministic levels ---------------------------------------------------------------
-// level 1: block (bx, by) sums rows [by*rows_per, ...) of 64 columns -> part[by][2][C]; mode 0: (sum x, sum x*x); mode 1: (sum a, sum a*b)
-__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
-                                                          long rows, int C, long rows_per, int mode) {
+// level 1: block (bx, by) sums rows [by*rows_per, ...) of 64 columns -> part[by][2][C]
+//   mode 0: (sum a, sum a*a)      mode 1: (sum a, sum a*b)      mode 2: (sum a, sum a*(b - mean[c]))      mode 3: (sum (a - mean[c])^2, 0)
+// The centred forms (2, 3) keep BatchNorm exact for channels whose mean is large against their spread (post-ReLU maps):
+// E[x^2] - mean^2 from fp32 partial sums loses ~eps*mean^2/var there (measured: 3e-3 in the input gradient of one block).
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
+                                                          float* __restrict__ part, long rows, int C, long rows_per, int mode) {
     __shared__ float s0[4][64], s1[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const long r0 = (long)blockIdx.y * rows_per, r1 = (r0 + rows_per < rows) ? r0 + rows_per : rows;
     float u = 0.f, v = 0.f;
-    if (c < C)
+    if (c < C) {
+        const float mu = (mode >= 2) ? mean[c] : 0.f;
         for (long r = r0 + w; r < r1; r += 4) {
             const float x = a[(size_t)r * C + c];
-            u += x;
-            v += mode ? x * b[(size_t)r * C + c] : x * x;
+            if (mode == 0) { u += x; v += x * x; }
+            else if (mode == 1) { u += x; v += x * b[(size_t)r * C + c]; }
+            else if (mode == 2) { u += x; v += x * (b[(size_t)r * C + c] - mu); }
+            else { const float d = x - mu; u += d * d; }
         }
+    }
     s0[w][threadIdx.x & 63] = u;
     s1[w][threadIdx.x & 63] = v;
     __syncthreads();
@@ -235,22 +242,27 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
     }
 }
-// level 2 for BatchNorm forward: mean, rstd (biased variance), running statistics (unbiased variance, momentum)
+// level 2 for BatchNorm forward, pass 1: mean;  pass 2 (from centred squares): rstd (biased variance) and the running statistics
+// (unbiased variance, momentum) exactly as torch.nn.BatchNorm updates them
+__global__ __launch_bounds__(256) void bn_mean_kernel(const float* __restrict__ part, int nblk, int C, long rows, float* __restrict__ mean) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part[((size_t)i * 2) * C + c];
+    mean[c] = (float)(s / (double)rows);
+}
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long rows, float eps, float momentum,
-                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                          const float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nblk; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
-    const double m = s / (double)rows;
-    double var = q / (double)rows - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
+    double q = 0.0;
+    for (int i = 0; i < nblk; ++i) q += part[((size_t)i * 2) * C + c];
+    const double var = q / (double)rows;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean) {
         const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
     }
 }
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         y[i] = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
     }
 }
-// dx = gamma*rstd * (dy - sum_dy/R - xhat * sum_dy_xhat/R);  sums arrive as (sum dy, sum dy*x): sum dy*xhat = rstd*(sum dy*x - mean*sum dy)
+// dx = gamma*rstd * (dy - sum_dy/R - xhat * sum_dy_xhat/R);  sums arrive as (sum dy, sum dy*(x - mean)): sum dy*xhat = rstd * the latter
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
@@ -279,9 +291,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const float xh = (x[i] - mean[c]) * rstd[c];
-        const float sdyxh = rstd[c] * (sum_dyx[c] - mean[c] * sum_dy[c]);
+        const float sdyxh = rstd[c] * sum_dyx[c];
         dx[i] = gamma[c] * rstd[c] * (dy[i] - sum_dy[c] * inv_rows - xh * sdyxh * inv_rows);
-        if (dgamma && i < (size_t)C) dgamma[i] = rstd[i] * (sum_dyx[i] - mean[i] * sum_dy[i]);
+        if (dgamma && i < (size_t)C) dgamma[i] = rstd[i] * sum_dyx[i];
     }
 }
 
@@ -592,13 +604,13 @@ extern "C" int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t le
 }
 
 namespace {
-int col_reduce(const float* a, const float* b, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st) {
+int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st) {
     long nblk = (rows + 2047) / 2048;
     if (nblk > 512) nblk = 512;
     if (nblk < 1) nblk = 1;
     const long rows_per = (rows + nblk - 1) / nblk;
     nblk = (rows + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a, b, part, (long)rows, c, rows_per, mode);
+    hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode);
     *nblk_out = (int)nblk;
     return eg_check_launch("col_partial");
 }
@@ -612,7 +624,10 @@ extern "C" int eg_bn_train_forward(const float* x, const float* gamma, const flo
                                    void* stream) {
     EG_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_bn_train_forward: bad argument");
     int nblk = 0;
-    if (int rc = col_reduce(x, nullptr, rows, c, 0, workspace, &nblk, ST)) return rc;
+    if (int rc = col_reduce(x, nullptr, nullptr, rows, c, 0, workspace, &nblk, ST)) return rc;            // pass 1: mean
+    hipLaunchKernelGGL(bn_mean_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, save_mean);
+    if (int rc = eg_check_launch("bn_mean")) return rc;
+    if (int rc = col_reduce(x, nullptr, save_mean, rows, c, 3, workspace, &nblk, ST)) return rc;           // pass 2: centred squares
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
                        running_mean, running_var);
     if (int rc = eg_check_launch("bn_finalize")) return rc;
@@ -624,7 +639,7 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
     EG_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG,
                "eg_bn_train_backward: bad argument");
     int nblk = 0;
-    if (int rc = col_reduce(dy, x, rows, c, 1, workspace, &nblk, ST)) return rc;        // (sum dy, sum dy*x)
+    if (int rc = col_reduce(dy, x, save_mean, rows, c, 2, workspace, &nblk, ST)) return rc;        // (sum dy, sum dy*(x - mean))
     float* sum_dyx = workspace + (size_t)2 * 512 * c;           // scratch column behind the partials
     // dbeta receives sum dy directly; sum dy*x goes to the scratch column
     hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx);
@@ -637,7 +652,7 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
 extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream) {
     EG_REQUIRE(a && (o0 || o1) && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_colsum: bad argument");
     int nblk = 0;
-    if (int rc = col_reduce(a, b, rows, c, b ? 1 : 0, workspace, &nblk, ST)) return rc;
+    if (int rc = col_reduce(a, b, nullptr, rows, c, b ? 1 : 0, workspace, &nblk, ST)) return rc;
     hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, o0, o1);
     return eg_check_launch("col_finalize");
 }

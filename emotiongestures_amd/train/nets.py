@@ -29,17 +29,28 @@ def _fork_n(x, n):
 
 
 # ---- audio tower (Full_model/ResNetSE34V2.py:62-74, ResNetBlocks.py:21-37) -------------------------------------------------
+DEBUG_TAPS = None       # tools/debug_block_grad.py: {id(block): dict} receives the block's intermediates with retain_grad()
+
+
 def se_basic_block(blk, x):
     xa, xb = F.fork(x)
-    out = F.conv3x3(xa, blk.conv1.weight, None, blk.stride, relu=True)          # conv1 -> ReLU -> bn1 (ReLU precedes BN, :24-26)
-    out = F.batch_norm(out, blk.bn1)
-    out = F.batch_norm(F.conv3x3(out, blk.conv2.weight), blk.bn2)
-    out = F.se_layer(out, blk.se.fc[0], blk.se.fc[2])
+    r1 = F.conv3x3(xa, blk.conv1.weight, None, blk.stride, relu=True)           # conv1 -> ReLU -> bn1 (ReLU precedes BN, :24-26)
+    b1 = F.batch_norm(r1, blk.bn1)
+    c2 = F.conv3x3(b1, blk.conv2.weight)
+    b2 = F.batch_norm(c2, blk.bn2)
+    se = F.se_layer(b2, blk.se.fc[0], blk.se.fc[2])
     if blk.downsample is not None:
         res = F.batch_norm(F.conv1x1(xb, blk.downsample[0].weight, blk.stride), blk.downsample[1])
     else:
         res = xb
-    return F.relu(F.add(out, res))
+    out = F.relu(F.add(se, res))
+    if DEBUG_TAPS is not None and id(blk) in DEBUG_TAPS:
+        t = dict(x=x, r1=r1, b1=b1, c2=c2, b2=b2, se=se, out=out)
+        for v in t.values():
+            if v.requires_grad:
+                v.retain_grad()
+        DEBUG_TAPS[id(blk)].update(t)
+    return out
 
 
 def resnetse_forward(enc, spec):

