@@ -143,6 +143,10 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32 parity-mode leg and the sustained (>= 2 s) leg")
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[2]: one step = generator forward + 100*smooth_l1 + CE + backward + bucketed gradient "
+                         "all-reduce (RCCL) + fused Adam on --train-batch clips per GPU (fp32 operators)")
+    ap.add_argument("--train-batch", type=int, default=16, help="clips per GPU per training step (16 = global 128 on 8 GPUs, SURVEY.md §8d cfg 3)")
     return ap.parse_args()
 
 
@@ -190,6 +194,74 @@ def dry_worker(args, rank, world):
     return 0
 
 
+def train_worker(args, rank, world, dev, dist, backend):
+    """--train: data-parallel training step of the generator (SURVEY.md §8d cfg 3, §8e): every rank its own synthetic clips,
+    gradients averaged with bucketed all-reduces launched from backward order on a side stream (emotiongestures_amd/train/optim.py)."""
+    from emotiongestures_amd.builders import build_mirror
+    from emotiongestures_amd.synth import hash_unit, synth_inputs
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
+    B = args.train_batch
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
+    fp = flatten_parameters(model)
+    opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
+    gb = GradBuckets(fp, bucket_mb=25.0).attach()
+    inp = synth_inputs(B, 34, 126, 4, seed=2000 + rank)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    target = torch.from_numpy((hash_unit("train.target_pose", B * 34 * 126, 2000 + rank) - 0.5).astype(np.float32).reshape(B, 34, 126)).to(dev)
+    label = g["label"].argmax(1)
+    ar_ms = []
+
+    def step():
+        opt.zero_grad()
+        gb.begin()
+        pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+        loss = F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label))
+        loss.backward()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gb.finish()                     # waits for the bucket all-reduces still running behind backward: the EXPOSED part
+        e1.record()
+        opt.step(collected=True)
+        ar_ms.append((e0, e1))
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    barrier()
+    ar_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms]))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        nparam = int(sum(p.numel() for p in fp.params))
+        print(json.dumps({
+            "metric": "training clips/sec (generator forward + backward + all-reduce + Adam)", "value": round(B * world * args.steps / el, 2),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion) -> backward -> Adam",
+                       "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
+                       "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": len(gb.buckets)},
+            "final_loss": float(loss.detach()), "allreduce_exposed_ms_per_step": round(exposed, 3)}))
+    return 0
+
+
 def main():
     args = parse_args()
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -223,6 +295,8 @@ def main():
 
     from emotiongestures_amd import _lib
     lib = _lib.load()
+    if args.train:
+        return train_worker(args, rank, world, dev, dist, backend)
     gen, vae, mel, sd_g, sd_v = build_models(args.precision, dev)
     lanes = 1 if args.no_graph else max(1, args.in_flight)
     gen.concurrent = lanes == 1 and (args.concurrent or not args.no_concurrent)
