@@ -143,6 +143,8 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32 parity-mode leg and the sustained (>= 2 s) leg")
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
+    ap.add_argument("--fold-affine", action="store_true",
+                    help="fold the Dropout-only Linear chains at pack time (fewer launches and FLOPs than the reference graph; reported in config)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]: one step = generator forward + 100*smooth_l1 + CE + backward + bucketed gradient "
                          "all-reduce (RCCL) + fused Adam on --train-batch clips per GPU (fp32 operators)")
@@ -300,6 +302,7 @@ def main():
     gen, vae, mel, sd_g, sd_v = build_models(args.precision, dev)
     lanes = 1 if args.no_graph else max(1, args.in_flight)
     gen.concurrent = lanes == 1 and (args.concurrent or not args.no_concurrent)
+    gen.fold_affine = bool(args.fold_affine)
     B = args.batch
     inp = make_inputs(B, seed=1000 + rank)          # every rank generates its own shard of clips
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
@@ -407,19 +410,41 @@ def main():
             fb = ae(pose_ref.to(dev))[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
         fgd = float(np.real(calculate_frechet_distance(fa.mean(0), np.cov(fa, rowvar=False), fb.mean(0), np.cov(fb, rowvar=False))))
 
-    # ---- f32 parity-mode leg (SURVEY.md §8d cfg 2: perf mode AND fp32 parity mode timed in the same run) ----
-    if not args.no_extra_legs and args.precision != "f32":
-        gen32 = build_models("f32", dev)[0]
-        gen32.concurrent = False
-        step32, pipe32 = make_runner(gen32, lanes)
-        el32, out32 = timed(step32, args.steps, max(2, args.warmup // 2))
-        if rank == 0:
-            f32 = {"value": round(total_clips / el32, 2), "ms_per_step": round(el32 / args.steps * 1e3, 4), "dtype": "f32",
-                   "pose_rel_l2_vs_cpu_oracle": clip_rel_l2(out32[0].cpu().numpy(), pose_ref.numpy()),
-                   "mfma_peak_tflops": PEAK_TFLOPS["f32"],
-                   "frac_of_f32_mfma_peak": round(total_clips / el32 * FLOP_PER_CLIP / 1e12 / PEAK_TFLOPS["f32"] / world, 4)}
-        del step32, pipe32, gen32
-        torch.cuda.empty_cache()
+    # ---- extra legs in the same run: f32 parity mode (SURVEY.md §8d cfg 2), the flagged affine folds, a 256-clip batch ----
+    extra = {}
+    if not args.no_extra_legs:
+        def leg(precision, fold, batch, lanes_):
+            nonlocal g
+            g_main = g
+            gen_x = build_models(precision, dev)[0]
+            gen_x.concurrent = False
+            gen_x.fold_affine = fold
+            if batch != B:
+                inp_x = make_inputs(batch, seed=1000 + rank)
+                g = {k: torch.from_numpy(v).to(dev) for k, v in inp_x.items()}
+            try:
+                step_x, pipe_x = make_runner(gen_x, lanes_)
+                el_x, out_x = timed(step_x, args.steps, max(2, args.warmup // 2))
+            finally:
+                g = g_main
+            rec = None
+            if rank == 0:
+                rec = {"value": round(batch * world * args.steps / el_x, 2), "ms_per_step": round(el_x / args.steps * 1e3, 4), "dtype": precision,
+                       "clips_per_gpu_per_step": batch, "fold_affine": fold, "steps_in_flight": lanes_}
+                if batch == B:
+                    rec["pose_rel_l2_vs_cpu_oracle"] = clip_rel_l2(out_x[0].cpu().numpy(), pose_ref.numpy())
+            del step_x, pipe_x, gen_x
+            torch.cuda.empty_cache()
+            return rec
+        if args.precision != "f32":
+            f32 = leg("f32", False, B, lanes)
+            if f32 is not None:
+                f32["mfma_peak_tflops"] = PEAK_TFLOPS["f32"]
+                f32["frac_of_f32_mfma_peak"] = round(f32["value"] * FLOP_PER_CLIP / 1e12 / PEAK_TFLOPS["f32"] / world, 4)
+        if not args.fold_affine:
+            extra["fold_affine"] = leg(args.precision, True, B, lanes)          # same arithmetic mode, fewer products than the reference graph
+        if B == 64:
+            extra["b256"] = leg(args.precision, False, 256, 2)                  # informational: the same path at 4x the batch (NOT the headline config)
 
     # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
     if rank == 0 and not args.no_roofline:
@@ -471,7 +496,7 @@ def main():
                        "branch_streams": timed_concurrent, "fold_affine": bool(getattr(gen, "fold_affine", False)),
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
             "pose_rel_l2_vs_cpu_oracle": parity, "parity_clips_checked": B, "fgd_vs_cpu_oracle": fgd,
-            "lanes_bitwise_equal": lanes_equal, "sustained": sustained, "f32": f32, "roofline": roof, "cpu_baseline": cpu,
+            "lanes_bitwise_equal": lanes_equal, "sustained": sustained, "f32": f32, "extra_legs": extra, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     return 0

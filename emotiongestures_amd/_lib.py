@@ -15,7 +15,7 @@ EG_PREC_F32, EG_PREC_BF16X3, EG_PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": EG_PREC_F32, "fp32": EG_PREC_F32, "bf16x3": EG_PREC_BF16X3, "bf16": EG_PREC_BF16}
 
 (PACK_RAW, PACK_LINEAR, PACK_VEC_PAD, PACK_CONV3X3, PACK_BN_SCALE, PACK_BN_SHIFT, PACK_CONV1X1, PACK_STEM,
- PACK_WN_TAP, PACK_CONV1D, PACK_POS_TABLE, PACK_LINEAR_T) = range(12)
+ PACK_WN_TAP, PACK_CONV1D, PACK_POS_TABLE, PACK_LINEAR_T, PACK_LINEAR_FOLD, PACK_BIAS_FOLD) = range(14)
 
 
 class EgError(RuntimeError):

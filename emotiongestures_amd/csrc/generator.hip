@@ -190,6 +190,16 @@ LinW add_linear_cat(Layout& L, const std::vector<std::string>& prefixes, int n_e
     if (bias) w.b = L.vec(bk, n, w.npad);
     return w;
 }
+// a Dropout-only chain of nn.Linear layers (eval mode: one affine map) folded at pack time; `chains` joined along N by '|'
+LinW add_linear_fold(Layout& L, const std::string& chains, int n, int k, int kpad_force = 0, int npad_force = 0) {
+    LinW w;
+    w.n = n; w.k = k;
+    w.npad = npad_force ? npad_force : (int)eg_round_up(n, 64);
+    w.kpad = kpad_force ? kpad_force : (int)eg_round_up(k, 64);
+    w.w = L.add(chains, EG_PACK_LINEAR_FOLD, n, k, w.npad, w.kpad, (int64_t)w.npad * w.kpad * 2);
+    w.b = L.add(chains, EG_PACK_BIAS_FOLD, n, w.npad, 0, 0, w.npad);
+    return w;
+}
 // self_attn: fused Q|K|V projection of one input; cross attention: Q alone, K|V of the encoder output
 MhaW add_mha(Layout& L, const std::string& p, int d, bool self_attn) {
     MhaW m;
@@ -235,6 +245,8 @@ struct EgGenerator {
     std::vector<BlockW> blocks;
     ConvW final_conv;
     LinW a_fc1, a_fc2, emosem0, emo2, sem2, fus0, fus2, cls[4], post[4], prior_h0, prior_h2, txt_dec;
+    bool fold = false;          // cfg.reserved[2]: the chains below replace their members
+    LinW f_audio, f_emo, f_sem, f_post, f_prior;
     int64_t pos_table;
     std::vector<MhaW> enc_attn, dec_attn;
     std::vector<FfnW> enc_ffn, dec_ffn;
@@ -439,6 +451,7 @@ int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec,
     }
     float* amap = P(ws, w.amap);
     EG_TRY(run_conv(arena, g->final_conv, bufs[xi], amap, nullptr, B, h, wd, 0, 1, prec, st));
+    if (g->fold) return lin(g, arena, g->f_audio, act(amap, g->HW3), 0, act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), true, B * F, 0, nullptr, 0, st);
     const Act h1 = act(P(ws, w.afc1), D, P(ws, w.im_a[0]), D);
     EG_TRY(lin(g, arena, g->a_fc1, act(amap, g->HW3), 0, h1, false, B * F, 0, nullptr, 0, st));
     return lin(g, arena, g->a_fc2, h1, 0, act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), true, B * F, 0, nullptr, 0, st);
@@ -481,6 +494,9 @@ int run_prior(const EgGenerator* g, const float* arena, const float* prior, cons
     EG_TRY(egi_prior_encoder(prior, pw, P(ws, w.prior_cat), P(ws, w.tm_mem), P(ws, w.tm_pe), P(ws, w.tm_gram), B, c.prior_frames, c.frames,
                              c.pose_dim, g->Dpad, c.chunk, c.variant, st));
     const int rows = B * c.frames;
+    if (g->fold)
+        return lin(g, arena, g->f_prior, act(P(ws, w.prior_cat), g->Dpad), 0, act(P(ws, w.prior_enc), c.d_model, P(ws, w.im_p[1]), c.d_model), true, rows, 0,
+                   nullptr, 0, st);
     const Act ph = act(P(ws, w.prior_h), c.d_model, P(ws, w.im_p[0]), c.d_model);
     EG_TRY(lin(g, arena, g->prior_h0, act(P(ws, w.prior_cat), g->Dpad), 0, ph, false, rows, 0, nullptr, 0, st));
     return lin(g, arena, g->prior_h2, ph, 0, act(P(ws, w.prior_enc), c.d_model, P(ws, w.im_p[1]), c.d_model), true, rows, 0, nullptr, 0, st);
@@ -515,6 +531,7 @@ int run_transformer(const EgGenerator* g, const float* arena, const float* fusio
         EG_TRY(run_ffn(g, arena, g->dec_ffn[l], mid, nxt, w, ws, rows, st));
         dx = nxt;
     }
+    if (g->fold) return lin(g, arena, g->f_post, dx, 0, act(pose, c.pose_dim), true, rows, 0, nullptr, 0, st);
     // post_projector: four affine layers chained through images (fp32 copies only in f32 mode)
     const Act pa = act(P(ws, w.post_a), D * 4, imh, D * 4), pb = act(P(ws, w.post_b), D, im0, D), pc = act(P(ws, w.post_c), g->Dpad, im1, g->Dpad);
     EG_TRY(lin(g, arena, g->post[0], dx, 0, pa, false, rows, 0, nullptr, 0, st));
@@ -556,6 +573,7 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     g->cfg = *cfg;
     g->keep_taps = cfg->reserved[0] != 0;
     g->concurrent = cfg->reserved[1] != 0;
+    g->fold = cfg->reserved[2] != 0;
     const EgGeneratorConfig& c = g->cfg;
     g->H1 = c.n_mels; g->W1 = c.spec_len;
     g->H2 = (g->H1 - 1) / 2 + 1; g->W2 = (g->W1 - 1) / 2 + 1;
@@ -606,25 +624,36 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     }
     g->final_conv.bias = L.vec("audio_encoder.final_conv1.bias", F, g->final_conv.coutp);
     add_bn(L, "audio_encoder.bn1", F, g->final_conv.coutp, g->final_conv.scale, g->final_conv.shift);
-    g->a_fc1 = add_linear(L, "audio_encoder.fc1", D, g->HW3, true);
-    g->a_fc2 = add_linear(L, "audio_encoder.fc2", D, D, true);
-    // --- projections
-    g->emosem0 = add_linear_cat(L, {"emotion_proj.0", "semantic_proj.0"}, D, D, true);      // both read spectrum_feature (:588-589)
-    g->emo2 = add_linear(L, "emotion_proj.2", D, D, true);
-    g->sem2 = add_linear(L, "semantic_proj.2", D, D, true);
+    if (g->fold) {
+        g->f_audio = add_linear_fold(L, "audio_encoder.fc2@audio_encoder.fc1", D, g->HW3);
+        g->f_emo = add_linear_fold(L, "emotion_proj.2@emotion_proj.0", D, D);
+        g->f_sem = add_linear_fold(L, "semantic_proj.2@semantic_proj.0", D, D);
+    } else {
+        g->a_fc1 = add_linear(L, "audio_encoder.fc1", D, g->HW3, true);
+        g->a_fc2 = add_linear(L, "audio_encoder.fc2", D, D, true);
+        // --- projections
+        g->emosem0 = add_linear_cat(L, {"emotion_proj.0", "semantic_proj.0"}, D, D, true);      // both read spectrum_feature (:588-589)
+        g->emo2 = add_linear(L, "emotion_proj.2", D, D, true);
+        g->sem2 = add_linear(L, "semantic_proj.2", D, D, true);
+    }
     g->fus0 = add_linear(L, "fusion_proj.0", D, D, true); g->fus2 = add_linear(L, "fusion_proj.2", D, D, true);
     g->cls[0] = add_linear(L, "emotion_classifer_header.0", D, F * D, true);
     g->cls[1] = add_linear(L, "emotion_classifer_header.2", 256, D, true);
     g->cls[2] = add_linear(L, "emotion_classifer_header.4", 64, 256, true);
     g->cls[3] = add_linear(L, "emotion_classifer_header.6", 8, 64, true);
-    g->post[0] = add_linear(L, "post_projector.0", D * 4, D, true);
-    g->post[1] = add_linear(L, "post_projector.2", D, D * 4, true);
-    g->post[2] = add_linear(L, "post_projector.4", PD, D, true, 0, g->Dpad);
-    g->post[3] = add_linear(L, "post_projector.6", PD, PD, true, g->Dpad, 0);
-    // --- prior encoder
     const std::string pp = "prior_seq_encoder";
-    g->prior_h0 = add_linear(L, pp + ".post_header.0", D, PD, true, g->Dpad, 0);
-    g->prior_h2 = add_linear(L, pp + ".post_header.2", D, D, true);
+    if (g->fold) {
+        g->f_post = add_linear_fold(L, "post_projector.6@post_projector.4@post_projector.2@post_projector.0", PD, D);
+        g->f_prior = add_linear_fold(L, pp + ".post_header.2@" + pp + ".post_header.0", D, PD, g->Dpad, 0);
+    } else {
+        g->post[0] = add_linear(L, "post_projector.0", D * 4, D, true);
+        g->post[1] = add_linear(L, "post_projector.2", D, D * 4, true);
+        g->post[2] = add_linear(L, "post_projector.4", PD, D, true, 0, g->Dpad);
+        g->post[3] = add_linear(L, "post_projector.6", PD, PD, true, g->Dpad, 0);
+        // --- prior encoder
+        g->prior_h0 = add_linear(L, pp + ".post_header.0", D, PD, true, g->Dpad, 0);
+        g->prior_h2 = add_linear(L, pp + ".post_header.2", D, D, true);
+    }
     g->pc_w1 = L.raw(pp + ".pred_conv.0.weight", (int64_t)PL * P_ * 3); g->pc_b1 = L.raw(pp + ".pred_conv.0.bias", PL);
     add_bn(L, pp + ".pred_conv.2", PL, PL, g->pc_s1, g->pc_t1);
     g->pc_w2 = L.raw(pp + ".pred_conv.3.weight", (int64_t)PL * PL * 3); g->pc_b2 = L.raw(pp + ".pred_conv.3.bias", PL);
@@ -719,9 +748,14 @@ extern "C" int eg_generator_forward(const EgGenerator* g, const float* arena, in
     float* sem = semantic_feature ? semantic_feature : P(ws, w.sem);
     // emotion_proj.0 | semantic_proj.0 fused: [rows, 2D] = (emotion hidden | semantic hidden)
     const Act afeat = act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), es = act(P(ws, w.emo_t), 2 * D, P(ws, w.im_a[2]), 2 * D);
-    EG_TRY(lin(g, arena, g->emosem0, afeat, 0, es, false, rows, 0, nullptr, 0, st));
-    EG_TRY(lin(g, arena, g->emo2, es, 0, act(emo, D), true, rows, 0, nullptr, 0, st));
-    EG_TRY(lin(g, arena, g->sem2, es, D, act(sem, D), true, rows, 0, nullptr, 0, st));
+    if (g->fold) {
+        EG_TRY(lin(g, arena, g->f_emo, afeat, 0, act(emo, D), true, rows, 0, nullptr, 0, st));
+        EG_TRY(lin(g, arena, g->f_sem, afeat, 0, act(sem, D), true, rows, 0, nullptr, 0, st));
+    } else {
+        EG_TRY(lin(g, arena, g->emosem0, afeat, 0, es, false, rows, 0, nullptr, 0, st));
+        EG_TRY(lin(g, arena, g->emo2, es, 0, act(emo, D), true, rows, 0, nullptr, 0, st));
+        EG_TRY(lin(g, arena, g->sem2, es, D, act(sem, D), true, rows, 0, nullptr, 0, st));
+    }
     // emotion classifier header on emotion_feature.reshape(B, F*D)  (:592)
     {
         const int K0 = F * D;
@@ -760,8 +794,12 @@ extern "C" int eg_generator_forward_draws(const EgGenerator* g, const float* are
     EG_TRY(run_audio_tower(g, arena, spec, w, ws, B, st));
     EG_TRY(run_prior(g, arena, prior, w, ws, B, st));
     const Act afeat = act(P(ws, w.afeat), D, P(ws, w.im_a[1]), D), es = act(P(ws, w.emo_t), 2 * D, P(ws, w.im_a[2]), 2 * D);
-    EG_TRY(lin(g, arena, g->emosem0, afeat, 0, es, false, rows, 0, nullptr, 0, st));
-    EG_TRY(lin(g, arena, g->sem2, es, D, act(P(ws, w.sem), D), true, rows, 0, nullptr, 0, st));
+    if (g->fold) {
+        EG_TRY(lin(g, arena, g->f_sem, afeat, 0, act(P(ws, w.sem), D), true, rows, 0, nullptr, 0, st));
+    } else {
+        EG_TRY(lin(g, arena, g->emosem0, afeat, 0, es, false, rows, 0, nullptr, 0, st));
+        EG_TRY(lin(g, arena, g->sem2, es, D, act(P(ws, w.sem), D), true, rows, 0, nullptr, 0, st));
+    }
     // fusion_in[(b,r,f)] = sampled[(b,r,f)] + semantic[(b,f)];  decoder target stream = prior_enc[b] for every draw
     EG_TRY(egi_add_bcast(sampled, P(ws, w.sem), P(ws, w.fus_in), (size_t)B * R * F, D, F, R, st));
     EG_TRY(egi_add_bcast(nullptr, P(ws, w.prior_enc), P(ws, w.prior_rep), (size_t)B * R * F, D, F, R, st));

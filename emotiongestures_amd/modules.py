@@ -565,6 +565,7 @@ class Transformer(nn.Module):
         self.precision = precision or _DEFAULT_PRECISION
         self.keep_taps = False
         self.concurrent = False          # fork the text / prior branches onto side streams (engine option)
+        self.fold_affine = False         # fold the Dropout-only Linear chains at pack time (fewer launches / FLOPs; off for parity runs)
         self._engine: Optional[GeneratorEngine] = None
         self._engine_key = None
 
@@ -577,10 +578,11 @@ class Transformer(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise L.EgError("emotiongestures_amd.Transformer runs only on a GPU (model.to('cuda')); there is no CPU fallback")
-        key = (str(dev), self.precision, self.keep_taps, self.concurrent, self._weights_version())
+        key = (str(dev), self.precision, self.keep_taps, self.concurrent, self.fold_affine, self._weights_version())
         if self._engine is None or self._engine_key != key:
-            if self._engine is None or self._engine_key[:4] != key[:4]:
-                self._engine = GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=self.concurrent, **self._cfg)
+            if self._engine is None or self._engine_key[:5] != key[:5]:
+                self._engine = GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=self.concurrent,
+                                               fold_affine=self.fold_affine, **self._cfg)
             self._engine.load_weights(self.state_dict(), dev)
             self._engine_key = key
         return self._engine

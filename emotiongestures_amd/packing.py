@@ -72,6 +72,22 @@ def _pad1(v: torch.Tensor, npad: int) -> np.ndarray:
     return out
 
 
+def _fold_chain(sd, chain: str):
+    """"last@...@first": y = W_last(... (W_first x + b_first) ...) + b_last as one affine map, folded in float64."""
+    names = chain.split("@")[::-1]                  # application order
+    w = _t(sd, names[0] + ".weight").double()
+    b = _t(sd, names[0] + ".bias").double()
+    for nme in names[1:]:
+        wi, bi = _t(sd, nme + ".weight").double(), _t(sd, nme + ".bias").double()
+        w, b = wi @ w, wi @ b + bi
+    return w, b
+
+
+def _fold(sd, key: str):
+    parts = [_fold_chain(sd, c) for c in key.split("|")]
+    return torch.cat([p[0] for p in parts], 0).float(), torch.cat([p[1] for p in parts], 0).float()
+
+
 def pack_entry(sd: Mapping[str, torch.Tensor], e: L.EgWeightEntry) -> np.ndarray:
     key, kind, d = e.key.decode(), e.kind, list(e.dims)
     if kind in (L.PACK_RAW, L.PACK_CONV1D):
@@ -101,6 +117,10 @@ def pack_entry(sd: Mapping[str, torch.Tensor], e: L.EgWeightEntry) -> np.ndarray
         out = _t(sd, key)[0, : d[0], :].contiguous().reshape(-1).numpy()
     elif kind == L.PACK_LINEAR_T:
         out = _t(sd, key).t().contiguous().reshape(-1).numpy()
+    elif kind == L.PACK_LINEAR_FOLD:
+        out = _pack_linear(_fold(sd, key)[0], d[2], d[3])
+    elif kind == L.PACK_BIAS_FOLD:
+        out = _pad1(_fold(sd, key)[1], d[1])
     else:
         raise L.EgError(f"unknown pack kind {kind} for '{key}'")
     out = np.ascontiguousarray(out, dtype=np.float32)

@@ -86,7 +86,11 @@ typedef enum EgPackKind {
                                    g*v/||v|| as [O,Ipad] (dims = O,I,tap,Ipad) */
     EG_PACK_CONV1D = 9,         /* Conv1d [O,I,k] -> [O][I][k] raw (alias of RAW, kept for readability) */
     EG_PACK_POS_TABLE = 10,     /* buffer [1,n_position,D] -> first dims[0] rows [frames,D] */
-    EG_PACK_LINEAR_T = 11       /* nn.Linear weight [N,K] -> transposed [K,N] */
+    EG_PACK_LINEAR_T = 11,      /* nn.Linear weight [N,K] -> transposed [K,N] */
+    EG_PACK_LINEAR_FOLD = 12,   /* key = chain "last@...@first" of nn.Linear prefixes with only Dropout between them (eval mode: an
+                                   affine chain): W = W_last ... W_first folded in float64, packed as EG_PACK_LINEAR (same dims);
+                                   several chains joined by '|' are concatenated along N */
+    EG_PACK_BIAS_FOLD = 13      /* the folded chain's bias, zero padded to dims[1] */
 } EgPackKind;
 
 typedef struct EgWeightEntry {
@@ -120,7 +124,10 @@ typedef struct EgGeneratorConfig {
     int32_t variant;            /* 0 = Models_spatial_memory (SP_v2 no-op), 1 = Models_memory (SP_v1 + TM) */
     int32_t precision;          /* EgPrecision */
     int32_t n_position;         /* rows of the positional table held in the checkpoint (>= frames) */
-    int32_t reserved[5];
+    int32_t reserved[5];        /* [0] keep_taps  [1] branch streams  [2] fold_affine: fold the Dropout-only Linear chains
+                                   (post_projector :528-536, emotion_proj / semantic_proj :488-496,509-517, post_header :360-364,
+                                   audio fc1 -> fc2 :128-130) into one product each at pack time -- exact algebra in eval mode,
+                                   different rounding, fewer FLOPs than the reference graph: OFF for parity runs */
 } EgGeneratorConfig;
 
 typedef struct EgGenerator EgGenerator;

@@ -20,11 +20,12 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run(name, variant, prec, keep_taps=False):
+def _run(name, variant, prec, keep_taps=False, fold_affine=False):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = golden_meta(z)
     model = build_mirror(variant, m["frames"], m["pose_dim"], m["prior"], m["chunk"], m["n_words"], m["seed"], m["spec_len"], precision=prec)
     model.keep_taps = keep_taps
+    model.fold_affine = fold_affine
     model.to(dev())
     inp = synth_inputs(m["batch"], m["frames"], m["pose_dim"], m["prior"], spec_len=m["spec_len"], n_words=m["n_words"], seed=m["seed"])
     g = {k: torch.from_numpy(v).to(dev()) for k, v in inp.items()}
@@ -46,6 +47,24 @@ def test_generator_matches_reference_golden(name, variant, prec):
         d = digest(t.cpu().numpy(), 8192)
         assert tuple(d["shape"]) == tuple(z[key + "/shape"])
         assert rel_l2(d["sample"], z[key + "/sample"]) < tol, key
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("name,variant", [("ted_spatial_b2", "spatial"), ("ted_memory_b4", "memory"), ("beat_spatial_b1", "spatial")])
+def test_fold_affine_matches_reference_golden(name, variant, prec):
+    """fold_affine=True: the Dropout-only Linear chains (post_projector, emotion_proj, semantic_proj, post_header, fc1 -> fc2:
+    Models_spatial_memory.py:128-130,360-364,488-496,509-517,528-536) folded into one product each at pack time.  Exact algebra
+    in eval mode, different rounding: same tolerances as the unfolded path, and fewer arena entries."""
+    z, m, model, (pose, emo, sem, pred, text) = _run(name, variant, prec, fold_affine=True)
+    tol = POSE_TOL[prec]
+    assert clip_rel_l2(pose.cpu().numpy(), z["pose"]) < tol
+    assert rel_l2(pred.cpu().numpy(), z["emotion_prediction"]) < tol * 5
+    for key, t in (("emotion_feature", emo), ("semantic_feature", sem)):
+        assert rel_l2(digest(t.cpu().numpy(), 8192)["sample"], z[key + "/sample"]) < tol, key
+    keys = [e.key.decode() for e in model.engine().entries]
+    assert any("@" in k for k in keys) and not any(k.startswith("post_projector.2.") for k in keys)
+    model.fold_affine = False
+    assert not any("@" in e.key.decode() for e in model.engine().entries)          # the flag rebuilds the engine
 
 
 def test_generator_taps_match_reference_golden():
