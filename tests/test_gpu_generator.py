@@ -128,6 +128,49 @@ def test_generator_draws_equal_per_draw_forward():
             assert clip_rel_l2(poses[:, r].cpu().numpy(), ref.cpu().numpy()) < 1e-6
 
 
+def test_diversity_sampling_64x32_matches_oracle():
+    """BASELINE configs[4] at full size: 64 clips x 32 CVAE draws (label one-hot + z -> MLP_Reconstruct_v3.sample,
+    CAVE/BEAT_CVAE.py:427-447) through forward_draws (audio tower once per clip, fusion -> encoder -> decoder -> post_projector per
+    draw, M = 69 632 rows on the 128x128-tile GEMM), bf16x3.  A subset of (clip, draw) pairs against the CPU oracle within the
+    north-star's 1e-3, the FGD auto-encoder features of all 2048 sequences finite, and the diversity statistic of the harness."""
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.harness import MLP_Reconstruct, diversity_score
+    from emotiongestures_amd.synth import hash_unit
+    from oracle import emogest_oracle as O
+    B, R, F = 64, 32, 34
+    model = build_mirror("spatial", F, 126, 4, 4, seed=11, precision="bf16x3")
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=F), 11).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sdv = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    inp = synth_inputs(B, F, 126, 4, seed=11)
+    z = (hash_unit("draws.z", B * R * 32, 11).reshape(B, R, 32) * 2 - 1).astype(np.float32) * 1.7          # ~unit variance
+    model.to(dev()); vae.to(dev())
+    g = {k: torch.from_numpy(v).to(dev()) for k, v in inp.items()}
+    with torch.no_grad():
+        lab = g["label"][:, None, :].expand(B, R, 8).reshape(B * R, 8).contiguous()
+        sampled = vae.sample(lab, z=torch.from_numpy(z).reshape(B * R, 32)).view(B, R, F, 512)
+        poses = model.forward_draws(g["spec"], g["pre_pose"], sampled)
+    torch.cuda.synchronize()
+    assert tuple(poses.shape) == (B, R, F, 126) and bool(torch.isfinite(poses).all())
+    clips, draws = [0, 17, 63], [0, 13, 31]
+    t = {k: torch.from_numpy(v[clips]) for k, v in inp.items()}
+    for r in draws:
+        with torch.no_grad():
+            s_ref = O.cvae_sample(sdv, t["label"], torch.from_numpy(z[clips, r]))
+            ref = O.generator_forward(sd, O.GenCfg(), t["spec"], t["text"], t["pre_pose"], s_ref)[0]
+        assert clip_rel_l2(poses[clips, r].cpu().numpy(), ref.numpy()) < 1e-3, f"draw {r}"
+    # draws of one clip differ from each other (the sampling is not degenerate) ...
+    assert float((poses[:, 0] - poses[:, 1]).abs().max()) > 1e-3
+    # ... and the evaluator side of configs[4] runs on them (model/FGD.py features -> model/FHD_score.py:247-311 diversity)
+    ae = load_synth_weights(MLP_Reconstruct(pose_dim=126), 5).eval().to(dev())
+    with torch.no_grad():
+        feats = ae(poses.view(B * R, F, 126).contiguous())[1].reshape(-1, 512).cpu().numpy().astype(np.float64)
+    assert np.isfinite(feats).all() and feats.shape == (B * R * F, 512)
+    np.random.seed(1234)
+    div, _ = diversity_score(feats, frames=F)
+    assert np.isfinite(div).all() and float(div[0]) > 0.0
+
+
 def test_state_dict_roundtrip_and_module_prefix():
     """load_state_dict of a DataParallel-style checkpoint ('module.' prefix stripped as the reference's loaders do,
     test_emotion_gesture_diversity_iterative.py:149) gives the same poses; new weights trigger a repack."""
@@ -214,9 +257,10 @@ def test_melspectrogram_matches_oracle():
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-def test_beat_long_120_frames_matches_oracle(prec):
-    """BASELINE config 4 (10 s audio -> spec 128x312, 120 frames, pose_dim 282, prior 10).  The reference hard-codes
-    32*31 / n_position=60 / 60 CVAE channels, so the checker here is the oracle, which is generic."""
+def test_beat_long_120_frames_matches_reference_golden_and_oracle(prec):
+    """BASELINE config 4 (10 s audio -> spec 128x312, 120 frames, pose_dim 282, prior 10) against the REFERENCE's classes with
+    their hard-coded sizes (32*31, 60 CVAE channels) replaced after construction
+    (tests/golden/make_golden_beat_long.py -> beat_long_b2.npz), and against the oracle."""
     from conftest import make_args, make_lang
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.Full_model.Models_spatial_memory import Transformer
@@ -240,4 +284,10 @@ def test_beat_long_120_frames_matches_oracle(prec):
     assert tuple(got[0].shape) == (2, F, D)
     assert rel_l2(s.cpu().numpy(), s_ref.numpy()) < 1e-5
     assert clip_rel_l2(got[0].cpu().numpy(), ref[0].numpy()) < POSE_TOL[prec]
+    z = np.load(os.path.join(GOLDEN, "beat_long_b2.npz"))                   # the reference itself
+    assert [int(v) for v in z["meta"][:8]] == [2, F, D, P, 10, T, 200, 21]
+    assert rel_l2(digest(s.cpu().numpy(), 16384)["sample"], z["cvae_sample/sample"]) < 1e-5
+    assert clip_rel_l2(got[0].cpu().numpy(), z["pose"]) < POSE_TOL[prec]
+    assert rel_l2(got[3].cpu().numpy(), z["emotion_prediction"]) < POSE_TOL[prec] * 5
+    assert rel_l2(digest(got[1].cpu().numpy(), 8192)["sample"], z["emotion_feature/sample"]) < POSE_TOL[prec]
     assert rel_l2(got[3].cpu().numpy(), ref[3].numpy()) < POSE_TOL[prec] * 5

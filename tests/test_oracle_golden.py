@@ -118,3 +118,28 @@ def test_mel_oracle_properties():
     assert fb.shape == (128, 513) and fb.min() >= 0 and np.all(fb.sum(axis=1) > 0)
     silent = O.melspectrogram(np.zeros((1, 16000), np.float32))
     assert np.all(silent == 0.0)          # all-amin input: db == ref everywhere
+
+
+def test_beat_long_oracle_matches_reference_golden():
+    """BASELINE configs[3] (120 frames, 128x312 spectrogram, 120-channel CVAE): the oracle against the reference's classes with
+    their hard-coded sizes replaced after construction (tests/golden/make_golden_beat_long.py)."""
+    from emotiongestures_amd.builders import make_args, make_lang
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.Full_model.Models_spatial_memory import Transformer
+    z = np.load(os.path.join(GOLDEN, "beat_long_b2.npz"))
+    B, F, D, P, chunk, T, n_words, seed = [int(v) for v in z["meta"][:8]]
+    model = Transformer(make_args(chunk), make_lang(n_words), frames=F, pose_dim=D, prior_frames=P, d_word_vec=512, d_model=512, d_inner=2048,
+                        n_layers=3, n_head=8, d_k=64, d_v=64, n_position=F, spec_len=T)
+    load_synth_weights(model, seed)
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=F), seed)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    sdv = {k: v.detach() for k, v in vae.state_dict().items()}
+    inp = synth_inputs(B, F, D, P, spec_len=T, seed=seed)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    with torch.no_grad():
+        s = O.cvae_sample(sdv, t["label"], t["z"])
+        pose, emo, sem, pred, _ = O.generator_forward(sd, O.GenCfg(frames=F, pose_dim=D, prior_frames=P, chunk=chunk), t["spec"], t["text"], t["pre_pose"], s)
+    assert rel_l2(digest(s.numpy(), 16384)["sample"], z["cvae_sample/sample"]) < TOL
+    assert clip_rel_l2(pose.numpy(), z["pose"]) < TOL
+    assert rel_l2(pred.numpy(), z["emotion_prediction"]) < TOL
+    assert rel_l2(digest(emo.numpy(), 8192)["sample"], z["emotion_feature/sample"]) < TOL
