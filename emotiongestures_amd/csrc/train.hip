@@ -242,6 +242,43 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
     }
 }
+// Fast path of level 1 when C divides 1024: the [rows, C] block is read as one float4 stream, thread t always sees the channel quad
+// (4t) mod C, 256 threads x 16 B = 4 KB per block-iteration fully coalesced; partials are combined through LDS in a fixed order.
+// Segmented: blockIdx.y = segment (a clip for the SE pooling, 1 segment for BatchNorm / bias / LayerNorm-affine sums),
+// blockIdx.x = chunk of rows inside the segment; part[seg][chunk][2][C].
+__global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
+                                                               float* __restrict__ part, long seg_rows, int C, long rows_per, int mode) {
+    __shared__ f4 s0[256], s1[256];
+    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const long r0 = (long)chunk * rows_per, r1 = (r0 + rows_per < seg_rows) ? r0 + rows_per : seg_rows;
+    const size_t base = ((size_t)seg * seg_rows + r0) * C;
+    const size_t n4 = (r1 > r0) ? (size_t)(r1 - r0) * C / 4 : 0;
+    const int cq = (tid * 4) % C;
+    f4 mu = (f4){0.f, 0.f, 0.f, 0.f};
+    if (mode >= 2) mu = *reinterpret_cast<const f4*>(mean + cq);
+    const f4* a4 = reinterpret_cast<const f4*>(a + base);
+    const f4* b4 = b ? reinterpret_cast<const f4*>(b + base) : nullptr;
+    f4 u = (f4){0.f, 0.f, 0.f, 0.f}, v = u;
+    for (size_t f = tid; f < n4; f += 256) {
+        const f4 x = a4[f];
+        if (mode == 0) { u += x; v += x * x; }
+        else if (mode == 1) { u += x; v += x * b4[f]; }
+        else if (mode == 2) { u += x; v += x * (b4[f] - mu); }
+        else { const f4 d = x - mu; u += d * d; }
+    }
+    s0[tid] = u;
+    s1[tid] = v;
+    __syncthreads();
+    const int nq = C >> 2;                  // channel quads; 256 / nq contributors each (nq <= 256)
+    if (tid < nq) {
+        f4 su = (f4){0.f, 0.f, 0.f, 0.f}, sv = su;
+        for (int t = tid; t < 256; t += nq) { su += s0[t]; sv += s1[t]; }
+        float* o = part + (((size_t)seg * nchunk + chunk) * 2) * C + tid * 4;
+        *reinterpret_cast<f4*>(o) = su;
+        *reinterpret_cast<f4*>(o + C) = sv;
+    }
+}
+
 // level 2 for BatchNorm forward, pass 1: mean;  pass 2 (from centred squares): rstd (biased variance) and the running statistics
 // (unbiased variance, momentum) exactly as torch.nn.BatchNorm updates them
 __global__ __launch_bounds__(256) void bn_mean_kernel(const float* __restrict__ part, int nblk, int C, long rows, float* __restrict__ mean) {
@@ -267,13 +304,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0,
-                                                           float* __restrict__ o1) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+                                                           float* __restrict__ o1, float scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (c >= C) return;
+    part += (size_t)seg * nblk * 2 * C;
     double s = 0.0, q = 0.0;
     for (int i = 0; i < nblk; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
-    if (o0) o0[c] = (float)s;
-    if (o1) o1[c] = (float)q;
+    if (o0) o0[(size_t)seg * C + c] = (float)(s * scale);
+    if (o1) o1[(size_t)seg * C + c] = (float)(q * scale);
 }
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
@@ -604,15 +642,29 @@ extern "C" int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t le
 }
 
 namespace {
-int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st) {
-    long nblk = (rows + 2047) / 2048;
-    if (nblk > 512) nblk = 512;
+// rows = rows per segment; nseg segments back to back; partials part[seg][nblk][2][c] with nseg * nblk <= 512
+int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st,
+               int nseg = 1) {
+    const bool fast = (c >= 4) && (1024 % c == 0) && eg_aligned16(a) && (!b || eg_aligned16(b));
+    long cap = 512 / nseg;
+    if (cap < 1) cap = 1;
+    long nblk = fast ? (rows * c + 16383) / 16384 : (rows + 2047) / 2048;       // fast path: >= 64 KB of input per block
+    if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     const long rows_per = (rows + nblk - 1) / nblk;
     nblk = (rows + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode);
     *nblk_out = (int)nblk;
-    return eg_check_launch("col_partial");
+    if (fast) {
+        hipLaunchKernelGGL(col_partial_fast_kernel, dim3((unsigned)nblk, nseg), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode);
+        return eg_check_launch("col_partial_fast");
+    }
+    for (int sgi = 0; sgi < nseg; ++sgi) {       // generic channel counts: one launch per segment
+        const size_t off = (size_t)sgi * rows * c;
+        hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a + off, b ? b + off : nullptr, mean,
+                           part + (size_t)sgi * nblk * 2 * c, (long)rows, c, rows_per, mode);
+        if (int rc = eg_check_launch("col_partial")) return rc;
+    }
+    return EG_OK;
 }
 }  // namespace
 
@@ -642,7 +694,7 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
     if (int rc = col_reduce(dy, x, save_mean, rows, c, 2, workspace, &nblk, ST)) return rc;        // (sum dy, sum dy*(x - mean))
     float* sum_dyx = workspace + (size_t)2 * 512 * c;           // scratch column behind the partials
     // dbeta receives sum dy directly; sum dy*x goes to the scratch column
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx, 1.0f);
     if (int rc = eg_check_launch("col_finalize")) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, dbeta, sum_dyx, dx, dgamma,
                        (size_t)rows * c, c, 1.0f / (float)rows);
@@ -653,7 +705,7 @@ extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, i
     EG_REQUIRE(a && (o0 || o1) && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_colsum: bad argument");
     int nblk = 0;
     if (int rc = col_reduce(a, b, nullptr, rows, c, b ? 1 : 0, workspace, &nblk, ST)) return rc;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, o0, o1);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, o0, o1, 1.0f);
     return eg_check_launch("col_finalize");
 }
 
@@ -664,15 +716,28 @@ extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t 
     return eg_check_launch("elementwise");
 }
 
-extern "C" int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, void* stream) {
+// per-clip pooled sums through the two-level column reduction (clips = segments): workspace >= eg_colreduce_workspace_floats(c)
+extern "C" int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, float* workspace, void* stream) {
     EG_REQUIRE(x && out && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_seg_mean: bad argument");
-    hipLaunchKernelGGL(seg_mean_kernel, dim3(eg_cdiv(c, 64), batch), dim3(256), 0, ST, x, out, hw, c, scale);
-    return eg_check_launch("seg_mean");
+    if (!workspace || batch > 512) {
+        hipLaunchKernelGGL(seg_mean_kernel, dim3(eg_cdiv(c, 64), batch), dim3(256), 0, ST, x, out, hw, c, scale);
+        return eg_check_launch("seg_mean");
+    }
+    int nblk = 0;
+    if (int rc = col_reduce(x, nullptr, nullptr, hw, c, 0, workspace, &nblk, ST, batch)) return rc;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256), batch), dim3(256), 0, ST, workspace, nblk, c, out, (float*)nullptr, scale);
+    return eg_check_launch("seg_mean_finalize");
 }
-extern "C" int eg_seg_dot(const float* dy, const float* x, float* out, int32_t batch, int32_t hw, int32_t c, void* stream) {
+extern "C" int eg_seg_dot(const float* dy, const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream) {
     EG_REQUIRE(dy && x && out && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_seg_dot: bad argument");
-    hipLaunchKernelGGL(seg_dot_kernel, dim3(eg_cdiv(c, 64), batch), dim3(256), 0, ST, dy, x, out, hw, c);
-    return eg_check_launch("seg_dot");
+    if (!workspace || batch > 512) {
+        hipLaunchKernelGGL(seg_dot_kernel, dim3(eg_cdiv(c, 64), batch), dim3(256), 0, ST, dy, x, out, hw, c);
+        return eg_check_launch("seg_dot");
+    }
+    int nblk = 0;
+    if (int rc = col_reduce(dy, x, nullptr, hw, c, 1, workspace, &nblk, ST, batch)) return rc;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256), batch), dim3(256), 0, ST, workspace, nblk, c, (float*)nullptr, out, 1.0f);
+    return eg_check_launch("seg_dot_finalize");
 }
 extern "C" int eg_se_scale(const float* a, const float* gate, const float* add, float* y, int32_t batch, int32_t hw, int32_t c, void* stream) {
     EG_REQUIRE(a && gate && y && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_se_scale: bad argument");

@@ -62,6 +62,12 @@ def raw_linear(x, w, bias=None, relu=False, res=None):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if res is None and M <= 128 and K >= 4096:          # short and deep (emotion_classifer_header.0: K = frames * d_model): split K over workgroups
+        splits = min(64, K // 1024)
+        part = _scratch(x.device, splits * M * N, "splitk")
+        L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(w), K, _ptr(bias), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part), F32, _stream(x.device)),
+                "eg_linear_splitk")
+        return y
     L.check(lib.eg_linear(_ptr(x), K, _ptr(w), K, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), 0, 0, F32, _stream(x.device)),
             "eg_linear")
     return y
@@ -350,7 +356,8 @@ class _SELayer(torch.autograd.Function):
         B, H, W, Cc = yd.shape
         dev = yd.device
         gap = torch.empty(B, Cc, device=dev)
-        L.check(lib.eg_seg_mean(_ptr(yd), _ptr(gap), B, H * W, Cc, 1.0 / (H * W), _stream(dev)), "eg_seg_mean")
+        ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        L.check(lib.eg_seg_mean(_ptr(yd), _ptr(gap), B, H * W, Cc, 1.0 / (H * W), _ptr(ws), _stream(dev)), "eg_seg_mean")
         w1d, b1d, w2d, b2d = _chk(w1), _chk(b1), _chk(w2), _chk(b2)
         h = raw_linear(gap, w1d, b1d, relu=True)
         gate = raw_ew(EW_SIGMOID, raw_linear(h, w2d, b2d))
@@ -367,7 +374,8 @@ class _SELayer(torch.autograd.Function):
         dev = y.device
         do = _chk(dout)
         dgate = torch.empty(B, Cc, device=dev)
-        L.check(lib.eg_seg_dot(_ptr(do), _ptr(y), _ptr(dgate), B, H * W, Cc, _stream(dev)), "eg_seg_dot")
+        ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        L.check(lib.eg_seg_dot(_ptr(do), _ptr(y), _ptr(dgate), B, H * W, Cc, _ptr(ws), _stream(dev)), "eg_seg_dot")
         dz2 = raw_ew(EW_SIGMOID_BWD, dgate, gate)
         dh, dw2, db2 = raw_linear_backward(h, w2, dz2)
         dz1 = raw_ew(EW_RELU_BWD, dh, h)
