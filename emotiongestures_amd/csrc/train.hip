@@ -281,20 +281,34 @@ __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __re
 
 // level 2 for BatchNorm forward, pass 1: mean;  pass 2 (from centred squares): rstd (biased variance) and the running statistics
 // (unbiased variance, momentum) exactly as torch.nn.BatchNorm updates them
+// level 2: one wave per channel; lanes stride over the partials, the two sums are folded with a fixed-order wave reduction (double)
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void fold_partials(const float* __restrict__ part, int nblk, int C, int c, double& s, double& q) {
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    for (int i = lane; i < nblk; i += 64) { a += part[((size_t)i * 2) * C + c]; b += part[((size_t)i * 2 + 1) * C + c]; }
+    s = wave_sum_d(a);
+    q = wave_sum_d(b);
+}
 __global__ __launch_bounds__(256) void bn_mean_kernel(const float* __restrict__ part, int nblk, int C, long rows, float* __restrict__ mean) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0;
-    for (int i = 0; i < nblk; ++i) s += part[((size_t)i * 2) * C + c];
-    mean[c] = (float)(s / (double)rows);
+    double s, q;
+    fold_partials(part, nblk, C, c, s, q);
+    if ((threadIdx.x & 63) == 0) mean[c] = (float)(s / (double)rows);
 }
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long rows, float eps, float momentum,
                                                           const float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double q = 0.0;
-    for (int i = 0; i < nblk; ++i) q += part[((size_t)i * 2) * C + c];
+    double q, unused;
+    fold_partials(part, nblk, C, c, q, unused);
+    if ((threadIdx.x & 63) != 0) return;
     const double var = q / (double)rows;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean) {
@@ -305,11 +319,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0,
                                                            float* __restrict__ o1, float scale) {
-    const int c = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), seg = blockIdx.y;
     if (c >= C) return;
-    part += (size_t)seg * nblk * 2 * C;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nblk; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    double s, q;
+    fold_partials(part + (size_t)seg * nblk * 2 * C, nblk, C, c, s, q);
+    if ((threadIdx.x & 63) != 0) return;
     if (o0) o0[(size_t)seg * C + c] = (float)(s * scale);
     if (o1) o1[(size_t)seg * C + c] = (float)(q * scale);
 }
@@ -648,7 +662,7 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
     const bool fast = (c >= 4) && (1024 % c == 0) && eg_aligned16(a) && (!b || eg_aligned16(b));
     long cap = 512 / nseg;
     if (cap < 1) cap = 1;
-    long nblk = fast ? (rows * c + 16383) / 16384 : (rows + 2047) / 2048;       // fast path: >= 64 KB of input per block
+    long nblk = fast ? (rows * c + 16383) / 16384 : (rows + 255) / 256;         // fast path: >= 64 KB of input per block
     if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     const long rows_per = (rows + nblk - 1) / nblk;
@@ -677,10 +691,10 @@ extern "C" int eg_bn_train_forward(const float* x, const float* gamma, const flo
     EG_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_bn_train_forward: bad argument");
     int nblk = 0;
     if (int rc = col_reduce(x, nullptr, nullptr, rows, c, 0, workspace, &nblk, ST)) return rc;            // pass 1: mean
-    hipLaunchKernelGGL(bn_mean_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, save_mean);
+    hipLaunchKernelGGL(bn_mean_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, save_mean);
     if (int rc = eg_check_launch("bn_mean")) return rc;
     if (int rc = col_reduce(x, nullptr, save_mean, rows, c, 3, workspace, &nblk, ST)) return rc;           // pass 2: centred squares
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
                        running_mean, running_var);
     if (int rc = eg_check_launch("bn_finalize")) return rc;
     hipLaunchKernelGGL(bn_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, save_mean, save_rstd, gamma, beta, y, (size_t)rows * c, c);
@@ -694,7 +708,7 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
     if (int rc = col_reduce(dy, x, save_mean, rows, c, 2, workspace, &nblk, ST)) return rc;        // (sum dy, sum dy*(x - mean))
     float* sum_dyx = workspace + (size_t)2 * 512 * c;           // scratch column behind the partials
     // dbeta receives sum dy directly; sum dy*x goes to the scratch column
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx, 1.0f);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx, 1.0f);
     if (int rc = eg_check_launch("col_finalize")) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, dbeta, sum_dyx, dx, dgamma,
                        (size_t)rows * c, c, 1.0f / (float)rows);
@@ -705,7 +719,7 @@ extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, i
     EG_REQUIRE(a && (o0 || o1) && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_colsum: bad argument");
     int nblk = 0;
     if (int rc = col_reduce(a, b, nullptr, rows, c, b ? 1 : 0, workspace, &nblk, ST)) return rc;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256)), dim3(256), 0, ST, workspace, nblk, c, o0, o1, 1.0f);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, o0, o1, 1.0f);
     return eg_check_launch("col_finalize");
 }
 
@@ -725,7 +739,7 @@ extern "C" int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw
     }
     int nblk = 0;
     if (int rc = col_reduce(x, nullptr, nullptr, hw, c, 0, workspace, &nblk, ST, batch)) return rc;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256), batch), dim3(256), 0, ST, workspace, nblk, c, out, (float*)nullptr, scale);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4), batch), dim3(256), 0, ST, workspace, nblk, c, out, (float*)nullptr, scale);
     return eg_check_launch("seg_mean_finalize");
 }
 extern "C" int eg_seg_dot(const float* dy, const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream) {
@@ -736,7 +750,7 @@ extern "C" int eg_seg_dot(const float* dy, const float* x, float* out, int32_t b
     }
     int nblk = 0;
     if (int rc = col_reduce(dy, x, nullptr, hw, c, 1, workspace, &nblk, ST, batch)) return rc;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 256), batch), dim3(256), 0, ST, workspace, nblk, c, (float*)nullptr, out, 1.0f);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4), batch), dim3(256), 0, ST, workspace, nblk, c, (float*)nullptr, out, 1.0f);
     return eg_check_launch("seg_dot_finalize");
 }
 extern "C" int eg_se_scale(const float* a, const float* gate, const float* add, float* y, int32_t batch, int32_t hw, int32_t c, void* stream) {

@@ -266,7 +266,14 @@ class _Conv3x3(torch.autograd.Function):
         dw = dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         db = raw_colsum(dy2)[0] if ctx.has_b else None
         dx = None
-        if ctx.need_dx:
+        if ctx.need_dx and ctx.stride == 1 and Ci == Co and Ci % 32 == 0:
+            # input gradient of a square stride-1 conv = the forward kernel on the 180-degree rotated, transposed filter
+            # (F.conv2d's dgrad); no 9x im2col intermediate
+            w_rot = w.flip(2, 3).transpose(0, 1).contiguous()                   # [ci][co][2-kh][2-kw] as OIHW of the transposed conv
+            wp = _pack_conv_f32(w_rot, (Ci + 15) // 16 * 16)
+            dx = torch.empty_like(x)
+            L.check(lib.eg_conv3x3(_ptr(dyd), _ptr(wp), None, None, None, _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, F32, _stream(dev)), "eg_conv3x3 (dgrad)")
+        elif ctx.need_dx:
             wmat_t = w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()   # [(kh,kw,ci), co] = Wmat^T
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
             dx = torch.empty_like(x)
