@@ -102,6 +102,7 @@ SIGNATURES = {
     "eg_transpose": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "eg_gemm_tn_workspace_floats": (_L, [_I, _I, _L]),
     "eg_gemm_tn": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _L, _P, _L, _I, _P]),
+    "eg_conv3x3_wgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_im2col3x3": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_subsample": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_im2col1d": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

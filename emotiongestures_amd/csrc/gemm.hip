@@ -120,6 +120,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    // f32 mode: the next K-step's operands are loaded into registers before the MFMAs of the current one (register double
+    // buffer), so the global latency hides under the matrix work (this kernel also carries the training path's fp32 products)
+    f4 px[2], pw[2];
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            const int r = (idx >> 6) * 8 + (idx & 7), q = (idx >> 3) & 7;
+            px[i] = load_x_quad(a, m0 + r, k0 + q * 4, kend);
+            pw[i] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (n0 + r < a.N && k0 + q * 4 < kend) pw[i] = *reinterpret_cast<const f4*>(a.w + (size_t)(n0 + r) * a.ldw + k0 + q * 4);
+        }
+    };
+    if (PREC == EG_PREC_F32) prefetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         if (k0 != kbeg) __syncthreads();
         if (PREC == EG_PREC_F32) {
@@ -127,10 +141,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             for (int i = 0; i < 2; ++i) {
                 const int idx = tid + i * 256;
                 const int r = (idx >> 6) * 8 + (idx & 7), q = (idx >> 3) & 7;
-                lds[q * 64 + r] = load_x_quad(a, m0 + r, k0 + q * 4, kend);
-                f4 wv = (f4){0.f, 0.f, 0.f, 0.f};
-                if (n0 + r < a.N && k0 + q * 4 < kend) wv = *reinterpret_cast<const f4*>(a.w + (size_t)(n0 + r) * a.ldw + k0 + q * 4);
-                lds[512 + q * 64 + r] = wv;
+                lds[q * 64 + r] = px[i];
+                lds[512 + q * 64 + r] = pw[i];
             }
         } else {
             bf8* l8 = reinterpret_cast<bf8*>(lds);
@@ -157,6 +169,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
         __syncthreads();
         if (PREC == EG_PREC_F32) {
+            if (k0 + 32 < kend) prefetch(k0 + 32);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 f4 wv[2], xv[2];

@@ -33,10 +33,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // ---- TN GEMM on fp32 MFMA: C[m,n] (+)= sum_k A[k,m] B[k,n];  workgroup tile 64 x 64, K-step 32, split-K over blockIdx.z ----
 // LDS images [32 k][80] (pitch 80 floats: the two 16-lane halves of a ds_read_b32 hit disjoint bank halves).
 // Operands are swapped (MFMA A = B-tile rows, MFMA B = A-tile rows) so that a lane owns 4 consecutive n of one m.
+// The next K-step's global loads are issued into registers before the MFMAs of the current one (register double buffer).
+// IMPLICIT: B is never materialised -- B[k = output pixel p][n = tap*Cin + ci] = x[b, oy*s + kh - 1, ox*s + kw - 1, ci] is gathered from
+// the NHWC activation while the tile is staged (implicit-GEMM weight gradient of a 3x3 / pad 1 convolution: dW = dY^T im2col(x)).
 constexpr int TN_P = 80;
+struct ConvGeo { int H, W, Ho, Wo, Cin, S; };
+template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
                                                       float* __restrict__ c, int ldc, int M, int N, long K, long k_per_split,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, ConvGeo geo) {
     __shared__ float As[32 * TN_P], Bs[32 * TN_P];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
@@ -48,31 +53,58 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[t][u] = (f4){0.f, 0.f, 0.f, 0.f};
     const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
-    const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
-    for (long k0 = kbeg; k0 < kend; k0 += 32) {
-        __syncthreads();
-        // stage 32 rows x 64 columns of each operand: thread -> (row = i / 16, column quad = i % 16), two passes
+    const bool b_vec = IMPLICIT || (((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0));
+    // staging role of this thread: rows r (+16), column quad cq
+    const int r_ = tid >> 4, cq = (tid & 15) * 4;
+    int tap_dy = 0, tap_dx = 0, ci = 0;
+    if (IMPLICIT) {                         // this thread's column of the implicit matrix is fixed: (tap, ci..ci+3)
+        const int col = n0 + cq, tap = col / geo.Cin;
+        ci = col - tap * geo.Cin;
+        tap_dy = tap / 3 - 1;
+        tap_dx = tap % 3 - 1;
+    }
+    f4 ra[2], rb[2];
+    auto load = [&](long k0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int i = tid + p * 256, r = i >> 4, cq = (i & 15) * 4;
-            const long k = k0 + r;
+            const long k = k0 + r_ + p * 16;
             f4 va = (f4){0.f, 0.f, 0.f, 0.f}, vb = va;
             if (k < kend) {
                 const float* ap = a + (size_t)k * lda + m0 + cq;
-                const float* bp = b + (size_t)k * ldb + n0 + cq;
                 if (a_vec && m0 + cq + 3 < M) va = *reinterpret_cast<const f4*>(ap);
                 else
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (m0 + cq + j < M) va[j] = ap[j];
-                if (b_vec && n0 + cq + 3 < N) vb = *reinterpret_cast<const f4*>(bp);
-                else
+                if (IMPLICIT) {
+                    if (n0 + cq < N) {
+                        const int hw = geo.Ho * geo.Wo;
+                        const int bi = (int)(k / hw), rem = (int)(k - (long)bi * hw), oy = rem / geo.Wo, ox = rem - oy * geo.Wo;
+                        const int iy = oy * geo.S + tap_dy, ix = ox * geo.S + tap_dx;
+                        if (iy >= 0 && iy < geo.H && ix >= 0 && ix < geo.W)
+                            vb = *reinterpret_cast<const f4*>(b + (((size_t)bi * geo.H + iy) * geo.W + ix) * geo.Cin + ci);
+                    }
+                } else {
+                    const float* bp = b + (size_t)k * ldb + n0 + cq;
+                    if (b_vec && n0 + cq + 3 < N) vb = *reinterpret_cast<const f4*>(bp);
+                    else
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n0 + cq + j < N) vb[j] = bp[j];
+                        for (int j = 0; j < 4; ++j) if (n0 + cq + j < N) vb[j] = bp[j];
+                }
             }
-            *reinterpret_cast<f4*>(As + r * TN_P + cq) = va;
-            *reinterpret_cast<f4*>(Bs + r * TN_P + cq) = vb;
+            ra[p] = va;
+            rb[p] = vb;
+        }
+    };
+    load(kbeg);
+    for (long k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();                                    // the previous step's fragment reads are done
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<f4*>(As + (r_ + p * 16) * TN_P + cq) = ra[p];
+            *reinterpret_cast<f4*>(Bs + (r_ + p * 16) * TN_P + cq) = rb[p];
         }
         __syncthreads();
+        if (k0 + 32 < kend) load(k0 + 32);                 // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float av[2], bv[2];
@@ -603,27 +635,47 @@ extern "C" int64_t eg_gemm_tn_workspace_floats(int32_t m, int32_t n, int64_t k) 
     if (splits < 1) splits = 1;
     return splits <= 1 ? 0 : splits * (int64_t)m * n;
 }
-extern "C" int eg_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int32_t m, int32_t n, int64_t k,
-                          float* workspace, int64_t workspace_floats, int32_t accumulate, void* stream) {
-    EG_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && lda >= m && ldb >= n && ldc >= n, EG_ERR_BAD_ARG, "eg_gemm_tn: bad argument");
+namespace {
+int launch_gemm_tn(bool implicit, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int64_t k, float* workspace,
+                   int64_t workspace_floats, int accumulate, ConvGeo geo, hipStream_t st) {
     const int64_t need = eg_gemm_tn_workspace_floats(m, n, k);
     EG_REQUIRE(need == 0 || (workspace && workspace_floats >= need), EG_ERR_WORKSPACE, "eg_gemm_tn: workspace %lld < %lld floats",
                (long long)workspace_floats, (long long)need);
     const int splits = need ? (int)(need / ((int64_t)m * n)) : 1;
     const long kps = ((k + splits - 1) / splits + 31) / 32 * 32;
     const int nz = (int)((k + kps - 1) / kps);
-    EgProfScope prof(7, 2.0 * m * (double)n * (double)k, ST);
-    if (nz <= 1 && !accumulate) {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(eg_cdiv(m, 64), eg_cdiv(n, 64), 1), dim3(256), 0, ST, a, lda, b, ldb, c, ldc, m, n, (long)k, (long)k,
-                           (float*)nullptr);
-        return eg_check_launch("gemm_tn");
-    }
-    float* part = workspace;
-    EG_REQUIRE(part && workspace_floats >= (int64_t)nz * m * n, EG_ERR_WORKSPACE, "eg_gemm_tn: accumulate / split-K needs a workspace");
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(eg_cdiv(m, 64), eg_cdiv(n, 64), nz), dim3(256), 0, ST, a, lda, b, ldb, c, ldc, m, n, (long)k, kps, part);
+    EgProfScope prof(7, 2.0 * m * (double)n * (double)k, st);
+    const bool direct = nz <= 1 && !accumulate;
+    float* part = direct ? nullptr : workspace;
+    EG_REQUIRE(direct || (part && workspace_floats >= (int64_t)nz * m * n), EG_ERR_WORKSPACE, "eg_gemm_tn: accumulate / split-K needs a workspace");
+    dim3 grid(eg_cdiv(m, 64), eg_cdiv(n, 64), direct ? 1 : nz);
+    if (implicit) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m, n, (long)k, direct ? (long)k : kps, part, geo);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m, n, (long)k, direct ? (long)k : kps, part, geo);
     if (int rc = eg_check_launch("gemm_tn")) return rc;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(eg_cdiv(m * n, 256)), dim3(256), 0, ST, part, c, ldc, m, n, nz, accumulate);
+    if (direct) return EG_OK;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(eg_cdiv(m * n, 256)), dim3(256), 0, st, part, c, ldc, m, n, nz, accumulate);
     return eg_check_launch("gemm_tn_reduce");
+}
+}  // namespace
+
+extern "C" int eg_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int32_t m, int32_t n, int64_t k,
+                          float* workspace, int64_t workspace_floats, int32_t accumulate, void* stream) {
+    EG_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && lda >= m && ldb >= n && ldc >= n, EG_ERR_BAD_ARG, "eg_gemm_tn: bad argument");
+    ConvGeo geo = {0, 0, 0, 0, 0, 0};
+    return launch_gemm_tn(false, a, lda, b, ldb, c, ldc, m, n, k, workspace, workspace_floats, accumulate, geo, ST);
+}
+
+// Weight gradient of nn.Conv2d(k=3, pad=1, stride s) on NHWC activations as an implicit GEMM (no im2col buffer):
+// dw_mat[co][(kh*3 + kw)*Cin + ci] = sum over (b, oy, ox) of dy[b,oy,ox,co] * x[b, oy*s + kh - 1, ox*s + kw - 1, ci].   Cin % 4 == 0.
+// workspace >= eg_gemm_tn_workspace_floats(cout, 9*cin, B*Ho*Wo).
+extern "C" int eg_conv3x3_wgrad(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                int32_t stride, float* workspace, int64_t workspace_floats, void* stream) {
+    EG_REQUIRE(x && dy && dw_mat && batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && (stride == 1 || stride == 2), EG_ERR_BAD_ARG,
+               "eg_conv3x3_wgrad: bad argument");
+    EG_REQUIRE((cin & 3) == 0 && eg_aligned16(x), EG_ERR_ALIGN, "eg_conv3x3_wgrad: Cin %% 4 and a 16-byte aligned activation");
+    ConvGeo geo = {h, w, (h + 2 - 3) / stride + 1, (w + 2 - 3) / stride + 1, cin, stride};
+    const int64_t k = (int64_t)batch * geo.Ho * geo.Wo;
+    return launch_gemm_tn(true, dy, cout, x, 0, dw_mat, 9 * cin, cout, 9 * cin, k, workspace, workspace_floats, 0, geo, ST);
 }
 
 extern "C" int eg_im2col3x3(const float* x, float* col, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, int32_t backward,

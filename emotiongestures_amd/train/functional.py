@@ -260,9 +260,16 @@ class _Conv3x3(torch.autograd.Function):
         Ho, Wo = dyd.shape[1], dyd.shape[2]
         dev = x.device
         dy2 = dyd.view(B * Ho * Wo, Co)
-        col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
-        L.check(lib.eg_im2col3x3(_ptr(x), _ptr(col), B, H, W, Ci, ctx.stride, 0, _stream(dev)), "eg_im2col3x3")
-        dwm = raw_gemm_tn(dy2, col)                                         # [Co, (kh,kw,ci)]
+        if Ci % 4 == 0:             # implicit GEMM over the output pixels (no im2col buffer)
+            dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
+            need = lib.eg_gemm_tn_workspace_floats(Co, 9 * Ci, B * Ho * Wo)
+            ws = _scratch(dev, need, "tn") if need else None
+            L.check(lib.eg_conv3x3_wgrad(_ptr(x), _ptr(dy2), _ptr(dwm), B, H, W, Ci, Co, ctx.stride, _ptr(ws), ws.numel() if ws is not None else 0,
+                                         _stream(dev)), "eg_conv3x3_wgrad")
+        else:                       # the stem (1 input channel)
+            col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
+            L.check(lib.eg_im2col3x3(_ptr(x), _ptr(col), B, H, W, Ci, ctx.stride, 0, _stream(dev)), "eg_im2col3x3")
+            dwm = raw_gemm_tn(dy2, col)                                     # [Co, (kh,kw,ci)]
         dw = dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         db = raw_colsum(dy2)[0] if ctx.has_b else None
         dx = None

@@ -344,6 +344,10 @@ int eg_transpose(const float* x, int32_t ldx, int32_t rows, int32_t cols, float*
 int64_t eg_gemm_tn_workspace_floats(int32_t m, int32_t n, int64_t k);
 int eg_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int32_t m, int32_t n, int64_t k,
                float* workspace, int64_t workspace_floats, int32_t accumulate, void* stream);
+/* weight gradient of a 3x3 / pad 1 / stride s convolution as an implicit TN GEMM over the output pixels (no im2col buffer):
+ * dw_mat [Cout][(kh*3+kw)*Cin + ci]; Cin % 4 == 0; workspace >= eg_gemm_tn_workspace_floats(cout, 9*cin, B*Ho*Wo) */
+int eg_conv3x3_wgrad(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                     int32_t stride, float* workspace, int64_t workspace_floats, void* stream);
 /* 3x3 / pad 1 / stride s, NHWC: forward  col[(b,oy,ox)][tap*C + c] = x[b, oy*s+kh-1, ox*s+kw-1, c];
  * backward (x = dcol, col = dx [B,H,W,C]): the transpose in gather form (F.conv2d's input gradient after the GEMM). */
 int eg_im2col3x3(const float* x, float* col, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t stride, int32_t backward, void* stream);
