@@ -277,6 +277,54 @@ def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
     return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
 
 
+class FrechetAccumulator:
+    """Running first and second moments of feature rows ON THE DEVICE ("(sum x, sum x x^T) accumulators"):
+    the Frechet distance of model/FHD_score.py:159-217 needs only the mean and covariance of the [N, 512] feature rows, so a
+    long evaluation (or several ranks) never has to hold or gather the rows themselves.
+
+    push(rows [N, D] on the GPU):  s += colsum(x - c);  S += (x - c)^T (x - c)   (eg_colsum / eg_gemm_tn, fp32, fixed-order sums;
+    c = a fixed shift -- the first batch's column mean by default -- keeps S - s s^T / n well conditioned).
+    stats() -> (mu, sigma) in float64 on the host, the same estimator as np.mean / np.cov(rowvar=False).
+    all_reduce(): sums (n, s, S) over the ranks of a process group (D + D^2 + 1 numbers per rank); every rank
+    must use the same shift (pass `shift=` explicitly, e.g. zeros)."""
+
+    def __init__(self, dim: int = 512, device="cuda", shift: Optional[torch.Tensor] = None):
+        self.dim, self.device = dim, torch.device(device)
+        self.n = 0
+        self.s = torch.zeros(dim, device=self.device)
+        self.S = torch.zeros(dim, dim, device=self.device)
+        self.shift = None if shift is None else shift.to(self.device, torch.float32).contiguous()
+
+    def push(self, rows: torch.Tensor) -> None:
+        from .train import functional as TFn
+        x = rows.detach().reshape(-1, self.dim)
+        if not x.is_cuda:
+            raise L.EgError("FrechetAccumulator.push: rows must be on the GPU (no CPU fallback)")
+        x = x.float().contiguous()
+        if self.shift is None:
+            self.shift = TFn.raw_ew(TFn.EW_SCALE, TFn.raw_colsum(x)[0], None, 1.0 / x.shape[0])
+        xc = ops.add_rows(x, TFn.raw_ew(TFn.EW_SCALE, self.shift, None, -1.0).view(1, -1), period=1)
+        self.s = TFn.raw_ew(TFn.EW_ADD, self.s, TFn.raw_colsum(xc)[0])
+        TFn.raw_gemm_tn(xc, xc, out=self.S, accumulate=True)
+        self.n += x.shape[0]
+
+    def all_reduce(self, group=None) -> None:
+        import torch.distributed as dist
+        n = torch.tensor([float(self.n)], device=self.device, dtype=torch.float64)
+        for t in (n, self.s, self.S):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        self.n = int(round(float(n.item())))
+
+    def stats(self):
+        n = self.n
+        if n < 2:
+            raise ValueError("FrechetAccumulator.stats: need at least two rows")
+        s, S = self.s.double().cpu().numpy(), self.S.double().cpu().numpy()
+        mu = self.shift.double().cpu().numpy() + s / n
+        sigma = (S - np.outer(s, s) / n) / (n - 1)
+        return mu, (sigma + sigma.T) / 2
+
+
 def calculate_diversity(activations: np.ndarray, labels, diversity_times: int = 5) -> np.float32:
     """model/FHD_score.py:270-286: mean L2 distance of `diversity_times` random pairs (np.random.randint twice, in that order)."""
     num = len(labels)
