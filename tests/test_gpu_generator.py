@@ -199,9 +199,15 @@ def test_errors_are_loud():
     model.to(dev())
     with pytest.raises(EgError):                       # wrong spectrogram width
         model(t["spec"][:, :, :100].to(dev()), t["text"].to(dev()), t["pre_pose"].to(dev()))
+    # train() mode: the spatial generator runs on the differentiable HIP operators (tests/test_gpu_training.py); modules without a
+    # train-mode path still refuse instead of falling back
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev()).train()
+    with pytest.raises(NotImplementedError):
+        vae.sample(t["label"].to(dev()), z=t["z"])
     model.train()
-    with pytest.raises(NotImplementedError):           # training forward is not built: refuse, do not fall back
-        model(t["spec"].to(dev()), t["text"].to(dev()), t["pre_pose"].to(dev()))
+    pose = model(t["spec"].to(dev()), t["text"].to(dev()), t["pre_pose"].to(dev()))[0]
+    assert pose.requires_grad and tuple(pose.shape) == (1, 34, 126)
 
 
 def test_cvae_matches_reference_golden():
