@@ -145,6 +145,7 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
     ap.add_argument("--fold-affine", action="store_true",
                     help="fold the Dropout-only Linear chains at pack time (fewer launches and FLOPs than the reference graph; reported in config)")
+    ap.add_argument("--no-fuse-se", action="store_true", help="A/B: keep the SE tail of identity blocks as a separate pass (round-1 data flow)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]: one step = generator forward + 100*smooth_l1 + CE + backward + bucketed gradient "
                          "all-reduce (RCCL) + fused Adam on --train-batch clips per GPU (fp32 operators)")
@@ -303,6 +304,7 @@ def main():
     lanes = 1 if args.no_graph else max(1, args.in_flight)
     gen.concurrent = lanes == 1 and (args.concurrent or not args.no_concurrent)
     gen.fold_affine = bool(args.fold_affine)
+    gen.fuse_se = not args.no_fuse_se
     B = args.batch
     inp = make_inputs(B, seed=1000 + rank)          # every rank generates its own shard of clips
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
@@ -451,7 +453,9 @@ def main():
         cap = 400 * max(args.steps, 1)
         gen.concurrent = False                  # per-launch durations are only meaningful without overlapping side streams
         eager_step = make_step(gen, vae, mel, None)
-        eager_step()
+        for _ in range(3):                      # warm: clocks up, kernels / weights resident, before per-launch events are taken
+            eager_step()
+        torch.cuda.synchronize(dev)
         _lib.check(lib.eg_profile_enable(cap), "eg_profile_enable")
         for _ in range(args.steps):
             eager_step()                    # per-launch event timing runs eagerly (events are not part of the graph)

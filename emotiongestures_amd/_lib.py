@@ -74,6 +74,8 @@ SIGNATURES = {
     "eg_mel_workspace_bytes": (_L, [_I, _I]),
     "eg_melspectrogram": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "eg_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_conv3x3_se": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_se_gate_pre": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eg_conv3x3_gap_tiles": (_I, [_I, _I, _I, _I, _I]),
     "eg_stem_conv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eg_se_gate": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

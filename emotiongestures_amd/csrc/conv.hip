@@ -24,6 +24,9 @@ struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* scale; const float* shift;
     float* y; float* gap;
     int H, W, Ho, Wo, cout, relu, nchw, tiles_x, tiles;
+    // fused SE tail (SEBasicBlock.forward, ResNetBlocks.py:28-36, identity shortcut): v = relu(v * gate[b, co] + res[pixel, co])
+    // applied after the BatchNorm affine; gate comes from se_gate_pre_kernel (computed BEFORE this convolution runs)
+    const float* gate = nullptr; const float* res = nullptr; int relu2 = 0;
 };
 
 template <int S, int TH> struct ConvGeom {
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
         const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
         const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
         const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
+        const f4 gt = (a.gate && co < a.cout) ? *reinterpret_cast<const f4*>(a.gate + (size_t)b * a.cout + co) : (f4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int id = wave * MT + t;
@@ -135,6 +139,12 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             v = v * sc + sh;
+            if (a.gate) v = v * gt;
+            if (a.res && valid && co < a.cout) v += *reinterpret_cast<const f4*>(a.res + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.cout + co);
+            if (a.relu2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
             if (valid) {
                 if (!a.nchw) {
                     if (co < a.cout)
@@ -409,6 +419,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
         const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
         const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
+        const f4 gt = (a.gate && co < a.cout) ? *reinterpret_cast<const f4*>(a.gate + (size_t)b * a.cout + co) : (f4){1.f, 1.f, 1.f, 1.f};
+        const float* __restrict__ rb = a.res ? a.res + (size_t)b * hw * a.cout : nullptr;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             f4 v = acc[t][n] + bi;
@@ -417,6 +429,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             v = v * sc + sh;
+            if (a.gate) v = v * gt;
+            if (rb && pixo[t] >= 0 && co < a.cout) v += *reinterpret_cast<const f4*>(rb + pixo[t] * a.cout + co);
+            if (a.relu2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
             if (pixo[t] >= 0) {
                 if (!a.nchw) {
                     if (co < a.cout) *reinterpret_cast<f4*>(yb + pixo[t] * a.cout + co) = v;
@@ -521,6 +539,93 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     }
 }
 
+// ---- SE gate computed BEFORE conv2 runs ("gate from the input's moments") ------------------------------------------------------
+// gate = sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2), y = BN2(conv2(t1)) (ResNetBlocks.py:28-30,92-96).  The spatial mean of a 3x3 / pad 1 /
+// stride 1 convolution is linear in shifted-window sums of its INPUT:
+//     mean_hw(conv2(t1))[co] = 1/HW * sum_{tap, ci} W[co][ci][tap] * S[tap][ci],   S[(kh,kw)][ci] = sum of t1[.., ci] over the rows / columns
+//     the tap reaches: everything, minus the last (kh = 0) or first (kh = 2) row, minus the last (kw = 0) or first (kw = 2) column, plus
+//     the doubly removed corner.
+// The total comes from conv1's per-tile channel sums (its `gap` output), the four border lines and corners are read from t1 itself.
+// With the gate known up front, conv2's epilogue applies relu(y * gate + x) directly: the block's y tensor is never written and the
+// separate tail pass (2 reads + 1 write of the activation) disappears.  One workgroup per clip; fixed-order sums (deterministic).
+__global__ __launch_bounds__(256) void se_gate_pre_kernel(const float* __restrict__ t1, const float* __restrict__ gap, int tiles,
+                                                          const float* __restrict__ w2img, const float* __restrict__ scale2,
+                                                          const float* __restrict__ shift2, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ wf2, const float* __restrict__ bf2, float* __restrict__ gate,
+                                                          int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, t = threadIdx.x, G = 256 / C, c = t % C, g = t / C, R = C >> 3;
+    float* part = sm;                   // [5][256]: total, first row, last row, first column, last column (per thread)
+    float* S = sm + 5 * 256;            // [9][C]
+    float* zp = S + 9 * C;              // [G][C]
+    float* m = zp + 256;                // [C]
+    float* hbuf = m + C;                // [R]
+    const float* tb = t1 + (size_t)b * H * W * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    for (int i = g; i < tiles; i += G) s0 += gap[((size_t)b * tiles + i) * C + c];
+    for (int x = g; x < W; x += G) {
+        s1 += tb[(size_t)x * C + c];
+        s2 += tb[((size_t)(H - 1) * W + x) * C + c];
+    }
+    for (int y = g; y < H; y += G) {
+        s3 += tb[((size_t)y * W) * C + c];
+        s4 += tb[((size_t)y * W + W - 1) * C + c];
+    }
+    part[t] = s0; part[256 + t] = s1; part[512 + t] = s2; part[768 + t] = s3; part[1024 + t] = s4;
+    __syncthreads();
+    if (t < C) {
+        float T = 0.f, R0 = 0.f, RL = 0.f, C0 = 0.f, CL = 0.f;
+        for (int j = 0; j < G; ++j) {
+            T += part[j * C + t]; R0 += part[256 + j * C + t]; RL += part[512 + j * C + t]; C0 += part[768 + j * C + t]; CL += part[1024 + j * C + t];
+        }
+        const float c00 = tb[t], c0L = tb[(size_t)(W - 1) * C + t], cL0 = tb[((size_t)(H - 1) * W) * C + t], cLL = tb[((size_t)(H - 1) * W + W - 1) * C + t];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float rex = kh == 0 ? RL : (kh == 2 ? R0 : 0.f);
+                const float cex = kw == 0 ? CL : (kw == 2 ? C0 : 0.f);
+                float corner = 0.f;
+                if (kh == 0 && kw == 0) corner = cLL;
+                if (kh == 0 && kw == 2) corner = cL0;
+                if (kh == 2 && kw == 0) corner = c0L;
+                if (kh == 2 && kw == 2) corner = c00;
+                S[(kh * 3 + kw) * C + t] = T - rex - cex + corner;
+            }
+    }
+    __syncthreads();
+    {   // z[co] = sum over (tap, ci) of W[tap][ci/4][co][4] * S[tap][ci]; the 9*C/4 quads are dealt to the G thread groups
+        const f4* w4 = reinterpret_cast<const f4*>(w2img);
+        const int nq = 9 * (C >> 2);
+        float z = 0.f;
+        for (int q = g; q < nq; q += G) {
+            const int tap = q / (C >> 2), cq = q - tap * (C >> 2);
+            const f4 wv = w4[(size_t)q * C + c];
+            const float* sp = S + tap * C + cq * 4;
+            z += (wv[0] * sp[0] + wv[1] * sp[1]) + (wv[2] * sp[2] + wv[3] * sp[3]);
+        }
+        zp[g * C + c] = z;
+    }
+    __syncthreads();
+    if (t < C) {
+        float z = 0.f;
+        for (int j = 0; j < G; ++j) z += zp[j * C + t];
+        m[t] = z / (float)(H * W) * scale2[t] + shift2[t];
+    }
+    __syncthreads();
+    if (t < R) {
+        float s = b1[t];
+        for (int cc = 0; cc < C; ++cc) s += w1[t * C + cc] * m[cc];
+        hbuf[t] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    if (t < C) {
+        float s = bf2[t];
+        for (int j = 0; j < R; ++j) s += wf2[t * R + j] * hbuf[j];
+        gate[(size_t)b * C + t] = 1.f / (1.f + expf(-s));
+    }
+}
+
 // ---- SE tail: out = relu(y*gate + residual) ----------------------------------------------------------
 __global__ __launch_bounds__(256) void se_tail_identity_kernel(const f4* __restrict__ y, const float* __restrict__ gate,
                                                                const f4* __restrict__ res, f4* __restrict__ out,
@@ -620,13 +725,23 @@ extern "C" int64_t eg_conv3x3_packed_floats(int32_t cin, int32_t cout_pad) {
 extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
                           float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
                           int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
+    return eg_conv3x3_se(x, w, bias, scale, shift, nullptr, nullptr, y, gap_partial, batch, h, wdt, cin, cout, stride, relu, nchw_out, precision, stream);
+}
+
+extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate,
+                             const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin,
+                             int32_t cout, int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
     EG_REQUIRE(x && w && y && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3: null pointer or empty shape");
+    EG_REQUIRE((gate == nullptr) == (residual == nullptr), EG_ERR_BAD_ARG, "eg_conv3x3_se: gate and residual come together");
+    EG_REQUIRE(!gate || (!nchw_out && stride == 1 && cout % 4 == 0 && eg_aligned16(gate) && eg_aligned16(residual) && residual != y), EG_ERR_BAD_ARG,
+               "eg_conv3x3_se: the fused SE tail needs NHWC output, stride 1, cout %% 4 == 0 and a residual buffer distinct from y");
     EG_REQUIRE(eg_aligned16(x) && eg_aligned16(w) && eg_aligned16(y), EG_ERR_ALIGN, "eg_conv3x3: pointers must be 16-byte aligned");
     EG_REQUIRE(stride == 1 || stride == 2, EG_ERR_UNSUPPORTED, "eg_conv3x3: stride %d", stride);
     EG_REQUIRE(precision >= 0 && precision <= 2, EG_ERR_BAD_ARG, "eg_conv3x3: precision %d", precision);
     EG_REQUIRE(nchw_out || (cout % 4 == 0), EG_ERR_UNSUPPORTED, "eg_conv3x3: NHWC output needs cout %% 4 == 0");
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.gap = gap_partial;
+    a.gate = gate; a.res = residual; a.relu2 = gate ? 1 : 0;
     a.H = h; a.W = wdt; a.Ho = (h + 2 - 3) / stride + 1; a.Wo = (wdt + 2 - 3) / stride + 1;
     a.cout = cout; a.relu = relu; a.nchw = nchw_out;
     const int th = conv_tile_rows(cin, cout, stride);
@@ -673,6 +788,18 @@ extern "C" int eg_se_gate(const float* gap_partial, int32_t tiles, const float* 
     hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(c <= 128 ? 128 : 256), 0, (hipStream_t)stream, gap_partial, tiles, w1, b1, w2, b2,
                        gate, c, 1.0f / (float)hw);
     return eg_check_launch("se_gate");
+}
+
+extern "C" int eg_se_gate_pre(const float* t1, const float* gap_partial, int32_t tiles, const float* conv2_w, const float* scale2,
+                              const float* shift2, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                              int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream) {
+    EG_REQUIRE(t1 && gap_partial && conv2_w && scale2 && shift2 && w1 && b1 && w2 && b2 && gate && batch > 0 && h > 1 && wdt > 1, EG_ERR_BAD_ARG,
+               "eg_se_gate_pre: null pointer or empty shape");
+    EG_REQUIRE(c % 8 == 0 && c <= 256 && 256 % c == 0 && eg_aligned16(conv2_w), EG_ERR_UNSUPPORTED, "eg_se_gate_pre: C=%d", c);
+    const size_t smem = sizeof(float) * (5 * 256 + 9 * (size_t)c + 256 + c + (c >> 3) + 4);
+    hipLaunchKernelGGL(se_gate_pre_kernel, dim3(batch), dim3(256), smem, (hipStream_t)stream, t1, gap_partial, tiles, conv2_w, scale2, shift2, w1,
+                       b1, w2, b2, gate, h, wdt, c);
+    return eg_check_launch("se_gate_pre");
 }
 
 extern "C" int eg_se_residual_relu(const float* y, const float* gate, const float* x_in, const float* ds_w,

@@ -245,6 +245,7 @@ struct EgGenerator {
     std::vector<BlockW> blocks;
     ConvW final_conv;
     LinW a_fc1, a_fc2, emosem0, emo2, sem2, fus0, fus2, cls[4], post[4], prior_h0, prior_h2, txt_dec;
+    bool fuse_se = true;        // identity SE blocks: gate from input moments + tail in conv2's epilogue (cfg.reserved[3] = 1 disables)
     bool fold = false;          // cfg.reserved[2]: the chains below replace their members
     LinW f_audio, f_emo, f_sem, f_post, f_prior;
     int64_t pos_table;
@@ -437,6 +438,18 @@ int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec,
             const BlockW& bw = g->blocks[bi];
             const int t1 = (xi + 1) % 3, t2 = (xi + 2) % 3;
             const int ho = (h + 2 - 3) / bw.stride + 1, wo = (wd + 2 - 3) / bw.stride + 1;
+            if (!bw.ds && g->fuse_se) {
+                // identity block: gate from the moments of conv1's output, then conv2 with relu(y * gate + x) in its epilogue --
+                // y is never materialised and the separate tail pass disappears (conv.hip: se_gate_pre_kernel)
+                EG_TRY(run_conv(arena, bw.c1, bufs[xi], bufs[t1], gap, B, h, wd, 1, 0, prec, st));
+                const int tiles1 = eg_conv3x3_gap_tiles(h, wd, bw.cin, bw.cout, 1);
+                EG_TRY(eg_se_gate_pre(bufs[t1], gap, tiles1, arena + bw.c2.w, arena + bw.c2.scale, arena + bw.c2.shift, arena + bw.se_w1,
+                                      arena + bw.se_b1, arena + bw.se_w2, arena + bw.se_b2, gate, B, ho, wo, bw.cout, st));
+                EG_TRY(eg_conv3x3_se(bufs[t1], arena + bw.c2.w, nullptr, arena + bw.c2.scale, arena + bw.c2.shift, gate, bufs[xi], bufs[t2], nullptr, B,
+                                     ho, wo, bw.cout, bw.cout, 1, 0, 0, prec, st));
+                xi = t2; h = ho; wd = wo;
+                continue;
+            }
             EG_TRY(run_conv(arena, bw.c1, bufs[xi], bufs[t1], nullptr, B, h, wd, 1, 0, prec, st));
             EG_TRY(run_conv(arena, bw.c2, bufs[t1], bufs[t2], gap, B, ho, wo, 0, 0, prec, st));
             const int tiles = eg_conv3x3_gap_tiles(ho, wo, bw.cout, bw.cout, 1);
@@ -574,6 +587,7 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     g->keep_taps = cfg->reserved[0] != 0;
     g->concurrent = cfg->reserved[1] != 0;
     g->fold = cfg->reserved[2] != 0;
+    g->fuse_se = cfg->reserved[3] == 0;
     const EgGeneratorConfig& c = g->cfg;
     g->H1 = c.n_mels; g->W1 = c.spec_len;
     g->H2 = (g->H1 - 1) / 2 + 1; g->W2 = (g->W1 - 1) / 2 + 1;

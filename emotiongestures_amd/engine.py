@@ -35,7 +35,7 @@ class GeneratorEngine:
 
     def __init__(self, *, frames=34, pose_dim=126, prior_frames=4, chunk=4, d_model=512, d_inner=2048, n_layers=3,
                  n_head=8, d_k=64, n_mels=128, spec_len=124, text_len=60, n_words=200, embed_dim=300, tcn_hidden=300,
-                 tcn_layers=3, variant="spatial", precision="f32", n_position=60, keep_taps=False, concurrent=False, fold_affine=False):
+                 tcn_layers=3, variant="spatial", precision="f32", n_position=60, keep_taps=False, concurrent=False, fold_affine=False, fuse_se=True):
         lib = L.load()
         cfg = L.EgGeneratorConfig()
         L.check(lib.eg_generator_default_config(C.byref(cfg)), "eg_generator_default_config")
@@ -49,6 +49,7 @@ class GeneratorEngine:
         cfg.reserved[0] = 1 if keep_taps else 0
         cfg.reserved[1] = 1 if concurrent else 0
         cfg.reserved[2] = 1 if fold_affine else 0
+        cfg.reserved[3] = 0 if fuse_se else 1
         self.cfg = cfg
         h = C.c_void_p()
         L.check(lib.eg_generator_create(C.byref(cfg), C.byref(h)), "eg_generator_create")

@@ -566,6 +566,7 @@ class Transformer(nn.Module):
         self.keep_taps = False
         self.concurrent = False          # fork the text / prior branches onto side streams (engine option)
         self.fold_affine = False         # fold the Dropout-only Linear chains at pack time (fewer launches / FLOPs; off for parity runs)
+        self.fuse_se = True              # identity SE blocks: gate from conv1's output moments, tail in conv2's epilogue (same arithmetic order per element)
         self._engine: Optional[GeneratorEngine] = None
         self._engine_key = None
 
@@ -578,11 +579,11 @@ class Transformer(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise L.EgError("emotiongestures_amd.Transformer runs only on a GPU (model.to('cuda')); there is no CPU fallback")
-        key = (str(dev), self.precision, self.keep_taps, self.concurrent, self.fold_affine, self._weights_version())
+        key = (str(dev), self.precision, self.keep_taps, self.concurrent, self.fold_affine, self.fuse_se, self._weights_version())
         if self._engine is None or self._engine_key != key:
-            if self._engine is None or self._engine_key[:5] != key[:5]:
+            if self._engine is None or self._engine_key[:6] != key[:6]:
                 self._engine = GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=self.concurrent,
-                                               fold_affine=self.fold_affine, **self._cfg)
+                                               fold_affine=self.fold_affine, fuse_se=self.fuse_se, **self._cfg)
             self._engine.load_weights(self.state_dict(), dev)
             self._engine_key = key
         return self._engine

@@ -127,7 +127,9 @@ typedef struct EgGeneratorConfig {
     int32_t reserved[5];        /* [0] keep_taps  [1] branch streams  [2] fold_affine: fold the Dropout-only Linear chains
                                    (post_projector :528-536, emotion_proj / semantic_proj :488-496,509-517, post_header :360-364,
                                    audio fc1 -> fc2 :128-130) into one product each at pack time -- exact algebra in eval mode,
-                                   different rounding, fewer FLOPs than the reference graph: OFF for parity runs */
+                                   different rounding, fewer FLOPs than the reference graph: OFF for parity runs
+                                   [3] 1 = keep the SE tail of identity blocks as a separate pass (default 0: gate from conv1's output
+                                   moments + relu(y*gate + x) in conv2's epilogue, eg_se_gate_pre / eg_conv3x3_se) */
 } EgGeneratorConfig;
 
 typedef struct EgGenerator EgGenerator;
@@ -229,6 +231,18 @@ int eg_conv3x3(const float* x, const float* w, const float* bias, const float* s
                float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
                int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
 int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride);
+/* eg_conv3x3 with the SEBasicBlock tail of an identity block fused into the epilogue (ResNetBlocks.py:28-36):
+ *   y = relu(BN(conv(x)) * gate[b, co] + residual[pixel, co]),   gate [B, Cout] from eg_se_gate_pre, residual NHWC like y.
+ * gate == residual == NULL: plain eg_conv3x3. */
+int eg_conv3x3_se(const float* x, const float* w_packed, const float* bias, const float* scale, const float* shift, const float* gate,
+                  const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
+                  int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
+/* SELayer gate of a block computed BEFORE its conv2 runs: the spatial mean of BN2(conv2(t1)) is linear in window sums of t1
+ * (total from conv1's gap partials, border lines / corners read from t1), so gate = sigmoid(W2 relu(W1 mean + b1) + b2) needs
+ * only t1 and conv2's fp32 weight image (the head of its EG_PACK_CONV3X3 entry).  t1 NHWC [B,H,W,C], conv2: C -> C, stride 1. */
+int eg_se_gate_pre(const float* t1, const float* gap_partial, int32_t tiles, const float* conv2_w_packed, const float* scale2,
+                   const float* shift2, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                   int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream);
 /* size in floats of one EG_PACK_CONV3X3 image (fp32 image + bf16 hi/lo images) */
 int64_t eg_conv3x3_packed_floats(int32_t cin, int32_t cout_pad);
 
