@@ -548,35 +548,40 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 // The total comes from conv1's per-tile channel sums (its `gap` output), the four border lines and corners are read from t1 itself.
 // With the gate known up front, conv2's epilogue applies relu(y * gate + x) directly: the block's y tensor is never written and the
 // separate tail pass (2 reads + 1 write of the activation) disappears.  One workgroup per clip; fixed-order sums (deterministic).
-__global__ __launch_bounds__(256) void se_gate_pre_kernel(const float* __restrict__ t1, const float* __restrict__ gap, int tiles,
-                                                          const float* __restrict__ w2img, const float* __restrict__ scale2,
-                                                          const float* __restrict__ shift2, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                          const float* __restrict__ wf2, const float* __restrict__ bf2, float* __restrict__ gate,
-                                                          int H, int W, int C) {
+constexpr int GP_T = 1024;      // threads per clip: G = 1024 / C thread groups share every sum (many loads in flight: the kernel is latency bound)
+__global__ __launch_bounds__(GP_T) void se_gate_pre_kernel(const float* __restrict__ t1, const float* __restrict__ gap, int tiles,
+                                                           const float* __restrict__ w2img, const float* __restrict__ scale2,
+                                                           const float* __restrict__ shift2, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ wf2, const float* __restrict__ bf2, float* __restrict__ gate,
+                                                           int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, t = threadIdx.x, G = 256 / C, c = t % C, g = t / C, R = C >> 3;
-    float* part = sm;                   // [5][256]: total, first row, last row, first column, last column (per thread)
-    float* S = sm + 5 * 256;            // [9][C]
+    const int b = blockIdx.x, t = threadIdx.x, G = GP_T / C, c = t % C, g = t / C, R = C >> 3;
+    float* part = sm;                   // [5][GP_T]: total, first row, last row, first column, last column (per thread)
+    float* S = sm + 5 * GP_T;           // [9][C]
     float* zp = S + 9 * C;              // [G][C]
-    float* m = zp + 256;                // [C]
+    float* m = zp + GP_T;               // [C]
     float* hbuf = m + C;                // [R]
     const float* tb = t1 + (size_t)b * H * W * C;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll 4
     for (int i = g; i < tiles; i += G) s0 += gap[((size_t)b * tiles + i) * C + c];
+#pragma unroll 4
     for (int x = g; x < W; x += G) {
         s1 += tb[(size_t)x * C + c];
         s2 += tb[((size_t)(H - 1) * W + x) * C + c];
     }
+#pragma unroll 4
     for (int y = g; y < H; y += G) {
         s3 += tb[((size_t)y * W) * C + c];
         s4 += tb[((size_t)y * W + W - 1) * C + c];
     }
-    part[t] = s0; part[256 + t] = s1; part[512 + t] = s2; part[768 + t] = s3; part[1024 + t] = s4;
+    part[t] = s0; part[GP_T + t] = s1; part[2 * GP_T + t] = s2; part[3 * GP_T + t] = s3; part[4 * GP_T + t] = s4;
     __syncthreads();
     if (t < C) {
         float T = 0.f, R0 = 0.f, RL = 0.f, C0 = 0.f, CL = 0.f;
         for (int j = 0; j < G; ++j) {
-            T += part[j * C + t]; R0 += part[256 + j * C + t]; RL += part[512 + j * C + t]; C0 += part[768 + j * C + t]; CL += part[1024 + j * C + t];
+            T += part[j * C + t]; R0 += part[GP_T + j * C + t]; RL += part[2 * GP_T + j * C + t]; C0 += part[3 * GP_T + j * C + t];
+            CL += part[4 * GP_T + j * C + t];
         }
         const float c00 = tb[t], c0L = tb[(size_t)(W - 1) * C + t], cL0 = tb[((size_t)(H - 1) * W) * C + t], cLL = tb[((size_t)(H - 1) * W + W - 1) * C + t];
 #pragma unroll
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(256) void se_gate_pre_kernel(const float* __restric
         const f4* w4 = reinterpret_cast<const f4*>(w2img);
         const int nq = 9 * (C >> 2);
         float z = 0.f;
+#pragma unroll 4
         for (int q = g; q < nq; q += G) {
             const int tap = q / (C >> 2), cq = q - tap * (C >> 2);
             const f4 wv = w4[(size_t)q * C + c];
@@ -796,8 +802,8 @@ extern "C" int eg_se_gate_pre(const float* t1, const float* gap_partial, int32_t
     EG_REQUIRE(t1 && gap_partial && conv2_w && scale2 && shift2 && w1 && b1 && w2 && b2 && gate && batch > 0 && h > 1 && wdt > 1, EG_ERR_BAD_ARG,
                "eg_se_gate_pre: null pointer or empty shape");
     EG_REQUIRE(c % 8 == 0 && c <= 256 && 256 % c == 0 && eg_aligned16(conv2_w), EG_ERR_UNSUPPORTED, "eg_se_gate_pre: C=%d", c);
-    const size_t smem = sizeof(float) * (5 * 256 + 9 * (size_t)c + 256 + c + (c >> 3) + 4);
-    hipLaunchKernelGGL(se_gate_pre_kernel, dim3(batch), dim3(256), smem, (hipStream_t)stream, t1, gap_partial, tiles, conv2_w, scale2, shift2, w1,
+    const size_t smem = sizeof(float) * (5 * GP_T + 9 * (size_t)c + GP_T + c + (c >> 3) + 4);
+    hipLaunchKernelGGL(se_gate_pre_kernel, dim3(batch), dim3(GP_T), smem, (hipStream_t)stream, t1, gap_partial, tiles, conv2_w, scale2, shift2, w1,
                        b1, w2, b2, gate, h, wdt, c);
     return eg_check_launch("se_gate_pre");
 }
