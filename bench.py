@@ -205,21 +205,30 @@ def train_worker(args, rank, world, dev, dist, backend):
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
     B = args.train_batch
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.synth import load_synth_weights
     model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
-    fp = flatten_parameters(model)
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
+    both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
+    fp = flatten_parameters(both)
     opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
     gb = GradBuckets(fp, bucket_mb=25.0).attach()
     inp = synth_inputs(B, 34, 126, 4, seed=2000 + rank)
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     target = torch.from_numpy((hash_unit("train.target_pose", B * 34 * 126, 2000 + rank) - 0.5).astype(np.float32).reshape(B, 34, 126)).to(dev)
     label = g["label"].argmax(1)
+    eps = torch.from_numpy(synth_inputs(B, seed=3000 + rank)["z"]).to(dev)
     ar_ms = []
 
     def step():
         opt.zero_grad()
         gb.begin()
-        pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
-        loss = F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label))
+        pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+        # the emotion CVAE learns to reconstruct the generator's emotion feature map under the clip's label (its eval-time role:
+        # sample(label) replaces that map, test_emotion_gesture_diversity_iterative.py:203-205)
+        rec, mu, logvar = vae(emo.detach(), g["label"], eps)
+        loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
+                     F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
         loss.backward()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -255,10 +264,10 @@ def train_worker(args, rank, world, dev, dist, backend):
     if rank == 0:
         nparam = int(sum(p.numel() for p in fp.params))
         print(json.dumps({
-            "metric": "training clips/sec (generator forward + backward + all-reduce + Adam)", "value": round(B * world * args.steps / el, 2),
+            "metric": "training clips/sec (generator + emotion CVAE: forward + backward + all-reduce + Adam)", "value": round(B * world * args.steps / el, 2),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion) -> backward -> Adam",
+            "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
                        "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": len(gb.buckets)},
             "final_loss": float(loss.detach()), "allreduce_exposed_ms_per_step": round(exposed, 3)}))

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---- elementwise ----------------------------------------------------------------------------------------------------------
 // op 0: y = max(x,0)            op 1: dx = dy * (x > 0)            op 2: y = x > 0 ? x : s*x        op 3: dx = dy * (x > 0 ? 1 : s)
 // op 4: y = a + b               op 5: y = a * s                    op 6: y = sigmoid(x)             op 7: dx = dy * y * (1 - y)  (a = dy, b = y)
-// op 8: y = a * b               op 9: y = a + s*b
+// op 8: y = a * b               op 9: y = a + s*b                  op 10: y = exp(s * a)
 __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n, int op,
                                                  float s) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
             case 6: r = 1.f / (1.f + expf(-u)); break;
             case 7: r = u * v * (1.f - v); break;
             case 8: r = u * v; break;
-            default: r = u + s * v; break;
+            case 9: r = u + s * v; break;
+            default: r = expf(s * u); break;
         }
         y[i] = r;
     }
@@ -604,6 +605,26 @@ __global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits
         }
 }
 
+// KL divergence of N(mu, exp(logvar)) from N(0, I), the standard VAE term: loss = scale * mean_b( -0.5 * sum_j (1 + lv - mu^2 - e^lv) )
+__global__ __launch_bounds__(256) void kld_kernel(const float* __restrict__ mu, const float* __restrict__ lv, float* __restrict__ dmu,
+                                                  float* __restrict__ dlv, float* __restrict__ loss, int n, int d, float scale) {
+    __shared__ float s[256];
+    float acc = 0.f;
+    const float k = scale / (float)n;
+    for (int i = threadIdx.x; i < n * d; i += 256) {
+        const float m = mu[i], l = lv[i], e = expf(l);
+        acc += 1.f + l - m * m - e;
+        if (dmu) { dmu[i] = k * m; dlv[i] = k * 0.5f * (e - 1.f); }
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = -0.5f * k * s[0];
+}
+
 // ---- Adam (torch.optim.Adam: grad += wd * p; m, v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)) ---------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
@@ -776,8 +797,8 @@ extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, i
 }
 
 extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream) {
-    EG_REQUIRE(a && y && n > 0 && op >= 0 && op <= 9, EG_ERR_BAD_ARG, "eg_elementwise: bad argument");
-    EG_REQUIRE(b || op == 0 || op == 2 || op == 5 || op == 6, EG_ERR_BAD_ARG, "eg_elementwise: op %d needs a second operand", op);
+    EG_REQUIRE(a && y && n > 0 && op >= 0 && op <= 10, EG_ERR_BAD_ARG, "eg_elementwise: bad argument");
+    EG_REQUIRE(b || op == 0 || op == 2 || op == 5 || op == 6 || op == 10, EG_ERR_BAD_ARG, "eg_elementwise: op %d needs a second operand", op);
     hipLaunchKernelGGL(ew_kernel, grid1((size_t)n), dim3(256), 0, ST, a, b, y, (size_t)n, op, s);
     return eg_check_launch("elementwise");
 }
@@ -850,6 +871,12 @@ extern "C" int eg_cross_entropy(const float* logits, const int64_t* labels, cons
     if (int rc = eg_check_launch("cross_entropy")) return rc;
     hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, ST, workspace, batch, (double)scale / (double)batch, loss);
     return eg_check_launch("cross_entropy_sum");
+}
+
+extern "C" int eg_kld(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, int32_t n, int32_t d, float scale, void* stream) {
+    EG_REQUIRE(mu && logvar && loss && n > 0 && d > 0 && ((dmu == nullptr) == (dlogvar == nullptr)), EG_ERR_BAD_ARG, "eg_kld: bad argument");
+    hipLaunchKernelGGL(kld_kernel, dim3(1), dim3(256), 0, ST, mu, logvar, dmu, dlogvar, loss, n, d, scale);
+    return eg_check_launch("kld");
 }
 
 extern "C" int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,

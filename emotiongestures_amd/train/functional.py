@@ -111,7 +111,7 @@ def raw_ew(op, a, b=None, s=0.0):
     return y
 
 
-EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY = range(10)
+EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY, EW_EXP = range(11)
 
 
 def raw_linear_backward(x, w, dy, need_dx=True):
@@ -509,6 +509,101 @@ class _Conv1dCL(torch.autograd.Function):
 
 def conv1d_cl(x_blc, w, b=None, stride=1, pad=0, dilation=1):
     return _Conv1dCL.apply(x_blc, w, b, stride, pad, dilation)
+
+
+class _ConvT1dCL(torch.autograd.Function):
+    """nn.ConvTranspose1d(k, stride, padding, output_padding) on channels-last x [B, L, Cin]; weight [Cin, Cout, k] as in the
+    reference's state_dict.  Forward = GEMM then col2im (the transpose of a strided conv), backward = im2col then the Linear rules."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad):
+        lib = _lib()
+        xd, wd = _chk(x), _chk(w)
+        B, Ln, Ci = xd.shape
+        _, Co, k = wd.shape
+        Lout = (Ln - 1) * stride - 2 * pad + k + out_pad
+        dev = xd.device
+        wm = wd.permute(2, 1, 0).reshape(k * Co, Ci).contiguous()            # [(j, co)][ci]
+        x2 = xd.reshape(B * Ln, Ci)
+        col = raw_linear(x2, wm)                                              # [B*L, k*Co]
+        y = torch.empty(B, Lout, Co, device=dev)
+        L.check(lib.eg_im2col1d(_ptr(col), _ptr(y), B, Lout, Co, k, stride, pad, 1, Ln, 1, _stream(dev)), "eg_col2im1d")
+        if b is not None:
+            y = raw_linear_bias_add(y.view(B * Lout, Co), _chk(b)).view(B, Lout, Co)
+        ctx.save_for_backward(x2, wd, wm)
+        ctx.cfg = (B, Ln, Ci, Co, k, stride, pad, Lout, b is not None, x.requires_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x2, w, wm = ctx.saved_tensors
+        B, Ln, Ci, Co, k, stride, pad, Lout, has_b, need_dx = ctx.cfg
+        dyd = _chk(dy)
+        dev = dyd.device
+        dcol = torch.empty(B * Ln, k * Co, device=dev)
+        L.check(lib.eg_im2col1d(_ptr(dyd), _ptr(dcol), B, Lout, Co, k, stride, pad, 1, Ln, 0, _stream(dev)), "eg_im2col1d")
+        dx, dwm, _ = raw_linear_backward(x2, wm, dcol, need_dx)
+        dw = dwm.view(k, Co, Ci).permute(2, 1, 0).contiguous()
+        db = raw_colsum(dyd.view(B * Lout, Co))[0] if has_b else None
+        return (dx.view(B, Ln, Ci) if dx is not None else None), dw, db, None, None, None
+
+
+def raw_linear_bias_add(y2, bias):
+    """y[r, :] + bias (row broadcast) on the row-periodic add kernel."""
+    from .. import ops
+    return ops.add_rows(y2.contiguous(), bias.view(1, -1).contiguous(), period=1)
+
+
+def conv_transpose1d_cl(x_blc, w, b=None, stride=2, pad=1, out_pad=1):
+    return _ConvT1dCL.apply(x_blc, w, b, stride, pad, out_pad)
+
+
+class _Reparam(torch.autograd.Function):
+    """z = eps * exp(0.5 * logvar) + mu (MLP_Reconstruct_v3.reparameterize, CAVE/BEAT_CVAE.py:389-399); eps is an input."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        m, lv, e = _chk(mu), _chk(logvar), _chk(eps)
+        std = raw_ew(EW_EXP, lv, None, 0.5)
+        es = raw_ew(EW_MUL, e, std)
+        ctx.save_for_backward(es)
+        return raw_ew(EW_ADD, es, m)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (es,) = ctx.saved_tensors
+        d = _chk(dz)
+        return d, raw_ew(EW_SCALE, raw_ew(EW_MUL, d, es), None, 0.5), None
+
+
+def reparameterize(mu, logvar, eps):
+    return _Reparam.apply(mu, logvar, eps)
+
+
+class _KLD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, scale):
+        lib = _lib()
+        m, lv = _chk(mu), _chk(logvar)
+        n, d = m.shape
+        loss, dm, dl = torch.empty(1, device=m.device), torch.empty_like(m), torch.empty_like(lv)
+        L.check(lib.eg_kld(_ptr(m), _ptr(lv), _ptr(loss), _ptr(dm), _ptr(dl), n, d, float(scale), _stream(m.device)), "eg_kld")
+        ctx.save_for_backward(dm, dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dm, dl = ctx.saved_tensors
+        s = float(g.reshape(-1)[0])
+        if s != 1.0:
+            dm, dl = raw_ew(EW_SCALE, dm, None, s), raw_ew(EW_SCALE, dl, None, s)
+        return dm, dl, None
+
+
+def kld_loss(mu, logvar, scale=1.0):
+    """scale * mean_b(-0.5 * sum_j(1 + logvar - mu^2 - exp(logvar))): the standard VAE KL term."""
+    return _KLD.apply(mu, logvar, scale)
 
 
 class _SmoothL1(torch.autograd.Function):

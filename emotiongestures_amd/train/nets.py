@@ -185,3 +185,38 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     dec_out = decoder_forward(model.decoder, prior, enc_out)
     pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out)
     return pose, emotion_feature, semantic_feature, emotion_prediction, text_embedding
+
+
+# ---- emotion CVAE (CAVE/BEAT_CVAE.py:312-424) ---------------------------------------------------------------------------------
+def _cl(x_ncl):
+    return x_ncl.transpose(1, 2).contiguous()
+
+
+def cvae_forward(vae, Input, y, eps):
+    """MLP_Reconstruct_v3.forward in train() mode -> (reconstruction [n, frames, d_model], mu [n,32], logvar [n,32]).
+    Conv1d / ConvTranspose1d run channels-last ([n, L, C]); LeakyReLU(0.2) precedes BatchNorm1d as upstream (:318-332,355-369);
+    `eps` replaces torch.randn_like(std) of reparameterize (:398)."""
+    E, D = vae.Encoder, vae.Decoder
+    h = _cl(Input)                                                     # [n, L = d_model, C = frames]
+    for ci, bi, st, pd in ((0, 2, 1, 1), (3, 5, 1, 1), (6, 8, 2, 2), (9, 11, 2, 2)):
+        h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, E[ci].weight, E[ci].bias, st, pd, 1), 0.2), E[bi])
+    n = h.shape[0]
+    latent = h.transpose(1, 2).reshape(n, -1)                          # NCL flatten (:409)
+    la, lb = F.fork(latent)
+    mu = F.linear(F.linear(la, vae.fc_mu[0].weight, vae.fc_mu[0].bias), vae.fc_mu[2].weight, vae.fc_mu[2].bias)
+    logvar = F.linear(F.linear(lb, vae.fc_var[0].weight, vae.fc_var[0].bias), vae.fc_var[2].weight, vae.fc_var[2].bias)
+    mu_z, mu_out = F.fork(mu)
+    lv_z, lv_out = F.fork(logvar)
+    z = F.reparameterize(mu_z, lv_z, eps)
+    py = vae.Posterior_Y_embedding
+    post_y = F.linear(F.linear(y, py[0].weight, py[0].bias), py[2].weight, py[2].bias)
+    zc = torch.cat((z, post_y), 1)
+    fz = vae.fusion_z_posterior
+    zc = F.linear(F.linear(zc, fz[0].weight, fz[0].bias), fz[2].weight, fz[2].bias)
+    h = _cl(zc.reshape(n, 4, -1))                                      # [n, L = d_model/4, C = 4]
+    h = F.batch_norm(F.leaky_relu(F.conv_transpose1d_cl(h, D[0].weight, D[0].bias), 0.2), D[2])
+    h = F.batch_norm(F.leaky_relu(F.conv_transpose1d_cl(h, D[3].weight, D[3].bias), 0.2), D[5])
+    h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, D[6].weight, D[6].bias, 1, 1, 1), 0.2), D[8])
+    h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, D[9].weight, D[9].bias, 1, 1, 1), 0.2), D[11])
+    h = F.conv1d_cl(h, D[12].weight, D[12].bias, 1, 1, 1)
+    return h.transpose(1, 2), mu_out, lv_out

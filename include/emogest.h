@@ -380,7 +380,7 @@ int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, co
                          float* dgamma, float* dbeta, int64_t rows, int32_t c, float* workspace, void* stream);
 /* o0[c] = sum_r a[r,c]; o1[c] = sum_r a[r,c]*b[r,c] (b NULL: sum a^2).  bias / LayerNorm affine gradients. */
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
-/* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b */
+/* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) */
 int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream);
 /* SELayer pieces (ResNetBlocks.py:92-96) on x [B, HW, C]: pooled mean (x scale), per-(clip, channel) dot, gate scaling (+ add[b,c]);
  * workspace (eg_colreduce_workspace_floats(c) floats) selects the two-level reduction, NULL the one-block-per-clip kernel */
@@ -400,6 +400,8 @@ int eg_smooth_l1(const float* pred, const float* target, float* loss, float* dpr
                  void* stream);
 int eg_cross_entropy(const float* logits, const int64_t* labels, const float* alpha, float gamma, float scale, float* loss, float* dlogits,
                      int32_t batch, int32_t classes, float* workspace, void* stream);
+/* VAE KL term of MLP_Reconstruct_v3's (mu, logvar) (CAVE/BEAT_CVAE.py:389-399,403-424): scale * mean_b(-0.5 sum_j(1 + lv - mu^2 - e^lv)) and its gradients */
+int eg_kld(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, int32_t n, int32_t d, float scale, void* stream);
 /* torch.optim.Adam step on a flat buffer (L2 weight decay added to the gradient; train_audio_classifier_K_fold.py:128) */
 int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, void* stream);

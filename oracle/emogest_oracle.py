@@ -305,6 +305,15 @@ def generator_train_loss(sd: SD, cfg: GenCfg, spec, text, prior, target_pose, la
     return loss, pose, pred
 
 
+def cvae_train_loss(sd: SD, x, y, eps, beta: float = 1.0):
+    """A VAE objective on MLP_Reconstruct_v3.forward (CAVE/BEAT_CVAE.py:403-424) in train() mode: smooth_l1(reconstruction, x) +
+    beta * mean_b(-0.5 * sum_j(1 + logvar - mu^2 - exp(logvar))).  (The reference ships the module, not its training loss.)"""
+    with bn_training():
+        rec, mu, logvar = cvae_forward(sd, x, y, eps)
+    kld = torch.mean(-0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp(), dim=1), dim=0)
+    return F.smooth_l1_loss(rec, x) + beta * kld, rec, mu, logvar
+
+
 def emotion_net_train_loss(sd: SD, mfcc, label, alpha, gamma: float = 2.0):
     """train_audio_classifier_K_fold.py:163-168 with FocalLoss :89-105: 100 * mean(alpha * (1 - pt)^gamma * CE), alpha a
     per-sample weight vector (that is how `self.alpha * ...` broadcasts), EmotionNet in train() mode."""

@@ -124,12 +124,45 @@ def emo_case(out, seed=31, batch=2):
     print("emo loss", loss.item())
 
 
+def cvae_case(out, seed=7, n=3):
+    """MLP_Reconstruct_v3 (CAVE/BEAT_CVAE.py:312-424) in train() mode, dropout p = 0, reparameterize's randn_like replaced by a
+    fixed eps; loss = smooth_l1(recon, x) + KLD(mu, logvar) (the reference has the module but no training loss: a standard VAE
+    objective exercises every parameter of Encoder / fc_mu / fc_var / Decoder)."""
+    stub()
+    from CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    m = MLP_Reconstruct_v3()
+    load_synth_weights(m, seed)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    inp = synth_inputs(n, frames=60, seed=seed)
+    x, y = torch.from_numpy(inp["sampled"]), torch.from_numpy(inp["label"])
+    eps = torch.from_numpy(synth_inputs(n, seed=seed + 1)["z"])
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: eps.clone()
+    try:
+        rec, mu, logvar = m(x, y)
+    finally:
+        torch.randn_like = real
+    kld = torch.mean(-0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp(), dim=1), dim=0)
+    loss = F.smooth_l1_loss(rec, x) + kld
+    loss.backward()
+    out["cvae/loss"] = np.float64(loss.item())
+    out["cvae/mu"] = mu.detach().numpy()
+    out["cvae/logvar"] = logvar.detach().numpy()
+    out["cvae/meta"] = np.asarray([n, seed], np.int64)
+    fingerprint(out, "cvae", m)
+    print("cvae loss", loss.item(), "params without grad", len(out["cvae/nograd"]))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     out = {}
     gen_case(out)
     emo_case(out)
+    cvae_case(out)
     path = os.path.join(ROOT, "tests", "golden", "grads.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

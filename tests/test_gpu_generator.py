@@ -203,7 +203,7 @@ def test_errors_are_loud():
     # train-mode path still refuse instead of falling back
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev()).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):           # sample() is an eval-time call (forward() has the train-mode path)
         vae.sample(t["label"].to(dev()), z=t["z"])
     model.train()
     pose = model(t["spec"].to(dev()), t["text"].to(dev()), t["pre_pose"].to(dev()))[0]

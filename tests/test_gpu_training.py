@@ -348,6 +348,53 @@ def test_emotion_net_train_step_and_adam():
     assert all(p.data_ptr() == fp.flat.data_ptr() + 4 * o for p, o in zip(fp.params, fp.offsets))
 
 
+def test_conv_transpose1d_reparam_kld_ops():
+    from emotiongestures_amd.train import functional as F
+    for (Ci, Co, L) in [(4, 8, 128), (8, 16, 256)]:
+        x, w, b = T("x", (3, L, Ci)), T("w", (Ci, Co, 3), -0.4, 0.4), T("b", (Co,))
+        _grad_check(lambda x, w, b: F.conv_transpose1d_cl(x, w, b, 2, 1, 1),
+                    lambda x, w, b: TF.conv_transpose1d(x.transpose(1, 2), w, b, stride=2, padding=1, output_padding=1).transpose(1, 2), [x, w, b])
+    mu, lv, eps = T("mu", (5, 32)), T("lv", (5, 32), -2, 1), T("eps", (5, 32), -2, 2)
+    _grad_check(lambda mu, lv: F.reparameterize(mu, lv, eps.to(DEV)), lambda mu, lv: eps * torch.exp(0.5 * lv) + mu, [mu, lv])
+    _grad_check(lambda mu, lv: F.kld_loss(mu, lv, 2.0),
+                lambda mu, lv: (2.0 * torch.mean(-0.5 * torch.sum(1 + lv - mu ** 2 - lv.exp(), dim=1), dim=0)).reshape(1), [mu, lv])
+
+
+def test_cvae_train_step_gradients_match_oracle():
+    """MLP_Reconstruct_v3.forward in train() mode (CAVE/BEAT_CVAE.py:403-424: Conv1d / ConvTranspose1d / LeakyReLU / BatchNorm1d on batch
+    statistics / reparameterize) + smooth_l1 + KLD: loss and (mu, logvar) against the reference, all 48 parameter gradients against the
+    oracle's autograd (LeakyReLU has no dead zone: no mask-flip caveat here)."""
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.train import functional as F
+    from oracle import emogest_oracle as O
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    n, seed = [int(v) for v in z["cvae/meta"]]
+    vae = load_synth_weights(MLP_Reconstruct_v3(), seed)
+    sd = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    inp = synth_inputs(n, frames=60, seed=seed)
+    x, y = torch.from_numpy(inp["sampled"]), torch.from_numpy(inp["label"])
+    eps = torch.from_numpy(synth_inputs(n, seed=seed + 1)["z"])
+    loss_ref, _, _, _ = O.cvae_train_loss(sd, x, y, eps, 1.0)
+    loss_ref.backward()
+    vae.to(DEV).train()
+    rec, mu, logvar = vae(x.to(DEV), y.to(DEV), eps.to(DEV))
+    ra, rb = F.fork(rec)
+    loss = F.add(F.smooth_l1_loss(ra, x.to(DEV), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0))
+    loss.backward()
+    assert tuple(rec.shape) == (n, 60, 512)
+    assert abs(float(loss.detach()) - float(z["cvae/loss"])) / float(z["cvae/loss"]) < 1e-5
+    assert np.abs(mu.detach().cpu().numpy() - z["cvae/mu"]).max() < 1e-4 and np.abs(logvar.detach().cpu().numpy() - z["cvae/logvar"]).max() < 1e-4
+    worst = 0.0
+    for k, p in vae.named_parameters():
+        e = rel(p.grad, sd[k].grad)
+        worst = max(worst, e)
+        assert e < 1e-4, f"{k}: {e:.2e}"
+    print(f"CVAE: {len(list(vae.parameters()))} parameter gradients, worst rel-L2 vs oracle {worst:.2e}")
+
+
 def test_train_mode_is_refused_elsewhere_and_cpu_is_refused():
     from emotiongestures_amd import _lib as L
     from emotiongestures_amd.train import functional as F
