@@ -872,6 +872,12 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
         if (precision == EG_PREC_BF16X3) return launch_presplit128<3>(a, xhi, xlo, xko, mt, eg_cdiv(n, 64), (hipStream_t)stream);
         return launch_presplit128<1>(a, xhi, xlo, xko, mt, eg_cdiv(n, 64), (hipStream_t)stream);
     }
-    if (precision == EG_PREC_BF16X3) return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+    if (precision == EG_PREC_BF16X3) {
+        if (const char* r = getenv("EG_GEMM_RING")) {           // experiment hook (tools/bench_ops.py): ring depth of the 64x64 kernel
+            if (r[0] == '8') return launch_presplit<3, 32, 8>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+            if (r[0] == '6') return launch_presplit<3, 32, 6>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+        }
+        return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+    }
     return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
 }

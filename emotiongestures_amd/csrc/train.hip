@@ -407,6 +407,22 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
     }
 }
 
+// ---- dropout: counter-based mask, nothing stored -- keep(i) = hash(seed, offset + i) >= p; y = keep ? x / (1 - p) : 0.  The backward pass
+// is the same kernel on dy with the same (seed, offset).  (nn.Dropout's semantics; the mask stream is this library's own, not torch's.)
+__device__ __forceinline__ unsigned int mix32(unsigned int h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p, float inv_keep,
+                                                      unsigned int seed, unsigned long long offset) {
+    const unsigned int thr = (unsigned int)(p * 4294967296.0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long ctr = offset + i;
+        const unsigned int h = mix32(mix32((unsigned int)ctr ^ seed) + (unsigned int)(ctr >> 32) * 0x9E3779B9u + 0x6A09E667u);
+        y[i] = (h >= thr) ? x[i] * inv_keep : 0.f;
+    }
+}
+
 // ---- SE pieces: x [B, HW, C] --------------------------------------------------------------------------------------------
 // segment mean over HW (two-level through col_partial per clip would need B launches; one block per (clip, 64 channels) instead)
 __global__ __launch_bounds__(256) void seg_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C, float scale) {
@@ -804,6 +820,12 @@ extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t 
 }
 
 // per-clip pooled sums through the two-level column reduction (clips = segments): workspace >= eg_colreduce_workspace_floats(c)
+extern "C" int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream) {
+    EG_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, EG_ERR_BAD_ARG, "eg_dropout: bad argument (p=%f)", (double)p);
+    hipLaunchKernelGGL(dropout_kernel, grid1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n, p, 1.0f / (1.0f - p), seed, (unsigned long long)offset);
+    return eg_check_launch("dropout");
+}
+
 extern "C" int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, float* workspace, void* stream) {
     EG_REQUIRE(x && out && batch > 0 && hw > 0 && c > 0, EG_ERR_BAD_ARG, "eg_seg_mean: bad argument");
     if (!workspace || batch > 512) {

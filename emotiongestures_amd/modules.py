@@ -566,6 +566,7 @@ class Transformer(nn.Module):
         self.keep_taps = False
         self.concurrent = False          # fork the text / prior branches onto side streams (engine option)
         self.fold_affine = False         # fold the Dropout-only Linear chains at pack time (fewer launches / FLOPs; off for parity runs)
+        self.train_dropout = False       # train(): activate the reference's Dropout layers (default: p = 0, the gradient-parity configuration)
         self.fuse_se = True              # identity SE blocks: gate from conv1's output moments, tail in conv2's epilogue (same arithmetic order per element)
         self._engine: Optional[GeneratorEngine] = None
         self._engine_key = None

@@ -204,6 +204,43 @@ def leaky_relu(x, slope=0.2):
     return _Act.apply(x, float(slope))
 
 
+_DROP = {"seed": 0, "offset": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the dropout mask stream (counter-based; every dropout call advances the counter by its element count)."""
+    _DROP["seed"], _DROP["offset"] = int(seed) & 0xFFFFFFFF, 0
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        lib = _lib()
+        xd = _chk(x)
+        y = torch.empty_like(xd)
+        L.check(lib.eg_dropout(_ptr(xd), _ptr(y), xd.numel(), float(p), seed, offset, _stream(xd.device)), "eg_dropout")
+        ctx.cfg = (float(p), seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        p, seed, offset = ctx.cfg
+        d = _chk(dy)
+        dx = torch.empty_like(d)
+        L.check(lib.eg_dropout(_ptr(d), _ptr(dx), d.numel(), p, seed, offset, _stream(d.device)), "eg_dropout")
+        return dx, None, None, None
+
+
+def dropout(x, p: float):
+    """nn.Dropout(p) in train() mode (p = 0: identity, no launch)."""
+    if p <= 0.0:
+        return x
+    off = _DROP["offset"]
+    _DROP["offset"] = off + (x.numel() + 1023) // 1024 * 1024
+    return _Dropout.apply(x, p, _DROP["seed"], off)
+
+
 def _pack_conv_f32(w, coutp):
     """OIHW -> the conv kernel's fp32 image [tap][ci/4][co_pad][4] (data movement only)."""
     co, ci = w.shape[:2]

@@ -3,8 +3,9 @@
 * `emotion_net_forward`  -- EmotionNet (model/audio_emotion_classifer.py:17-49), the one network the reference ships a training
   loop for (train_audio_classifier_K_fold.py:109-200).
 * `generator_forward`    -- Transformer.forward of Full_model/Models_spatial_memory.py:566-616 in train() mode: BatchNorm on
-  batch statistics (running buffers updated), every other layer as in eval.  Dropout layers act with p = 0 (the
-  gradient-parity configuration); stochastic dropout masks are not implemented.
+  batch statistics (running buffers updated), every other layer as in eval.  Dropout layers act with p = 0 by default (SURVEY.md §8c:
+  the gradient-parity configuration); `model.train_dropout = True` activates the reference's Dropout placements on a counter-based
+  mask stream (see `_dp` below).
 
 The modules are the parameter trees of `emotiongestures_amd.modules` (same names / shapes as the reference's state_dict);
 activations are NHWC in the audio tower and row-major [rows, features] elsewhere.
@@ -15,6 +16,17 @@ import torch
 
 from .. import ops
 from . import functional as F
+
+
+# Dropout: the gradient-parity configuration (tests, goldens) runs with every Dropout at p = 0.  With
+# `model.train_dropout = True` the reference's placements are active with its probabilities, on the library's own mask stream
+# (functional.manual_seed); ScaledDotProductAttention's dropout on the probabilities (Modules.py:21, p = 0.1) is NOT applied: the
+# fused attention kernel never materialises them for a second pass.
+_P = {"on": False}
+
+
+def _dp(x, p):
+    return F.dropout(x, p) if _P["on"] else x
 
 
 def _fork_n(x, n):
@@ -81,13 +93,13 @@ def mha_forward(m, xq, xk, xv):
     k = F.linear(xk, m.w_ks.weight)
     v = F.linear(xv, m.w_vs.weight)
     o = F.attention(q, k, v, m.n_head)
-    return F.layer_norm(F.add(F.linear(o, m.fc.weight), xq_r), m.layer_norm)
+    return F.layer_norm(F.add(_dp(F.linear(o, m.fc.weight), 0.2), xq_r), m.layer_norm)      # q = self.dropout(self.fc(q)) (SubLayers.py:54)
 
 
 def ffn_forward(f, x):
     xa, xr = F.fork(x)
     h = F.linear(xa, f.w_1.weight, f.w_1.bias, relu=True)
-    return F.layer_norm(F.add(F.linear(h, f.w_2.weight, f.w_2.bias), xr), f.layer_norm)
+    return F.layer_norm(F.add(_dp(F.linear(h, f.w_2.weight, f.w_2.bias), 0.2), xr), f.layer_norm)         # SubLayers.py:79
 
 
 class _AddRows(torch.autograd.Function):
@@ -103,7 +115,7 @@ class _AddRows(torch.autograd.Function):
 
 
 def encoder_forward(enc, x):
-    x = _AddRows.apply(x, enc.position_enc.pos_table[0, :x.shape[1]].contiguous())
+    x = _dp(_AddRows.apply(x, enc.position_enc.pos_table[0, :x.shape[1]].contiguous()), 0.2)        # Models_spatial_memory.py:422
     for layer in enc.layer_stack:
         a, b, c = _fork_n(x, 3)
         x = ffn_forward(layer.pos_ffn, mha_forward(layer.slf_attn, a, b, c))
@@ -118,9 +130,12 @@ def decoder_forward(dec, trg, enc_out):
     return x
 
 
-def _seq_linear(seq, idx, x, relu_between=False):
+def _seq_linear(seq, idx, x, relu_between=False, drop=0.0):
+    """Linear chain; `drop`: the nn.Dropout between consecutive Linears of the reference's Sequential (no ReLU there)."""
     for j, i in enumerate(idx):
         x = F.linear(x, seq[i].weight, seq[i].bias, relu=relu_between and j + 1 < len(idx))
+        if drop and j + 1 < len(idx):
+            x = _dp(x, drop)
     return x
 
 
@@ -132,7 +147,7 @@ def prior_encoder_forward(pe, prior):
     h = F.batch_norm(F.relu(F.conv1d_cl(x, c0.weight, c0.bias, 1, 1, 1)), b0)
     h = F.batch_norm(F.relu(F.conv1d_cl(h, c1.weight, c1.bias, 1, 1, 1)), b1)
     out = torch.cat((prior, h.transpose(1, 2)), 1)                               # [B, frames, pose_dim]
-    return _seq_linear(pe.post_header, (0, 2), out.contiguous())
+    return _seq_linear(pe.post_header, (0, 2), out.contiguous(), drop=0.2)
 
 
 def audio_encoder_forward(ae, spec):
@@ -141,7 +156,7 @@ def audio_encoder_forward(ae, spec):
     x = F.batch_norm(F.conv3x3(x, ae.final_conv1.weight, ae.final_conv1.bias), ae.bn1)          # [B,H,W,F]
     B, H, W, Fr = x.shape
     x = x.permute(0, 3, 1, 2).reshape(B, Fr, H * W)                              # channel c becomes time step c (:124)
-    return F.linear(F.linear(x, ae.fc1.weight, ae.fc1.bias), ae.fc2.weight, ae.fc2.bias)
+    return F.linear(_dp(F.linear(x, ae.fc1.weight, ae.fc1.bias), 0.2), ae.fc2.weight, ae.fc2.bias)          # :128-130
 
 
 def text_encoder_forward_nograd(te, text):
@@ -168,12 +183,13 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     (:577,616), so it is evaluated without gradient on the inference kernels."""
     if model._variant != "spatial":
         raise NotImplementedError("train-mode forward: Models_spatial_memory variant only (TM_Memory_Net couples the batch)")
+    _P["on"] = bool(getattr(model, "train_dropout", False))
     text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
     spectrum_feature = audio_encoder_forward(model.audio_encoder, input_spectrum)
     prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
     sa, sb = F.fork(spectrum_feature)
-    emotion_feature = _seq_linear(model.emotion_proj, (0, 2), sa)
-    semantic_feature = _seq_linear(model.semantic_proj, (0, 2), sb)
+    emotion_feature = _seq_linear(model.emotion_proj, (0, 2), sa, drop=0.2)
+    semantic_feature = _seq_linear(model.semantic_proj, (0, 2), sb, drop=0.2)
     B = emotion_feature.shape[0]
     if sampled_emotion_feature is None:
         e_cls, e_fus = F.fork(emotion_feature)
@@ -183,7 +199,8 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     fusion = _seq_linear(model.fusion_proj, (0, 2), F.add(e_fus, semantic_feature), relu_between=True)
     enc_out = encoder_forward(model.encoder, fusion)
     dec_out = decoder_forward(model.decoder, prior, enc_out)
-    pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out)
+    pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
+    _P["on"] = False
     return pose, emotion_feature, semantic_feature, emotion_prediction, text_embedding
 
 

@@ -382,6 +382,9 @@ int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, co
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
 /* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) */
 int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream);
+/* nn.Dropout in train() mode with a counter-based mask (nothing stored): keep(i) = hash(seed, offset + i) >= p, y = keep ? x/(1-p) : 0;
+ * the backward pass is the same call on dy.  The mask stream is this library's own (not torch's RNG). */
+int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);
 /* SELayer pieces (ResNetBlocks.py:92-96) on x [B, HW, C]: pooled mean (x scale), per-(clip, channel) dot, gate scaling (+ add[b,c]);
  * workspace (eg_colreduce_workspace_floats(c) floats) selects the two-level reduction, NULL the one-block-per-clip kernel */
 int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, float* workspace, void* stream);

@@ -404,3 +404,34 @@ def test_train_mode_is_refused_elsewhere_and_cpu_is_refused():
     inp = synth_inputs(4, 34, 126, 4, seed=0)
     with pytest.raises(NotImplementedError):
         m(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV), torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+
+
+def test_dropout_mask_stream_and_generator_step_with_dropout():
+    """nn.Dropout in train() mode on the counter-based mask stream: keep fraction ~ 1 - p, kept values scaled by 1/(1-p), the backward
+    pass applies the same mask, the stream is reproducible under manual_seed and advances between calls; a generator step with the
+    reference's Dropout placements active runs to finite, non-degenerate gradients."""
+    from emotiongestures_amd.train import functional as F
+    x = torch.ones(1 << 20, device=DEV, requires_grad=True)
+    F.manual_seed(123)
+    y1 = F.dropout(x, 0.2)
+    y2 = F.dropout(x, 0.2)
+    keep = float((y1 != 0).float().mean())
+    assert abs(keep - 0.8) < 2e-3 and abs(float(y1.max()) - 1.25) < 1e-6
+    assert not torch.equal(y1, y2)                                     # the counter advanced
+    y1.sum().backward()
+    assert torch.equal(x.grad, y1.detach())                            # dy = 1 -> dx is exactly the scaled mask
+    F.manual_seed(123)
+    assert torch.equal(F.dropout(x, 0.2).detach(), y1.detach())        # reproducible
+    assert F.dropout(x, 0.0) is x
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+    model.train_dropout = True
+    inp = synth_inputs(2, 34, 126, 4, seed=0)
+    F.manual_seed(7)
+    pose, _e, _s, pred, _t = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV), torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+    model.train_dropout = False
+    pose0 = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV), torch.from_numpy(inp["pre_pose"]).to(DEV), None)[0]
+    assert not torch.allclose(pose, pose0)                             # dropout really acted
+    loss = F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, torch.tensor([1, 2], device=DEV)))
+    loss.backward()
+    g = model.post_projector[0].weight.grad
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
