@@ -149,6 +149,8 @@ def parse_args():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]: one step = generator forward + 100*smooth_l1 + CE + backward + bucketed gradient "
                          "all-reduce (RCCL) + fused Adam on --train-batch clips per GPU (fp32 operators)")
+    ap.add_argument("--train-precision", choices=("f32", "bf16x3"), default="f32",
+                    help="--train: arithmetic of the 3x3 convolutions (forward + input gradient); f32 is the gradient-parity configuration")
     ap.add_argument("--train-batch", type=int, default=16, help="clips per GPU per training step (16 = global 128 on 8 GPUs, SURVEY.md §8d cfg 3)")
     return ap.parse_args()
 
@@ -205,6 +207,7 @@ def train_worker(args, rank, world, dev, dist, backend):
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
     B = args.train_batch
+    F.set_precision(args.train_precision)
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.synth import load_synth_weights
     model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
@@ -266,7 +269,7 @@ def train_worker(args, rank, world, dev, dist, backend):
         print(json.dumps({
             "metric": "training clips/sec (generator + emotion CVAE: forward + backward + all-reduce + Adam)", "value": round(B * world * args.steps / el, 2),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_precision, "data": "synthetic",
             "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
                        "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": len(gb.buckets)},

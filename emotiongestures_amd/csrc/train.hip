@@ -407,6 +407,37 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
     }
 }
 
+// ---- conv3x3 weight image, built on the device (training: the weights change every step) ----------------------------------------
+// OIHW fp32 -> the image eg_conv3x3 reads (conv.hip: launch_conv): fp32 [tap][ci/4][coutp][4], then bf16 hi and lo images
+// [tap][ci/8][coutp][8].  flip != 0 packs the filter of the input-gradient convolution instead: w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
+// (the result then convolves `cout` input channels into `cin` output channels).  One thread per (tap, channel octet, output channel).
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int cout, int cin, int flip, float* __restrict__ image) {
+    const int CI = flip ? cout : cin, CO = flip ? cin : cout, coutp = (CO + 15) / 16 * 16;
+    const int total = 9 * (CI / 8) * coutp;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int co = idx % coutp, oc = (idx / coutp) % (CI / 8), tap = idx / (coutp * (CI / 8));
+    const int st = flip ? 8 - tap : tap;
+    f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (co < CO) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = oc * 8 + j;
+            const float x = flip ? w[((size_t)ci * cin + co) * 9 + st] : w[((size_t)co * cin + ci) * 9 + st];
+            if (j < 4) v0[j] = x; else v1[j - 4] = x;
+        }
+    }
+    f4* f32img = reinterpret_cast<f4*>(image);
+    f32img[((size_t)tap * (CI / 4) + oc * 2) * coutp + co] = v0;
+    f32img[((size_t)tap * (CI / 4) + oc * 2 + 1) * coutp + co] = v1;
+    bf8 hi, lo;
+    split_octet<true>(v0, v1, hi, lo);
+    bf8* himg = reinterpret_cast<bf8*>(image + (size_t)9 * CI * coutp);
+    bf8* limg = himg + (size_t)9 * (CI / 8) * coutp;
+    himg[idx] = hi;
+    limg[idx] = lo;
+}
+
 // ---- dropout: counter-based mask, nothing stored -- keep(i) = hash(seed, offset + i) >= p; y = keep ? x / (1 - p) : 0.  The backward pass
 // is the same kernel on dy with the same (seed, offset).  (nn.Dropout's semantics; the mask stream is this library's own, not torch's.)
 __device__ __forceinline__ unsigned int mix32(unsigned int h) {
@@ -820,6 +851,15 @@ extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t 
 }
 
 // per-clip pooled sums through the two-level column reduction (clips = segments): workspace >= eg_colreduce_workspace_floats(c)
+extern "C" int eg_pack_conv3x3_device(const float* w_oihw, int32_t cout, int32_t cin, int32_t flip_transpose, float* image, void* stream) {
+    EG_REQUIRE(w_oihw && image && cout > 0 && cin > 0, EG_ERR_BAD_ARG, "eg_pack_conv3x3_device: null pointer or empty shape");
+    const int ci = flip_transpose ? cout : cin, co = flip_transpose ? cin : cout;
+    EG_REQUIRE(ci % 8 == 0 && eg_aligned16(image), EG_ERR_UNSUPPORTED, "eg_pack_conv3x3_device: input channels %d (need a multiple of 8), 16-byte aligned image", ci);
+    const int total = 9 * (ci / 8) * (int)eg_round_up(co, 16);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, w_oihw, cout, cin, flip_transpose, image);
+    return eg_check_launch("pack_conv3x3");
+}
+
 extern "C" int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream) {
     EG_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, EG_ERR_BAD_ARG, "eg_dropout: bad argument (p=%f)", (double)p);
     hipLaunchKernelGGL(dropout_kernel, grid1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n, p, 1.0f / (1.0f - p), seed, (unsigned long long)offset);

@@ -241,12 +241,29 @@ def dropout(x, p: float):
     return _Dropout.apply(x, p, _DROP["seed"], off)
 
 
-def _pack_conv_f32(w, coutp):
-    """OIHW -> the conv kernel's fp32 image [tap][ci/4][co_pad][4] (data movement only)."""
+_PREC = {"conv": F32}
+
+
+def set_precision(name: str) -> None:
+    """Arithmetic of the 3x3 convolutions of the training path (forward and input gradient): "f32" (fp32 MFMA; the
+    gradient-parity configuration) or "bf16x3" (3-term split-bf16 MFMA with fp32 accumulation, the inference kernels)."""
+    if name not in ("f32", "bf16x3"):
+        raise ValueError(f"train precision {name!r}: expected 'f32' or 'bf16x3'")
+    _PREC["conv"] = F32 if name == "f32" else L.EG_PREC_BF16X3
+
+
+def get_precision() -> str:
+    return "f32" if _PREC["conv"] == F32 else "bf16x3"
+
+
+def _pack_conv(w, flip=False):
+    """OIHW -> the image eg_conv3x3 reads (fp32 + bf16 hi/lo), built on the device in one launch; flip: the dgrad filter."""
+    lib = _lib()
     co, ci = w.shape[:2]
-    t = torch.zeros(9, ci, coutp, dtype=torch.float32, device=w.device)
-    t[:, :, :co].copy_(w.permute(2, 3, 1, 0).reshape(9, ci, co))
-    return t.view(9, ci // 4, 4, coutp).permute(0, 1, 3, 2).contiguous()
+    cie, coe = (co, ci) if flip else (ci, co)
+    img = torch.empty(int(lib.eg_conv3x3_packed_floats(cie, (coe + 15) // 16 * 16)), dtype=torch.float32, device=w.device)
+    L.check(lib.eg_pack_conv3x3_device(_ptr(w), co, ci, int(flip), _ptr(img), _stream(w.device)), "eg_pack_conv3x3_device")
+    return img
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -262,18 +279,19 @@ class _Conv3x3(torch.autograd.Function):
         dev = xd.device
         if Ci % 32 == 0:
             coutp = (Co + 15) // 16 * 16
-            wp = _pack_conv_f32(wd, coutp)
+            wp = _pack_conv(wd)
+            prec = _PREC["conv"]
             bp = None
             if b is not None:
                 bp = torch.zeros(coutp, dtype=torch.float32, device=dev)
                 bp[:Co].copy_(_chk(b))
             if Co % 4 == 0:
                 y = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev)
-                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), None, B, H, W, Ci, Co, stride, int(relu), 0, F32,
+                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), None, B, H, W, Ci, Co, stride, int(relu), 0, prec,
                                        _stream(dev)), "eg_conv3x3")
             else:           # ragged channel count (final_conv1: 128 -> frames): channel-major epilogue, then back to NHWC
                 yc = torch.empty(B, Co, Ho * Wo, dtype=torch.float32, device=dev)
-                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(yc), None, B, H, W, Ci, Co, stride, int(relu), 1, F32,
+                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(yc), None, B, H, W, Ci, Co, stride, int(relu), 1, prec,
                                        _stream(dev)), "eg_conv3x3")
                 y = yc.view(B, Co, Ho, Wo).permute(0, 2, 3, 1).contiguous()
         else:               # the stem (1 input channel): im2col rows through the GEMM
@@ -313,10 +331,10 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.need_dx and ctx.stride == 1 and Ci == Co and Ci % 32 == 0:
             # input gradient of a square stride-1 conv = the forward kernel on the 180-degree rotated, transposed filter
             # (F.conv2d's dgrad); no 9x im2col intermediate
-            w_rot = w.flip(2, 3).transpose(0, 1).contiguous()                   # [ci][co][2-kh][2-kw] as OIHW of the transposed conv
-            wp = _pack_conv_f32(w_rot, (Ci + 15) // 16 * 16)
+            wp = _pack_conv(w, flip=True)                                       # w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
             dx = torch.empty_like(x)
-            L.check(lib.eg_conv3x3(_ptr(dyd), _ptr(wp), None, None, None, _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, F32, _stream(dev)), "eg_conv3x3 (dgrad)")
+            L.check(lib.eg_conv3x3(_ptr(dyd), _ptr(wp), None, None, None, _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"], _stream(dev)),
+                    "eg_conv3x3 (dgrad)")
         elif ctx.need_dx:
             wmat_t = w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()   # [(kh,kw,ci), co] = Wmat^T
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]

@@ -382,6 +382,11 @@ int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, co
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
 /* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) */
 int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream);
+/* Device-side build of the weight image eg_conv3x3 reads (eg_conv3x3_packed_floats(cin', round_up(cout',16)) floats: fp32 image, then the
+ * bf16 hi / lo images), for weights that change every step.  flip_transpose = 0: conv weight [cout][cin][3][3] as in the state_dict
+ * (cin' = cin, cout' = cout).  flip_transpose = 1: the filter of the input-gradient convolution, w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
+ * (cin' = cout, cout' = cin) -- F.conv2d's dgrad for stride 1 is eg_conv3x3 of dy with that image. */
+int eg_pack_conv3x3_device(const float* w_oihw, int32_t cout, int32_t cin, int32_t flip_transpose, float* image, void* stream);
 /* nn.Dropout in train() mode with a counter-based mask (nothing stored): keep(i) = hash(seed, offset + i) >= p, y = keep ? x/(1-p) : 0;
  * the backward pass is the same call on dy.  The mask stream is this library's own (not torch's RNG). */
 int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);

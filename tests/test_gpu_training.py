@@ -435,3 +435,50 @@ def test_dropout_mask_stream_and_generator_step_with_dropout():
     loss.backward()
     g = model.post_projector[0].weight.grad
     assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+def test_device_conv_weight_image_matches_host_packer_bitwise():
+    """eg_pack_conv3x3_device builds the same image (fp32 + bf16 hi / lo) as the load-time host packer, and with flip_transpose the image
+    of the rotated, transposed filter."""
+    from emotiongestures_amd.packing import _pack_conv3x3
+    from emotiongestures_amd.train import functional as F
+    g = torch.Generator().manual_seed(3)
+    for co, ci in ((32, 32), (64, 32), (34, 128), (128, 128)):
+        w = torch.randn(co, ci, 3, 3, generator=g) * 0.1
+        host = torch.from_numpy(_pack_conv3x3(w, (co + 15) // 16 * 16).view(np.float32).reshape(-1))
+        dev = F._pack_conv(w.to(DEV)).cpu()
+        assert torch.equal(host.view(torch.int32), dev.view(torch.int32)), (co, ci)
+        if co % 8 == 0:
+            w_rot = w.flip(2, 3).transpose(0, 1).contiguous()
+            host_r = torch.from_numpy(_pack_conv3x3(w_rot, (ci + 15) // 16 * 16).view(np.float32).reshape(-1))
+            assert torch.equal(host_r.view(torch.int32), F._pack_conv(w.to(DEV), flip=True).cpu().view(torch.int32)), (co, ci, "flip")
+
+
+def test_bf16x3_training_convolutions_track_the_f32_step():
+    """F.set_precision('bf16x3'): the tower's forward and input-gradient convolutions run on the split-bf16 MFMA kernels.  The loss and the
+    gradients behind the last ReLU stay within 1e-4 of the f32 step; further upstream the usual mask flips bound the agreement."""
+    from emotiongestures_amd.train import functional as F
+    inp = synth_inputs(4, 34, 126, 4, seed=5)
+    out = {}
+    try:
+        for prec in ("f32", "bf16x3"):
+            F.set_precision(prec)
+            model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+            pose, _e, _s, pred, _t = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
+                                           torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+            loss = F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, torch.tensor([0, 1, 2, 3], device=DEV)))
+            loss.backward()
+            out[prec] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        F.set_precision("f32")
+    assert abs(out["f32"][0] - out["bf16x3"][0]) <= 1e-4 * abs(out["f32"][0])
+    # downstream of every ReLU whose mask can flip: the forward difference (3e-5) is the only source
+    for k in ("post_projector.0.weight", "decoder.layer_stack.2.pos_ffn.w_1.weight", "decoder.layer_stack.2.enc_attn.w_qs.weight"):
+        a, b = out["f32"][1][k], out["bf16x3"][1][k]
+        assert float((a - b).norm() / a.norm()) < 1e-4, k
+    # upstream of the FFN ReLUs a 3e-5 forward difference flips a few mask elements (measured 1e-4 .. 1.7e-3, tools/debug_train_prec.py)
+    for k in ("encoder.layer_stack.0.slf_attn.w_qs.weight", "audio_encoder.fc1.weight", "prior_seq_encoder.post_header.0.weight"):
+        a, b = out["f32"][1][k], out["bf16x3"][1][k]
+        assert float((a - b).norm() / a.norm()) < 1e-2, k
+    tower = [float((out["f32"][1][k] - out["bf16x3"][1][k]).norm() / (out["f32"][1][k].norm() + 1e-30)) for k in out["f32"][1] if "feat_extractor" in k and k.endswith("conv1.weight")]
+    assert float(np.median(tower)) < 2e-2
