@@ -315,7 +315,12 @@ class _Conv3x3(torch.autograd.Function):
         Ho, Wo = dyd.shape[1], dyd.shape[2]
         dev = x.device
         dy2 = dyd.view(B * Ho * Wo, Co)
-        if Ci % 4 == 0:             # implicit GEMM over the output pixels (no im2col buffer)
+        if _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 32 == 0:       # split-bf16 MFMA weight gradient
+            dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
+            need = lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Co)
+            ws = _scratch(dev, need, "wgrad")
+            L.check(lib.eg_conv3x3_wgrad_mfma(_ptr(x), _ptr(dy2), _ptr(dwm), B, H, W, Ci, Co, _ptr(ws), ws.numel(), _stream(dev)), "eg_conv3x3_wgrad_mfma")
+        elif Ci % 4 == 0:           # implicit GEMM over the output pixels (no im2col buffer)
             dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
             need = lib.eg_gemm_tn_workspace_floats(Co, 9 * Ci, B * Ho * Wo)
             ws = _scratch(dev, need, "tn") if need else None

@@ -382,6 +382,11 @@ int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, co
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
 /* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) */
 int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream);
+/* The same weight gradient for stride 1 on the split-bf16 matrix pipe (x and dy split to hi/lo bf16 while staged, 3 MFMA terms, fp32
+ * accumulation, fixed-order partial sums): cin % 32 == 0, cout % 32 == 0.  workspace >= eg_conv3x3_wgrad_mfma_workspace_floats(...). */
+int64_t eg_conv3x3_wgrad_mfma_workspace_floats(int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout);
+int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                          float* workspace, int64_t workspace_floats, void* stream);
 /* Device-side build of the weight image eg_conv3x3 reads (eg_conv3x3_packed_floats(cin', round_up(cout',16)) floats: fp32 image, then the
  * bf16 hi / lo images), for weights that change every step.  flip_transpose = 0: conv weight [cout][cin][3][3] as in the state_dict
  * (cin' = cin, cout' = cout).  flip_transpose = 1: the filter of the input-gradient convolution, w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]

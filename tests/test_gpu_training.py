@@ -482,3 +482,33 @@ def test_bf16x3_training_convolutions_track_the_f32_step():
         assert float((a - b).norm() / a.norm()) < 1e-2, k
     tower = [float((out["f32"][1][k] - out["bf16x3"][1][k]).norm() / (out["f32"][1][k].norm() + 1e-30)) for k in out["f32"][1] if "feat_extractor" in k and k.endswith("conv1.weight")]
     assert float(np.median(tower)) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 31, 128, 128), (3, 20, 62, 64, 64), (2, 37, 70, 32, 32), (1, 5, 9, 64, 32), (2, 33, 33, 32, 64), (5, 32, 31, 256, 256)])
+def test_conv3x3_wgrad_mfma_matches_fp32_wgrad(B, H, W, Ci, Co):
+    """eg_conv3x3_wgrad_mfma (split-bf16, pixels transposed while staged) against the fp32 implicit-GEMM weight gradient and, for
+    one tap, a float64 einsum: ragged strips (W % 32 != 0), row chunks, several units per workgroup, 1..8 channel tiles."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, Ci, generator=g).to(DEV)
+    dy = torch.randn(B, H, W, Co, generator=g).to(DEV)
+    ref = torch.empty(Co, 9 * Ci, device=DEV)
+    need = lib.eg_gemm_tn_workspace_floats(Co, 9 * Ci, B * H * W)
+    ws = torch.empty(max(int(need), 1), device=DEV)
+    L.check(lib.eg_conv3x3_wgrad(_ptr(x), _ptr(dy), _ptr(ref), B, H, W, Ci, Co, 1, _ptr(ws), ws.numel(), _stream(DEV)), "wgrad f32")
+    out = torch.full((Co, 9 * Ci), float("nan"), device=DEV)
+    need2 = int(lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Co))
+    assert need2 > 0
+    ws2 = torch.full((need2,), float("nan"), device=DEV)
+    L.check(lib.eg_conv3x3_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(out), B, H, W, Ci, Co, _ptr(ws2), ws2.numel(), _stream(DEV)), "wgrad mfma")
+    assert bool(torch.isfinite(out).all())
+    assert float((out - ref).norm() / ref.norm()) < 2e-5
+    # tap (kh, kw) = (0, 2) in float64
+    xs = torch.zeros(B, H, W, Ci, dtype=torch.float64, device=DEV)
+    xs[:, 1:, :-1] = x.double()[:, :-1, 1:]                 # x[b, oy - 1, ox + 1]
+    t = torch.einsum("bhwo,bhwi->oi", dy.double(), xs)
+    got = out.view(Co, 9, Ci)[:, 2].double()
+    assert float((got - t).norm() / t.norm()) < 1e-5
+    assert lib.eg_conv3x3_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(out), B, H, W, Ci, Co, _ptr(ws2), 16, _stream(DEV)) == -3            # EG_ERR_WORKSPACE (include/emogest.h)
