@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__
 // ---- column reductions over rows: two deterministic levels ---------------------------------------------------------------
 // level 1: block (bx, by) sums rows [by*rows_per, ...) of 64 columns -> part[by][2][C]
 //   mode 0: (sum a, sum a*a)      mode 1: (sum a, sum a*b)      mode 2: (sum a, sum a*(b - mean[c]))      mode 3: (sum (a - mean[c])^2, 0)
+//   mode 4 (fast path only): mode 2 with a replaced by a * [mask > 0]  (gradient behind a ReLU whose output is `mask`)
 // The centred forms (2, 3) keep BatchNorm exact for channels whose mean is large against their spread (post-ReLU maps):
 // E[x^2] - mean^2 from fp32 partial sums loses ~eps*mean^2/var there (measured: 3e-3 in the input gradient of one block).
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 // Segmented: blockIdx.y = segment (a clip for the SE pooling, 1 segment for BatchNorm / bias / LayerNorm-affine sums),
 // blockIdx.x = chunk of rows inside the segment; part[seg][chunk][2][C].
 __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
-                                                               float* __restrict__ part, long seg_rows, int C, long rows_per, int mode) {
+                                                               float* __restrict__ part, long seg_rows, int C, long rows_per, int mode,
+                                                               const float* __restrict__ mask) {
     __shared__ f4 s0[256], s1[256];
     const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const long r0 = (long)chunk * rows_per, r1 = (r0 + rows_per < seg_rows) ? r0 + rows_per : seg_rows;
@@ -290,9 +292,18 @@ __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __re
     if (mode >= 2) mu = *reinterpret_cast<const f4*>(mean + cq);
     const f4* a4 = reinterpret_cast<const f4*>(a + base);
     const f4* b4 = b ? reinterpret_cast<const f4*>(b + base) : nullptr;
+    const f4* m4 = mask ? reinterpret_cast<const f4*>(mask + base) : nullptr;
     f4 u = (f4){0.f, 0.f, 0.f, 0.f}, v = u;
     for (size_t f = tid; f < n4; f += 256) {
-        const f4 x = a4[f];
+        f4 x = a4[f];
+        if (mode == 4) {
+            const f4 m = m4[f];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = m[r] > 0.f ? x[r] : 0.f;
+            u += x;
+            v += x * (b4[f] - mu);
+            continue;
+        }
         if (mode == 0) { u += x; v += x * x; }
         else if (mode == 1) { u += x; v += x * b4[f]; }
         else if (mode == 2) { u += x; v += x * (b4[f] - mu); }
@@ -371,13 +382,188 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
-                                                           float* __restrict__ dx, float* __restrict__ dgamma, size_t total, int C, float inv_rows) {
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, size_t total, int C, float inv_rows,
+                                                           int relu_mask) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
-        const float xh = (x[i] - mean[c]) * rstd[c];
+        const float xv = x[i];
+        const float xh = (xv - mean[c]) * rstd[c];
         const float sdyxh = rstd[c] * sum_dyx[c];
-        dx[i] = gamma[c] * rstd[c] * (dy[i] - sum_dy[c] * inv_rows - xh * sdyxh * inv_rows);
+        const float d = gamma[c] * rstd[c] * (dy[i] - sum_dy[c] * inv_rows - xh * sdyxh * inv_rows);
+        dx[i] = (relu_mask && !(xv > 0.f)) ? 0.f : d;          // x = relu(conv): the ReLU's backward rides on this pass
         if (dgamma && i < (size_t)C) dgamma[i] = rstd[i] * sum_dyx[i];
+    }
+}
+
+// ---- fused SE-block pieces of the training path (ResNetBlocks.py:21-37 under autograd) --------------------------------------------
+// The conv kernels already emit per-(clip, tile) channel sums of their output (the SE pooling partials of the inference path):
+// BatchNorm's mean and the per-clip sums come from those without reading the map again.  One wave per channel.
+__global__ __launch_bounds__(256) void bn_mean_from_gap_kernel(const float* __restrict__ gap, int B, int tiles, int C, long rows,
+                                                               float* __restrict__ mean, float* __restrict__ clip_sum) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double tot = 0.0;
+    for (int b = lane; b < B; b += 64) {
+        double s = 0.0;
+        const float* g = gap + (size_t)b * tiles * C + c;
+        for (int t = 0; t < tiles; ++t) s += g[(size_t)t * C];
+        if (clip_sum) clip_sum[(size_t)b * C + c] = (float)s;
+        tot += s;
+    }
+    tot = wave_sum_d(tot);
+    if (lane == 0) mean[c] = (float)(tot / (double)rows);
+}
+
+// SE gate of one clip from the pooled BatchNorm output, pooled[c] = gamma (clip_sum/HW - mean) rstd + beta = mean_hw(bn2(c2)):
+// h = relu(W1 pooled + b1), gate = sigmoid(W2 h + b2) (ResNetBlocks.py:92-96).  One workgroup per clip, C <= 256.
+__global__ __launch_bounds__(256) void se_gate_train_kernel(const float* __restrict__ clip_sum, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ pooled,
+                                                            float* __restrict__ h, float* __restrict__ gate, int C, float inv_hw) {
+    __shared__ float sp[256], sh[32];
+    const int b = blockIdx.x, t = threadIdx.x, Ch = C >> 3;
+    if (t < C) {
+        const float p = (clip_sum[(size_t)b * C + t] * inv_hw - mean[t]) * rstd[t] * gamma[t] + beta[t];
+        sp[t] = p;
+        pooled[(size_t)b * C + t] = p;
+    }
+    __syncthreads();
+    if (t < Ch) {
+        float a = b1[t];
+        for (int c = 0; c < C; ++c) a += w1[(size_t)t * C + c] * sp[c];
+        a = fmaxf(a, 0.f);
+        sh[t] = a;
+        h[(size_t)b * Ch + t] = a;
+    }
+    __syncthreads();
+    if (t < C) {
+        float z = b2[t];
+        for (int j = 0; j < Ch; ++j) z += w2[(size_t)t * Ch + j] * sh[j];
+        gate[(size_t)b * C + t] = 1.f / (1.f + expf(-z));
+    }
+}
+
+// out = relu(bn2(c2) * gate[b,c] + res): the block's tail in one pass (bn2's output is never written; the backward pass recomputes it).
+__global__ __launch_bounds__(256) void se_tail_fwd_kernel(const f4* __restrict__ c2, const f4* __restrict__ res, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ gate, f4* __restrict__ out, size_t n4, int hwq, int cq_n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cq_n) * 4;
+        const size_t b = i / (size_t)hwq;
+        const f4 x = c2[i], r = res[i];
+        const f4 mu = *reinterpret_cast<const f4*>(mean + c), rs = *reinterpret_cast<const f4*>(rstd + c);
+        const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+        const f4 gt = *reinterpret_cast<const f4*>(gate + b * (size_t)(cq_n * 4) + c);
+        f4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(((x[k] - mu[k]) * rs[k] * ga[k] + be[k]) * gt[k] + r[k], 0.f);
+        out[i] = v;
+    }
+}
+
+// Backward of the SE gate of one clip.  With d_pre = dout * [out > 0], S1 = sum_hw d_pre, S2 = rstd * sum_hw d_pre (c2 - mean):
+//   dgate = sum_hw d_pre * bn2 = gamma S2 + beta S1;   dz2 = dgate g (1 - g);   dh = W2^T dz2;   dz1 = dh [h > 0];   dpool = W1^T dz1;
+// bn2's element gradient is d_pre * gate + dpool / HW, so its two BatchNorm reductions are sums over clips of
+//   u1 = gate S1 + dpool        u2 = gate S2 + dpool * P1 / HW,   P1 = sum_hw xhat = (clip_sum - HW mean) rstd
+// and no second reduction pass over the map is needed.
+__global__ __launch_bounds__(256) void se_gate_train_bwd_kernel(const float* __restrict__ s1, const float* __restrict__ s2raw,
+                                                                const float* __restrict__ clip_sum, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ gate, const float* __restrict__ h,
+                                                                const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ dz2,
+                                                                float* __restrict__ dz1, float* __restrict__ dgap_hw, float* __restrict__ u1,
+                                                                float* __restrict__ u2, int C, float hw) {
+    __shared__ float sz2[256], sz1[32];
+    const int b = blockIdx.x, t = threadIdx.x, Ch = C >> 3;
+    float S1 = 0.f, S2 = 0.f, g = 0.f;
+    if (t < C) {
+        S1 = s1[(size_t)b * C + t];
+        S2 = rstd[t] * s2raw[(size_t)b * C + t];
+        g = gate[(size_t)b * C + t];
+        const float z = (gamma[t] * S2 + beta[t] * S1) * g * (1.f - g);
+        sz2[t] = z;
+        dz2[(size_t)b * C + t] = z;
+    }
+    __syncthreads();
+    if (t < Ch) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += w2[(size_t)c * Ch + t] * sz2[c];
+        a = h[(size_t)b * Ch + t] > 0.f ? a : 0.f;
+        sz1[t] = a;
+        dz1[(size_t)b * Ch + t] = a;
+    }
+    __syncthreads();
+    if (t < C) {
+        float dp = 0.f;
+        for (int j = 0; j < Ch; ++j) dp += w1[(size_t)j * C + t] * sz1[j];
+        const float P1 = (clip_sum[(size_t)b * C + t] - hw * mean[t]) * rstd[t];
+        dgap_hw[(size_t)b * C + t] = dp / hw;
+        u1[(size_t)b * C + t] = g * S1 + dp;
+        u2[(size_t)b * C + t] = g * S2 + dp * P1 / hw;
+    }
+}
+
+// Sums over clips (fixed order): bn2's parameter gradients and reduction means, and the SE layer's weight gradients.  One block per channel c.
+__global__ __launch_bounds__(64) void se_tail_bwd_finish_kernel(const float* __restrict__ u1, const float* __restrict__ u2, const float* __restrict__ dz2,
+                                                                const float* __restrict__ dz1, const float* __restrict__ h, const float* __restrict__ pooled,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ m1,
+                                                                float* __restrict__ m2, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2, int B, int C, float inv_rows) {
+    const int c = blockIdx.x, t = threadIdx.x, Ch = C >> 3;
+    if (t < Ch) {               // dW2[c][t] = sum_b dz2[b,c] h[b,t];  dW1[t][c] = sum_b dz1[b,t] pooled[b,c]
+        float a = 0.f, d = 0.f;
+        for (int b = 0; b < B; ++b) {
+            a += dz2[(size_t)b * C + c] * h[(size_t)b * Ch + t];
+            d += dz1[(size_t)b * Ch + t] * pooled[(size_t)b * C + c];
+        }
+        dw2[(size_t)c * Ch + t] = a;
+        dw1[(size_t)t * C + c] = d;
+        if (c == 0) {
+            float e = 0.f;
+            for (int b = 0; b < B; ++b) e += dz1[(size_t)b * Ch + t];
+            db1[t] = e;
+        }
+    } else if (t == 32) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += u1[(size_t)b * C + c];
+        dbeta[c] = a;
+        m1[c] = a * inv_rows;
+    } else if (t == 33) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += u2[(size_t)b * C + c];
+        dgamma[c] = a;
+        m2[c] = a * inv_rows;
+    } else if (t == 34) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dz2[(size_t)b * C + c];
+        db2[c] = a;
+    }
+}
+
+// dres = d_pre = dout [out > 0];  dc2 = gamma rstd (db2 - m1 - xhat m2),  db2 = d_pre gate + dgap_hw,  xhat = (c2 - mean) rstd.
+__global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(const f4* __restrict__ dout, const f4* __restrict__ out, const f4* __restrict__ c2,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ gate,
+                                                                const float* __restrict__ dgap_hw, const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                f4* __restrict__ dc2, f4* __restrict__ dres, size_t n4, int hwq, int cq_n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cq_n) * 4;
+        const size_t b = i / (size_t)hwq;
+        const f4 d = dout[i], o = out[i], x = c2[i];
+        const f4 mu = *reinterpret_cast<const f4*>(mean + c), rs = *reinterpret_cast<const f4*>(rstd + c), ga = *reinterpret_cast<const f4*>(gamma + c);
+        const f4 a1 = *reinterpret_cast<const f4*>(m1 + c), a2 = *reinterpret_cast<const f4*>(m2 + c);
+        const f4 gt = *reinterpret_cast<const f4*>(gate + b * (size_t)(cq_n * 4) + c);
+        const f4 dg = *reinterpret_cast<const f4*>(dgap_hw + b * (size_t)(cq_n * 4) + c);
+        f4 dp, dx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dp[k] = o[k] > 0.f ? d[k] : 0.f;
+            const float xh = (x[k] - mu[k]) * rs[k];
+            dx[k] = ga[k] * rs[k] * (dp[k] * gt[k] + dg[k] - a1[k] - xh * a2[k]);
+        }
+        dres[i] = dp;
+        dc2[i] = dx;
     }
 }
 
@@ -778,7 +964,7 @@ extern "C" int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t le
 namespace {
 // rows = rows per segment; nseg segments back to back; partials part[seg][nblk][2][c] with nseg * nblk <= 512
 int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st,
-               int nseg = 1) {
+               int nseg = 1, const float* mask = nullptr) {
     const bool fast = (c >= 4) && (1024 % c == 0) && eg_aligned16(a) && (!b || eg_aligned16(b));
     long cap = 512 / nseg;
     if (cap < 1) cap = 1;
@@ -789,9 +975,10 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
     nblk = (rows + rows_per - 1) / rows_per;
     *nblk_out = (int)nblk;
     if (fast) {
-        hipLaunchKernelGGL(col_partial_fast_kernel, dim3((unsigned)nblk, nseg), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode);
+        hipLaunchKernelGGL(col_partial_fast_kernel, dim3((unsigned)nblk, nseg), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode, mask);
         return eg_check_launch("col_partial_fast");
     }
+    EG_REQUIRE(mode != 4, EG_ERR_UNSUPPORTED, "column reduction behind a ReLU mask: C=%d must divide 1024 and the operands be 16-byte aligned", c);
     for (int sgi = 0; sgi < nseg; ++sgi) {       // generic channel counts: one launch per segment
         const size_t off = (size_t)sgi * rows * c;
         hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a + off, b ? b + off : nullptr, mean,
@@ -821,7 +1008,7 @@ extern "C" int eg_bn_train_forward(const float* x, const float* gamma, const flo
     return eg_check_launch("bn_apply");
 }
 extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, const float* save_mean, const float* save_rstd, float* dx,
-                                    float* dgamma, float* dbeta, int64_t rows, int32_t c, float* workspace, void* stream) {
+                                    float* dgamma, float* dbeta, int64_t rows, int32_t c, int32_t relu_mask, float* workspace, void* stream) {
     EG_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG,
                "eg_bn_train_backward: bad argument");
     int nblk = 0;
@@ -831,9 +1018,97 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
     hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx, 1.0f);
     if (int rc = eg_check_launch("col_finalize")) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, dbeta, sum_dyx, dx, dgamma,
-                       (size_t)rows * c, c, 1.0f / (float)rows);
+                       (size_t)rows * c, c, 1.0f / (float)rows, relu_mask);
     return eg_check_launch("bn_bwd_apply");
 }
+// BatchNorm (train mode) whose input came out of eg_conv3x3 with gap_partial [batch][tiles][c]: the mean (and the per-clip sums, for the
+// SE pooling) are taken from those partials; one centred pass gives the variance.  y == nullptr: statistics only (the fused tail applies it).
+extern "C" int eg_bn_train_forward_gap(const float* x, const float* gap_partial, int32_t tiles, int32_t batch, const float* gamma, const float* beta,
+                                       float* y, float* save_mean, float* save_rstd, float* clip_sum, float* running_mean, float* running_var,
+                                       int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream) {
+    EG_REQUIRE(x && gap_partial && save_mean && save_rstd && workspace && rows > 0 && c > 0 && tiles > 0 && batch > 0 && (!y || (gamma && beta)),
+               EG_ERR_BAD_ARG, "eg_bn_train_forward_gap: bad argument");
+    hipLaunchKernelGGL(bn_mean_from_gap_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, gap_partial, batch, tiles, c, (long)rows, save_mean, clip_sum);
+    if (int rc = eg_check_launch("bn_mean_from_gap")) return rc;
+    int nblk = 0;
+    if (int rc = col_reduce(x, nullptr, save_mean, rows, c, 3, workspace, &nblk, ST)) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var);
+    if (int rc = eg_check_launch("bn_finalize")) return rc;
+    if (!y) return EG_OK;
+    hipLaunchKernelGGL(bn_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, save_mean, save_rstd, gamma, beta, y, (size_t)rows * c, c);
+    return eg_check_launch("bn_apply");
+}
+
+#define SE_TAIL_SHAPE(who) EG_REQUIRE(batch > 0 && hw > 0 && c >= 8 && c <= 256 && c % 8 == 0, EG_ERR_UNSUPPORTED, who ": C=%d (multiple of 8, <= 256)", c)
+
+extern "C" int eg_se_gate_train_forward(const float* clip_sum, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w1,
+                                        const float* b1, const float* w2, const float* b2, float* pooled, float* h, float* gate, int32_t batch, int32_t hw,
+                                        int32_t c, void* stream) {
+    EG_REQUIRE(clip_sum && mean && rstd && gamma && beta && w1 && b1 && w2 && b2 && pooled && h && gate, EG_ERR_BAD_ARG, "eg_se_gate_train_forward: null pointer");
+    SE_TAIL_SHAPE("eg_se_gate_train_forward");
+    hipLaunchKernelGGL(se_gate_train_kernel, dim3(batch), dim3(256), 0, ST, clip_sum, mean, rstd, gamma, beta, w1, b1, w2, b2, pooled, h, gate, c, 1.0f / (float)hw);
+    return eg_check_launch("se_gate_train");
+}
+
+extern "C" int eg_se_tail_forward(const float* c2, const float* res, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* gate, float* out, int32_t batch, int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(c2 && res && mean && rstd && gamma && beta && gate && out, EG_ERR_BAD_ARG, "eg_se_tail_forward: null pointer");
+    SE_TAIL_SHAPE("eg_se_tail_forward");
+    EG_REQUIRE(eg_aligned16(c2) && eg_aligned16(res) && eg_aligned16(out) && eg_aligned16(gate), EG_ERR_ALIGN, "eg_se_tail_forward: 16-byte aligned maps");
+    const size_t n4 = (size_t)batch * hw * c / 4;
+    hipLaunchKernelGGL(se_tail_fwd_kernel, grid1(n4), dim3(256), 0, ST, reinterpret_cast<const f4*>(c2), reinterpret_cast<const f4*>(res), mean, rstd, gamma,
+                       beta, gate, reinterpret_cast<f4*>(out), n4, hw * (c / 4), c / 4);
+    return eg_check_launch("se_tail_fwd");
+}
+
+// s1[b,c] = sum_hw dout [out > 0];  s2raw[b,c] = sum_hw dout [out > 0] (c2 - mean[c]).   workspace >= eg_colreduce_workspace_floats(c); batch <= 512.
+extern "C" int eg_se_tail_backward_reduce(const float* dout, const float* out, const float* c2, const float* mean, float* s1, float* s2raw,
+                                          int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream) {
+    EG_REQUIRE(dout && out && c2 && mean && s1 && s2raw && workspace && batch <= 512, EG_ERR_BAD_ARG, "eg_se_tail_backward_reduce: bad argument");
+    SE_TAIL_SHAPE("eg_se_tail_backward_reduce");
+    int nblk = 0;
+    if (int rc = col_reduce(dout, c2, mean, hw, c, 4, workspace, &nblk, ST, batch, out)) return rc;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4), batch), dim3(256), 0, ST, workspace, nblk, c, s1, s2raw, 1.0f);
+    return eg_check_launch("se_tail_bwd_reduce");
+}
+
+extern "C" int eg_se_gate_train_backward(const float* s1, const float* s2raw, const float* clip_sum, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, const float* gate, const float* h, const float* w1, const float* w2,
+                                         float* dz2, float* dz1, float* dgap_hw, float* u1, float* u2, int32_t batch, int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(s1 && s2raw && clip_sum && mean && rstd && gamma && beta && gate && h && w1 && w2 && dz2 && dz1 && dgap_hw && u1 && u2, EG_ERR_BAD_ARG,
+               "eg_se_gate_train_backward: null pointer");
+    SE_TAIL_SHAPE("eg_se_gate_train_backward");
+    hipLaunchKernelGGL(se_gate_train_bwd_kernel, dim3(batch), dim3(256), 0, ST, s1, s2raw, clip_sum, mean, rstd, gamma, beta, gate, h, w1, w2, dz2, dz1,
+                       dgap_hw, u1, u2, c, (float)hw);
+    return eg_check_launch("se_gate_train_bwd");
+}
+
+extern "C" int eg_se_tail_backward_finish(const float* u1, const float* u2, const float* dz2, const float* dz1, const float* h, const float* pooled,
+                                          float* dgamma, float* dbeta, float* m1, float* m2, float* dw1, float* db1, float* dw2, float* db2,
+                                          int32_t batch, int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(u1 && u2 && dz2 && dz1 && h && pooled && dgamma && dbeta && m1 && m2 && dw1 && db1 && dw2 && db2, EG_ERR_BAD_ARG,
+               "eg_se_tail_backward_finish: null pointer");
+    SE_TAIL_SHAPE("eg_se_tail_backward_finish");
+    hipLaunchKernelGGL(se_tail_bwd_finish_kernel, dim3(c), dim3(64), 0, ST, u1, u2, dz2, dz1, h, pooled, dgamma, dbeta, m1, m2, dw1, db1, dw2, db2, batch, c,
+                       1.0f / ((float)batch * (float)hw));
+    return eg_check_launch("se_tail_bwd_finish");
+}
+
+extern "C" int eg_se_tail_backward_apply(const float* dout, const float* out, const float* c2, const float* mean, const float* rstd, const float* gamma,
+                                         const float* gate, const float* dgap_hw, const float* m1, const float* m2, float* dc2, float* dres, int32_t batch,
+                                         int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(dout && out && c2 && mean && rstd && gamma && gate && dgap_hw && m1 && m2 && dc2 && dres, EG_ERR_BAD_ARG, "eg_se_tail_backward_apply: null pointer");
+    SE_TAIL_SHAPE("eg_se_tail_backward_apply");
+    EG_REQUIRE(eg_aligned16(dout) && eg_aligned16(out) && eg_aligned16(c2) && eg_aligned16(dc2) && eg_aligned16(dres), EG_ERR_ALIGN,
+               "eg_se_tail_backward_apply: 16-byte aligned maps");
+    const size_t n4 = (size_t)batch * hw * c / 4;
+    hipLaunchKernelGGL(se_tail_bwd_apply_kernel, grid1(n4), dim3(256), 0, ST, reinterpret_cast<const f4*>(dout), reinterpret_cast<const f4*>(out),
+                       reinterpret_cast<const f4*>(c2), mean, rstd, gamma, gate, dgap_hw, m1, m2, reinterpret_cast<f4*>(dc2), reinterpret_cast<f4*>(dres), n4,
+                       hw * (c / 4), c / 4);
+    return eg_check_launch("se_tail_bwd_apply");
+}
+
 // o0[c] = sum_r a[r][c];  o1[c] = sum_r a[r][c]*b[r][c] (b optional: then o1 = sum a^2)
 extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream) {
     EG_REQUIRE(a && (o0 || o1) && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_colsum: bad argument");

@@ -270,9 +270,10 @@ class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(k=3, pad=1, stride s) on NHWC activations; weight OIHW as in the reference's state_dict."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu):
+    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False):
         lib = _lib()
         xd, wd = _chk(x, "x"), _chk(w, "weight")
+        gap = None
         B, H, W, Ci = xd.shape
         Co = wd.shape[0]
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -287,7 +288,9 @@ class _Conv3x3(torch.autograd.Function):
                 bp[:Co].copy_(_chk(b))
             if Co % 4 == 0:
                 y = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev)
-                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), None, B, H, W, Ci, Co, stride, int(relu), 0, prec,
+                if want_gap:            # per-(clip, tile) channel sums of y from the conv epilogue: BatchNorm's mean / the SE pooling for free
+                    gap = torch.empty(B, int(lib.eg_conv3x3_gap_tiles(H, W, Ci, Co, stride)), Co, dtype=torch.float32, device=dev)
+                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), _ptr(gap), B, H, W, Ci, Co, stride, int(relu), 0, prec,
                                        _stream(dev)), "eg_conv3x3")
             else:           # ragged channel count (final_conv1: 128 -> frames): channel-major epilogue, then back to NHWC
                 yc = torch.empty(B, Co, Ho * Wo, dtype=torch.float32, device=dev)
@@ -299,12 +302,17 @@ class _Conv3x3(torch.autograd.Function):
             L.check(lib.eg_im2col3x3(_ptr(xd), _ptr(col), B, H, W, Ci, stride, 0, _stream(dev)), "eg_im2col3x3")
             wm = wd.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
             y = raw_linear(col, wm, _chk(b) if b is not None else None, relu).view(B, Ho, Wo, Co)
-        ctx.save_for_backward(xd, wd, y if relu else None)
+        if want_gap and gap is None:
+            raise ValueError("conv3x3(want_gap=True): only the NHWC tower convolutions (Cin % 32 == 0, Cout % 4 == 0) emit pooling partials")
+        ctx.save_for_backward(xd, wd, y if (relu and not defer_mask) else None)      # defer_mask: the consumer (batch_norm(relu_input=True)) applies it
         ctx.stride, ctx.has_b, ctx.need_dx = stride, b is not None, x.requires_grad
+        if want_gap:
+            ctx.mark_non_differentiable(gap)
+            return y, gap
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dgap=None):
         lib = _lib()
         x, w, y = ctx.saved_tensors
         B, H, W, Ci = x.shape
@@ -345,11 +353,12 @@ class _Conv3x3(torch.autograd.Function):
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
             dx = torch.empty_like(x)
             L.check(lib.eg_im2col3x3(_ptr(dcol), _ptr(dx), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_col2im3x3")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False):
-    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu)
+def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False):
+    """want_gap: also return the per-(clip, tile) channel sums of the output; defer_mask: the ReLU's backward is applied by the consumer."""
+    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask)
 
 
 class _Subsample(torch.autograd.Function):
@@ -384,7 +393,7 @@ class _BatchNorm(torch.autograd.Function):
     """nn.BatchNorm{1,2}d in train() mode over the last (channel) axis; updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, gap=None, relu_input=False):
         lib = _lib()
         xd, g, b = _chk(x), _chk(gamma), _chk(beta)
         Cc = xd.shape[-1]
@@ -393,9 +402,15 @@ class _BatchNorm(torch.autograd.Function):
         y = torch.empty_like(xd)
         mean, rstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
-        L.check(lib.eg_bn_train_forward(_ptr(xd), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(run_mean), _ptr(run_var), rows, Cc,
-                                        float(momentum), float(eps), _ptr(ws), _stream(dev)), "eg_bn_train_forward")
+        if gap is not None:         # mean from the producing convolution's pooling partials: one pass (centred squares) instead of two
+            L.check(lib.eg_bn_train_forward_gap(_ptr(xd), _ptr(gap), gap.shape[1], gap.shape[0], _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), None,
+                                                _ptr(run_mean), _ptr(run_var), rows, Cc, float(momentum), float(eps), _ptr(ws), _stream(dev)),
+                    "eg_bn_train_forward_gap")
+        else:
+            L.check(lib.eg_bn_train_forward(_ptr(xd), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(run_mean), _ptr(run_var), rows, Cc,
+                                            float(momentum), float(eps), _ptr(ws), _stream(dev)), "eg_bn_train_forward")
         ctx.save_for_backward(xd, g, mean, rstd)
+        ctx.relu_input = bool(relu_input)
         return y
 
     @staticmethod
@@ -408,16 +423,74 @@ class _BatchNorm(torch.autograd.Function):
         dyd = _chk(dy)
         dx, dg, db = torch.empty_like(x), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
-        L.check(lib.eg_bn_train_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, Cc, _ptr(ws),
-                                         _stream(dev)), "eg_bn_train_backward")
-        return dx, dg, db, None, None, None, None
+        L.check(lib.eg_bn_train_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, Cc, int(ctx.relu_input),
+                                         _ptr(ws), _stream(dev)), "eg_bn_train_backward")
+        return dx, dg, db, None, None, None, None, None, None
 
 
-def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5):
-    """`bn` = a BatchNorm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked)."""
-    y = _BatchNorm.apply(x_channels_last, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, eps)
+def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5, gap=None, relu_input=False):
+    """`bn` = a BatchNorm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked).  gap: pooling partials of the
+    convolution that produced x (conv3x3(want_gap=True)); relu_input: x = relu(.) whose mask this backward applies (conv3x3(defer_mask=True))."""
+    y = _BatchNorm.apply(x_channels_last, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, eps, gap, relu_input)
     bn.num_batches_tracked += 1
     return y
+
+
+class _SEBlockTail(torch.autograd.Function):
+    """relu(se(bn2(c2)) + res) of SEBasicBlock.forward (ResNetBlocks.py:28-36) as one operator: bn2's statistics from conv2's pooling
+    partials + one centred pass, the SE gate per clip, one fused output pass; bn2's output is never stored (the backward recomputes it)."""
+
+    @staticmethod
+    def forward(ctx, c2, gap, res, gamma, beta, run_mean, run_var, w1, b1, w2, b2, momentum, eps):
+        lib = _lib()
+        x, r = _chk(c2), _chk(res)
+        B, H, W, Cc = x.shape
+        hw, dev = H * W, x.device
+        g, bt, w1d, b1d, w2d, b2d = _chk(gamma), _chk(beta), _chk(w1), _chk(b1), _chk(w2), _chk(b2)
+        mean, rstd, clip = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(B, Cc, device=dev)
+        ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        st = _stream(dev)
+        L.check(lib.eg_bn_train_forward_gap(_ptr(x), _ptr(gap), gap.shape[1], B, None, None, None, _ptr(mean), _ptr(rstd), _ptr(clip), _ptr(run_mean),
+                                            _ptr(run_var), B * hw, Cc, float(momentum), float(eps), _ptr(ws), st), "eg_bn_train_forward_gap")
+        pooled, h, gate = torch.empty(B, Cc, device=dev), torch.empty(B, Cc // 8, device=dev), torch.empty(B, Cc, device=dev)
+        L.check(lib.eg_se_gate_train_forward(_ptr(clip), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(w1d), _ptr(b1d), _ptr(w2d), _ptr(b2d), _ptr(pooled),
+                                             _ptr(h), _ptr(gate), B, hw, Cc, st), "eg_se_gate_train_forward")
+        out = torch.empty_like(x)
+        L.check(lib.eg_se_tail_forward(_ptr(x), _ptr(r), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(out), B, hw, Cc, st), "eg_se_tail_forward")
+        ctx.save_for_backward(x, out, mean, rstd, clip, pooled, h, gate, g, bt, w1d, w2d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib()
+        x, out, mean, rstd, clip, pooled, h, gate, g, bt, w1, w2 = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        hw, dev, Ch = H * W, x.device, Cc // 8
+        d = _chk(dout)
+        st = _stream(dev)
+        ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        small = torch.empty(6, B, Cc, device=dev)                                   # s1, s2raw, dz2, dgap_hw, u1, u2
+        s1, s2, dz2, dgap, u1, u2 = small.unbind(0)
+        dz1 = torch.empty(B, Ch, device=dev)
+        L.check(lib.eg_se_tail_backward_reduce(_ptr(d), _ptr(out), _ptr(x), _ptr(mean), _ptr(s1), _ptr(s2), B, hw, Cc, _ptr(ws), st),
+                "eg_se_tail_backward_reduce")
+        L.check(lib.eg_se_gate_train_backward(_ptr(s1), _ptr(s2), _ptr(clip), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(h), _ptr(w1), _ptr(w2),
+                                              _ptr(dz2), _ptr(dz1), _ptr(dgap), _ptr(u1), _ptr(u2), B, hw, Cc, st), "eg_se_gate_train_backward")
+        vec = torch.empty(5, Cc, device=dev)                                        # dgamma, dbeta, m1, m2, db2
+        dg, db, m1, m2, db2 = vec.unbind(0)
+        dw1, db1, dw2 = torch.empty(Ch, Cc, device=dev), torch.empty(Ch, device=dev), torch.empty(Cc, Ch, device=dev)
+        L.check(lib.eg_se_tail_backward_finish(_ptr(u1), _ptr(u2), _ptr(dz2), _ptr(dz1), _ptr(h), _ptr(pooled), _ptr(dg), _ptr(db), _ptr(m1), _ptr(m2),
+                                               _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), B, hw, Cc, st), "eg_se_tail_backward_finish")
+        dc2, dres = torch.empty_like(x), torch.empty_like(x)
+        L.check(lib.eg_se_tail_backward_apply(_ptr(d), _ptr(out), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(gate), _ptr(dgap), _ptr(m1), _ptr(m2),
+                                              _ptr(dc2), _ptr(dres), B, hw, Cc, st), "eg_se_tail_backward_apply")
+        return dc2, None, dres, dg, db, None, None, dw1, db1, dw2, db2, None, None
+
+
+def se_block_tail(c2, gap, res, bn, fc0, fc2, momentum=0.1, eps=1e-5):
+    out = _SEBlockTail.apply(c2, gap, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, fc0.weight, fc0.bias, fc2.weight, fc2.bias, momentum, eps)
+    bn.num_batches_tracked += 1
+    return out
 
 
 class _SELayer(torch.autograd.Function):

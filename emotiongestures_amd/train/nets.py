@@ -44,7 +44,26 @@ def _fork_n(x, n):
 DEBUG_TAPS = None       # tools/debug_block_grad.py: {id(block): dict} receives the block's intermediates with retain_grad()
 
 
+FUSE_BLOCK = True           # False: the operator-by-operator block (A/B switch of tests and tools)
+
+
 def se_basic_block(blk, x):
+    if not FUSE_BLOCK or DEBUG_TAPS is not None:
+        return _se_basic_block_unfused(blk, x)
+    # fused data flow: the convolutions emit pooling partials (BatchNorm means and the SE pooling without extra passes), bn1's backward
+    # carries conv1's ReLU mask, and everything behind conv2 -- bn2, SE gate, scale, residual add, ReLU -- is one operator
+    xa, xb = F.fork(x)
+    r1, gap1 = F.conv3x3(xa, blk.conv1.weight, None, blk.stride, relu=True, want_gap=True, defer_mask=True)     # conv1 -> ReLU -> bn1 (:24-26)
+    b1 = F.batch_norm(r1, blk.bn1, gap=gap1, relu_input=True)
+    c2, gap2 = F.conv3x3(b1, blk.conv2.weight, want_gap=True)
+    if blk.downsample is not None:
+        res = F.batch_norm(F.conv1x1(xb, blk.downsample[0].weight, blk.stride), blk.downsample[1])
+    else:
+        res = xb
+    return F.se_block_tail(c2, gap2, res, blk.bn2, blk.se.fc[0], blk.se.fc[2])
+
+
+def _se_basic_block_unfused(blk, x):
     xa, xb = F.fork(x)
     r1 = F.conv3x3(xa, blk.conv1.weight, None, blk.stride, relu=True)           # conv1 -> ReLU -> bn1 (ReLU precedes BN, :24-26)
     b1 = F.batch_norm(r1, blk.bn1)

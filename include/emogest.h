@@ -376,8 +376,35 @@ int64_t eg_colreduce_workspace_floats(int32_t c);
 int eg_bn_train_forward(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_rstd,
                         float* running_mean, float* running_var, int64_t rows, int32_t c, float momentum, float eps, float* workspace,
                         void* stream);
+/* relu_mask != 0: x is the output of a ReLU (conv1 -> ReLU -> bn1, ResNetBlocks.py:24-26) and dx is that ReLU's input gradient, dx * [x > 0]. */
 int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, const float* save_mean, const float* save_rstd, float* dx,
-                         float* dgamma, float* dbeta, int64_t rows, int32_t c, float* workspace, void* stream);
+                         float* dgamma, float* dbeta, int64_t rows, int32_t c, int32_t relu_mask, float* workspace, void* stream);
+/* BatchNorm (train mode) on a map that eg_conv3x3 just wrote together with gap_partial [batch][tiles][c] (per-tile channel sums): the mean
+ * and clip_sum [batch][c] (nullable) come from the partials, one centred pass over x gives the variance.  y NULL: statistics only. */
+int eg_bn_train_forward_gap(const float* x, const float* gap_partial, int32_t tiles, int32_t batch, const float* gamma, const float* beta,
+                            float* y, float* save_mean, float* save_rstd, float* clip_sum, float* running_mean, float* running_var,
+                            int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream);
+/* SEBasicBlock tail under autograd (ResNetBlocks.py:28-36,92-96), maps [batch, hw, c] channels-last, c % 8 == 0, c <= 256:
+ *   forward:  pooled = mean_hw(bn2(c2)) from clip_sum; h = relu(W1 pooled + b1); gate = sigmoid(W2 h + b2)      (eg_se_gate_train_forward)
+ *             out = relu(bn2(c2) * gate + res) in one pass, bn2's output never stored                            (eg_se_tail_forward)
+ *   backward: one masked reduction pass (s1, s2raw per clip), the gate's backward per clip (dz2, dz1, dgap_hw, u1, u2), the sums over
+ *             clips (bn2 / SE parameter gradients, m1, m2), and one apply pass writing dc2 and dres. */
+int eg_se_gate_train_forward(const float* clip_sum, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w1,
+                             const float* b1, const float* w2, const float* b2, float* pooled, float* h, float* gate, int32_t batch, int32_t hw,
+                             int32_t c, void* stream);
+int eg_se_tail_forward(const float* c2, const float* res, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* gate, float* out, int32_t batch, int32_t hw, int32_t c, void* stream);
+int eg_se_tail_backward_reduce(const float* dout, const float* out, const float* c2, const float* mean, float* s1, float* s2raw,
+                               int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream);
+int eg_se_gate_train_backward(const float* s1, const float* s2raw, const float* clip_sum, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, const float* gate, const float* h, const float* w1, const float* w2,
+                              float* dz2, float* dz1, float* dgap_hw, float* u1, float* u2, int32_t batch, int32_t hw, int32_t c, void* stream);
+int eg_se_tail_backward_finish(const float* u1, const float* u2, const float* dz2, const float* dz1, const float* h, const float* pooled,
+                               float* dgamma, float* dbeta, float* m1, float* m2, float* dw1, float* db1, float* dw2, float* db2,
+                               int32_t batch, int32_t hw, int32_t c, void* stream);
+int eg_se_tail_backward_apply(const float* dout, const float* out, const float* c2, const float* mean, const float* rstd, const float* gamma,
+                              const float* gate, const float* dgap_hw, const float* m1, const float* m2, float* dc2, float* dres, int32_t batch,
+                              int32_t hw, int32_t c, void* stream);
 /* o0[c] = sum_r a[r,c]; o1[c] = sum_r a[r,c]*b[r,c] (b NULL: sum a^2).  bias / LayerNorm affine gradients. */
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
 /* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) */

@@ -512,3 +512,45 @@ def test_conv3x3_wgrad_mfma_matches_fp32_wgrad(B, H, W, Ci, Co):
     got = out.view(Co, 9, Ci)[:, 2].double()
     assert float((got - t).norm() / t.norm()) < 1e-5
     assert lib.eg_conv3x3_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(out), B, H, W, Ci, Co, _ptr(ws2), 16, _stream(DEV)) == -3            # EG_ERR_WORKSPACE (include/emogest.h)
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(1, 32, 32), (2, 32, 64), (1, 128, 128)])
+def test_fused_se_block_matches_operator_by_operator_block(stride, cin, cout):
+    """nets.se_basic_block's fused data flow (pooling partials -> BatchNorm mean, ReLU mask inside bn1's backward, one-operator tail) against
+    the operator-by-operator block on the same weights and input: output, input gradient, every parameter gradient, running statistics."""
+    from emotiongestures_amd.modules import SEBasicBlock
+    from emotiongestures_amd.train import nets
+    import copy
+    torch.manual_seed(11)
+    from emotiongestures_amd.modules import ResNetSE
+    net = ResNetSE(SEBasicBlock, [1, 1, 1], [32, 64, 128])
+    blk = {(1, 32, 32): net.layer1[0], (2, 32, 64): net.layer2[0], (1, 128, 128): SEBasicBlock(128, 128)}[(stride, cin, cout)]
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.1)
+    for n, p in blk.named_parameters():
+        if n.endswith("bn1.weight") or n.endswith("bn2.weight") or n.endswith("downsample.1.weight"):
+            p.data.add_(1.0)
+    blk = blk.to(DEV)
+    blk2 = copy.deepcopy(blk)
+    x = torch.randn(3, 20, 37, cin, device=DEV)
+    dy = None
+    res = []
+    for b, fuse in ((blk, True), (blk2, False)):
+        nets.FUSE_BLOCK = fuse
+        try:
+            xi = x.clone().requires_grad_(True)
+            out = nets.se_basic_block(b, xi)
+            if dy is None:
+                dy = torch.randn_like(out)
+            out.backward(dy)
+        finally:
+            nets.FUSE_BLOCK = True
+        res.append((out.detach(), xi.grad, {n: p.grad for n, p in b.named_parameters()}, {n: v.clone() for n, v in b.named_buffers()}))
+    (o1, g1, p1, b1), (o2, g2, p2, b2) = res
+    rel = lambda a, c: float((a - c).norm() / (c.norm() + 1e-30))
+    assert rel(o1, o2) < 2e-6
+    assert rel(g1, g2) < 2e-5
+    for n in p2:
+        assert p1[n] is not None and rel(p1[n], p2[n]) < 5e-5, n
+    for n in b2:
+        assert rel(b1[n].float(), b2[n].float()) < 1e-6, n
