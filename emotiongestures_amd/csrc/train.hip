@@ -398,18 +398,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---- fused SE-block pieces of the training path (ResNetBlocks.py:21-37 under autograd) --------------------------------------------
 // The conv kernels already emit per-(clip, tile) channel sums of their output (the SE pooling partials of the inference path):
 // BatchNorm's mean and the per-clip sums come from those without reading the map again.  One wave per channel.
-__global__ __launch_bounds__(256) void bn_mean_from_gap_kernel(const float* __restrict__ gap, int B, int tiles, int C, long rows,
-                                                               float* __restrict__ mean, float* __restrict__ clip_sum) {
+__global__ __launch_bounds__(256) void clip_sum_from_gap_kernel(const float* __restrict__ gap, int tiles, int C, float* __restrict__ clip_sum) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, t = threadIdx.x, c = t % C, g = t / C, ng = 256 / C;          // C divides 256: ng tile groups
+    float s = 0.f;
+    for (int k = g; k < tiles; k += ng) s += gap[((size_t)b * tiles + k) * C + c];
+    red[t] = s;
+    __syncthreads();
+    if (t < C) {
+        float a = 0.f;
+        for (int k = 0; k < ng; ++k) a += red[k * C + t];
+        clip_sum[(size_t)b * C + t] = a;
+    }
+}
+__global__ __launch_bounds__(256) void bn_mean_from_clips_kernel(const float* __restrict__ clip_sum, int B, int C, long rows, float* __restrict__ mean) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double tot = 0.0;
-    for (int b = lane; b < B; b += 64) {
-        double s = 0.0;
-        const float* g = gap + (size_t)b * tiles * C + c;
-        for (int t = 0; t < tiles; ++t) s += g[(size_t)t * C];
-        if (clip_sum) clip_sum[(size_t)b * C + c] = (float)s;
-        tot += s;
-    }
+    for (int b = lane; b < B; b += 64) tot += clip_sum[(size_t)b * C + c];
     tot = wave_sum_d(tot);
     if (lane == 0) mean[c] = (float)(tot / (double)rows);
 }
@@ -504,40 +510,50 @@ __global__ __launch_bounds__(256) void se_gate_train_bwd_kernel(const float* __r
     }
 }
 
-// Sums over clips (fixed order): bn2's parameter gradients and reduction means, and the SE layer's weight gradients.  One block per channel c.
+// Sums over clips (fixed order: lanes stride over clips, butterfly wave reduction): bn2's parameter gradients and reduction means, and the
+// SE layer's weight gradients.  One wave per channel c.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int CH>
 __global__ __launch_bounds__(64) void se_tail_bwd_finish_kernel(const float* __restrict__ u1, const float* __restrict__ u2, const float* __restrict__ dz2,
                                                                 const float* __restrict__ dz1, const float* __restrict__ h, const float* __restrict__ pooled,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ m1,
                                                                 float* __restrict__ m2, float* __restrict__ dw1, float* __restrict__ db1,
                                                                 float* __restrict__ dw2, float* __restrict__ db2, int B, int C, float inv_rows) {
-    const int c = blockIdx.x, t = threadIdx.x, Ch = C >> 3;
-    if (t < Ch) {               // dW2[c][t] = sum_b dz2[b,c] h[b,t];  dW1[t][c] = sum_b dz1[b,t] pooled[b,c]
-        float a = 0.f, d = 0.f;
-        for (int b = 0; b < B; ++b) {
-            a += dz2[(size_t)b * C + c] * h[(size_t)b * Ch + t];
-            d += dz1[(size_t)b * Ch + t] * pooled[(size_t)b * C + c];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float a2[CH], a1[CH], e1[CH], su1 = 0.f, su2 = 0.f, sz = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) a2[j] = a1[j] = e1[j] = 0.f;
+    for (int b = lane; b < B; b += 64) {
+        const float z2 = dz2[(size_t)b * C + c], p = pooled[(size_t)b * C + c];
+        su1 += u1[(size_t)b * C + c];
+        su2 += u2[(size_t)b * C + c];
+        sz += z2;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float z1 = dz1[(size_t)b * CH + j];
+            a2[j] += z2 * h[(size_t)b * CH + j];            // dW2[c][j] = sum_b dz2[b,c] h[b,j]
+            a1[j] += z1 * p;                                // dW1[j][c] = sum_b dz1[b,j] pooled[b,c]
+            e1[j] += z1;
         }
-        dw2[(size_t)c * Ch + t] = a;
-        dw1[(size_t)t * C + c] = d;
-        if (c == 0) {
-            float e = 0.f;
-            for (int b = 0; b < B; ++b) e += dz1[(size_t)b * Ch + t];
-            db1[t] = e;
+    }
+    su1 = wave_sum_f(su1); su2 = wave_sum_f(su2); sz = wave_sum_f(sz);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const float x2 = wave_sum_f(a2[j]), x1 = wave_sum_f(a1[j]), y1 = wave_sum_f(e1[j]);
+        if (lane == 0) {
+            dw2[(size_t)c * CH + j] = x2;
+            dw1[(size_t)j * C + c] = x1;
+            if (c == 0) db1[j] = y1;
         }
-    } else if (t == 32) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += u1[(size_t)b * C + c];
-        dbeta[c] = a;
-        m1[c] = a * inv_rows;
-    } else if (t == 33) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += u2[(size_t)b * C + c];
-        dgamma[c] = a;
-        m2[c] = a * inv_rows;
-    } else if (t == 34) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dz2[(size_t)b * C + c];
-        db2[c] = a;
+    }
+    if (lane == 0) {
+        dbeta[c] = su1; m1[c] = su1 * inv_rows;
+        dgamma[c] = su2; m2[c] = su2 * inv_rows;
+        db2[c] = sz;
     }
 }
 
@@ -1028,8 +1044,13 @@ extern "C" int eg_bn_train_forward_gap(const float* x, const float* gap_partial,
                                        int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream) {
     EG_REQUIRE(x && gap_partial && save_mean && save_rstd && workspace && rows > 0 && c > 0 && tiles > 0 && batch > 0 && (!y || (gamma && beta)),
                EG_ERR_BAD_ARG, "eg_bn_train_forward_gap: bad argument");
-    hipLaunchKernelGGL(bn_mean_from_gap_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, gap_partial, batch, tiles, c, (long)rows, save_mean, clip_sum);
-    if (int rc = eg_check_launch("bn_mean_from_gap")) return rc;
+    EG_REQUIRE(c <= 256 && 256 % c == 0, EG_ERR_UNSUPPORTED, "eg_bn_train_forward_gap: C=%d must divide 256", c);
+    float* cs = clip_sum ? clip_sum : workspace + (size_t)2 * 512 * c - (size_t)batch * c;        // scratch behind the (later) partials: read before they are written
+    EG_REQUIRE(clip_sum || batch <= 512, EG_ERR_UNSUPPORTED, "eg_bn_train_forward_gap: batch %d > 512 needs a clip_sum buffer", batch);
+    hipLaunchKernelGGL(clip_sum_from_gap_kernel, dim3(batch), dim3(256), 0, ST, gap_partial, tiles, c, cs);
+    if (int rc = eg_check_launch("clip_sum_from_gap")) return rc;
+    hipLaunchKernelGGL(bn_mean_from_clips_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, cs, batch, c, (long)rows, save_mean);
+    if (int rc = eg_check_launch("bn_mean_from_clips")) return rc;
     int nblk = 0;
     if (int rc = col_reduce(x, nullptr, save_mean, rows, c, 3, workspace, &nblk, ST)) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
@@ -1090,8 +1111,17 @@ extern "C" int eg_se_tail_backward_finish(const float* u1, const float* u2, cons
     EG_REQUIRE(u1 && u2 && dz2 && dz1 && h && pooled && dgamma && dbeta && m1 && m2 && dw1 && db1 && dw2 && db2, EG_ERR_BAD_ARG,
                "eg_se_tail_backward_finish: null pointer");
     SE_TAIL_SHAPE("eg_se_tail_backward_finish");
-    hipLaunchKernelGGL(se_tail_bwd_finish_kernel, dim3(c), dim3(64), 0, ST, u1, u2, dz2, dz1, h, pooled, dgamma, dbeta, m1, m2, dw1, db1, dw2, db2, batch, c,
-                       1.0f / ((float)batch * (float)hw));
+    const float inv_rows = 1.0f / ((float)batch * (float)hw);
+#define FINISH(CH) hipLaunchKernelGGL(se_tail_bwd_finish_kernel<CH>, dim3(c), dim3(64), 0, ST, u1, u2, dz2, dz1, h, pooled, dgamma, dbeta, m1, m2, dw1, db1, \
+                                      dw2, db2, batch, c, inv_rows)
+    switch (c / 8) {
+        case 4: FINISH(4); break;
+        case 8: FINISH(8); break;
+        case 16: FINISH(16); break;
+        case 32: FINISH(32); break;
+        default: eg_set_error("eg_se_tail_backward_finish: C=%d (32, 64, 128 or 256)", c); return EG_ERR_UNSUPPORTED;
+    }
+#undef FINISH
     return eg_check_launch("se_tail_bwd_finish");
 }
 
