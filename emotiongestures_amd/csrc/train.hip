@@ -640,6 +640,36 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
     limg[idx] = lo;
 }
 
+// ---- nn.Linear weight image, built on the device --------------------------------------------------------------------------------------
+// [n][k] fp32 (row stride ld) -> the image eg_linear's split-bf16 modes read (gemm.hip: fill_common): fp32 [rows][kpad], then tile-planar bf16
+// hi and lo images [rows/64][kpad/8][64][8]; rows = n rounded up to 64, kpad = k rounded up to 64, zero padded.  transpose != 0 packs
+// the transposed matrix (the `weight` of dX = dY W is W^T): image row r, column q = w[q][r].  One thread per (row tile, k octet, row).
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, int ld, int n, int k, int transpose, float* __restrict__ image) {
+    const int rows = (n + 63) / 64 * 64, kpad = (k + 63) / 64 * 64, KO = kpad / 8;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * KO) return;
+    const int r = idx & 63, ko = (idx >> 6) % KO, rt = idx / (64 * KO);
+    const int row = rt * 64 + r;
+    f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (row < n) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = ko * 8 + j;
+            const float x = q < k ? (transpose ? w[(size_t)q * ld + row] : w[(size_t)row * ld + q]) : 0.f;
+            if (j < 4) v0[j] = x; else v1[j - 4] = x;
+        }
+    }
+    f4* f32img = reinterpret_cast<f4*>(image + (size_t)row * kpad + ko * 8);
+    f32img[0] = v0;
+    f32img[1] = v1;
+    bf8 hi, lo;
+    split_octet<true>(v0, v1, hi, lo);
+    bf8* himg = reinterpret_cast<bf8*>(image + (size_t)rows * kpad);
+    bf8* limg = himg + (size_t)rows * KO;
+    himg[idx] = hi;
+    limg[idx] = lo;
+}
+
 // ---- dropout: counter-based mask, nothing stored -- keep(i) = hash(seed, offset + i) >= p; y = keep ? x / (1 - p) : 0.  The backward pass
 // is the same kernel on dy with the same (seed, offset).  (nn.Dropout's semantics; the mask stream is this library's own, not torch's.)
 __device__ __forceinline__ unsigned int mix32(unsigned int h) {
@@ -1163,6 +1193,17 @@ extern "C" int eg_pack_conv3x3_device(const float* w_oihw, int32_t cout, int32_t
     const int total = 9 * (ci / 8) * (int)eg_round_up(co, 16);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, w_oihw, cout, cin, flip_transpose, image);
     return eg_check_launch("pack_conv3x3");
+}
+
+extern "C" int64_t eg_linear_packed_floats(int32_t n, int32_t k) {
+    return 2 * (int64_t)eg_round_up(n, 64) * (int64_t)eg_round_up(k, 64);      // fp32 image + (hi, lo) bf16 images (= the same bytes again)
+}
+extern "C" int eg_pack_linear_device(const float* w, int32_t ld, int32_t n, int32_t k, int32_t transpose, float* image, void* stream) {
+    EG_REQUIRE(w && image && n > 0 && k > 0 && ld >= (transpose ? n : k), EG_ERR_BAD_ARG, "eg_pack_linear_device: bad argument");
+    EG_REQUIRE(eg_aligned16(image), EG_ERR_ALIGN, "eg_pack_linear_device: image must be 16-byte aligned");
+    const int total = (int)(eg_round_up(n, 64) * (eg_round_up(k, 64) / 8));
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, w, ld, n, k, transpose, image);
+    return eg_check_launch("pack_linear");
 }
 
 extern "C" int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream) {

@@ -20,6 +20,21 @@ F32 = L.EG_PREC_F32
 _WS = {}
 
 
+_PREC = {"conv": F32, "gemm": F32}
+
+
+def set_precision(name: str) -> None:
+    """Arithmetic of the convolutions (forward, input and weight gradient) and of the Linear products (forward, input gradient) of the
+    training path: "f32" (fp32 MFMA; the gradient-parity configuration) or "bf16x3" (3-term split-bf16 MFMA with fp32 accumulation)."""
+    if name not in ("f32", "bf16x3"):
+        raise ValueError(f"train precision {name!r}: expected 'f32' or 'bf16x3'")
+    _PREC["conv"] = _PREC["gemm"] = F32 if name == "f32" else L.EG_PREC_BF16X3
+
+
+def get_precision() -> str:
+    return "f32" if _PREC["conv"] == F32 else "bf16x3"
+
+
 def _lib():
     return L.load()
 
@@ -55,9 +70,37 @@ def _pad_cols(t: torch.Tensor, mult=4) -> torch.Tensor:
 
 
 # ---- raw (non-autograd) kernels ---------------------------------------------------------------------------------------------
-def raw_linear(x, w, bias=None, relu=False, res=None):
-    """y[M,N] = x[M,K] w[N,K]^T (+bias) (+res) (relu) on the fp32 MFMA GEMM (eg_linear)."""
+def _pack_linear(w, transpose=False):
+    """[N,K] fp32 (or its transpose) -> eg_linear's split-bf16 weight image, one launch; returns (image, ldw)."""
     lib = _lib()
+    r, c = w.shape
+    n, k = (c, r) if transpose else (r, c)
+    img = torch.empty(int(lib.eg_linear_packed_floats(n, k)), dtype=torch.float32, device=w.device)
+    L.check(lib.eg_pack_linear_device(_ptr(w), c, n, k, int(transpose), _ptr(img), _stream(w.device)), "eg_pack_linear_device")
+    return img, (k + 63) // 64 * 64
+
+
+def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False):
+    """y[M,N] = x[M,K] w[N,K]^T (+bias) (+res) (relu) on the MFMA GEMM (eg_linear): fp32, or split-bf16 under set_precision("bf16x3").
+    w_transposed: w is [K,N] and the product is x w (the input gradient of a Linear)."""
+    lib = _lib()
+    if _PREC["gemm"] != F32:
+        x = _pad_cols(x)
+        M, K = x.shape
+        N = w.shape[1] if w_transposed else w.shape[0]
+        wimg, ldw = _pack_linear(w, w_transposed)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        if res is None and M <= 128 and K >= 4096:
+            splits = min(64, K // 1024)
+            part = _scratch(x.device, splits * M * N, "splitk")
+            L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part), _PREC["gemm"],
+                                         _stream(x.device)), "eg_linear_splitk")
+            return y
+        L.check(lib.eg_linear(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), 0, 0, _PREC["gemm"],
+                              _stream(x.device)), "eg_linear")
+        return y
+    if w_transposed:
+        w = raw_transpose(w)
     x, w = _pad_cols(x), _pad_cols(w)
     M, K = x.shape
     N = w.shape[0]
@@ -118,7 +161,7 @@ def raw_linear_backward(x, w, dy, need_dx=True):
     """dx = dy w;  dw = dy^T x;  db = colsum(dy)"""
     dw = raw_gemm_tn(dy, x)
     db, _ = raw_colsum(dy)
-    dx = raw_linear(dy, raw_transpose(w)) if need_dx else None          # [M,N] x ([K,N])^T
+    dx = raw_linear(dy, w, w_transposed=True) if need_dx else None      # [M,N] x [N,K]
     return dx, dw, db
 
 
@@ -239,21 +282,6 @@ def dropout(x, p: float):
     off = _DROP["offset"]
     _DROP["offset"] = off + (x.numel() + 1023) // 1024 * 1024
     return _Dropout.apply(x, p, _DROP["seed"], off)
-
-
-_PREC = {"conv": F32}
-
-
-def set_precision(name: str) -> None:
-    """Arithmetic of the 3x3 convolutions of the training path (forward and input gradient): "f32" (fp32 MFMA; the
-    gradient-parity configuration) or "bf16x3" (3-term split-bf16 MFMA with fp32 accumulation, the inference kernels)."""
-    if name not in ("f32", "bf16x3"):
-        raise ValueError(f"train precision {name!r}: expected 'f32' or 'bf16x3'")
-    _PREC["conv"] = F32 if name == "f32" else L.EG_PREC_BF16X3
-
-
-def get_precision() -> str:
-    return "f32" if _PREC["conv"] == F32 else "bf16x3"
 
 
 def _pack_conv(w, flip=False):

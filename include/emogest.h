@@ -419,6 +419,10 @@ int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_
  * (cin' = cin, cout' = cout).  flip_transpose = 1: the filter of the input-gradient convolution, w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
  * (cin' = cout, cout' = cin) -- F.conv2d's dgrad for stride 1 is eg_conv3x3 of dy with that image. */
 int eg_pack_conv3x3_device(const float* w_oihw, int32_t cout, int32_t cin, int32_t flip_transpose, float* image, void* stream);
+/* Device-side build of the weight image eg_linear's split-bf16 modes read (EG_PACK_LINEAR layout; eg_linear_packed_floats(n, k) floats,
+ * ldw = k rounded up to 64) from w [n][k] fp32 with row stride ld.  transpose != 0: the image of w^T (w is then [k][n]): dX = dY W. */
+int64_t eg_linear_packed_floats(int32_t n, int32_t k);
+int eg_pack_linear_device(const float* w, int32_t ld, int32_t n, int32_t k, int32_t transpose, float* image, void* stream);
 /* nn.Dropout in train() mode with a counter-based mask (nothing stored): keep(i) = hash(seed, offset + i) >= p, y = keep ? x/(1-p) : 0;
  * the backward pass is the same call on dy.  The mask stream is this library's own (not torch's RNG). */
 int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);
