@@ -151,6 +151,8 @@ def parse_args():
                          "all-reduce (RCCL) + fused Adam on --train-batch clips per GPU (fp32 operators)")
     ap.add_argument("--train-precision", choices=("f32", "bf16x3"), default="f32",
                     help="--train: arithmetic of the 3x3 convolutions (forward + input gradient); f32 is the gradient-parity configuration")
+    ap.add_argument("--train-graph", action="store_true",
+                    help="--train: capture the whole step (forward, backward, gradient collection, Adam) as one hipGraph and replay it")
     ap.add_argument("--train-batch", type=int, default=16, help="clips per GPU per training step (16 = global 128 on 8 GPUs, SURVEY.md §8d cfg 3)")
     return ap.parse_args()
 
@@ -223,7 +225,7 @@ def train_worker(args, rank, world, dev, dist, backend):
     eps = torch.from_numpy(synth_inputs(B, seed=3000 + rank)["z"]).to(dev)
     ar_ms = []
 
-    def step():
+    def step(timed=True):
         opt.zero_grad()
         gb.begin()
         pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
@@ -233,6 +235,10 @@ def train_worker(args, rank, world, dev, dist, backend):
         loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
                      F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
         loss.backward()
+        if not timed:                   # inside a stream capture: no timing events
+            gb.finish()
+            opt.step(collected=True)
+            return loss
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         gb.finish()                     # waits for the bucket all-reduces still running behind backward: the EXPOSED part
@@ -240,6 +246,12 @@ def train_worker(args, rank, world, dev, dist, backend):
         opt.step(collected=True)
         ar_ms.append((e0, e1))
         return loss
+
+    if args.train_graph:
+        from emotiongestures_amd.train.graph import GraphedStep
+        gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, args.warmup))
+        eager_step = step
+        step = lambda: gs.run()         # noqa: E731
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -260,7 +272,7 @@ def train_worker(args, rank, world, dev, dist, backend):
         tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms]))
+    exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms])) if ar_ms else None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -273,7 +285,8 @@ def train_worker(args, rank, world, dev, dist, backend):
             "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
                        "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": len(gb.buckets)},
-            "final_loss": float(loss.detach()), "allreduce_exposed_ms_per_step": round(exposed, 3)}))
+            "final_loss": float(loss.detach()), "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
+            "launch": "one captured hipGraph per step" if args.train_graph else "eager (autograd issues every kernel)"}))
     return 0
 
 

@@ -135,6 +135,8 @@ SIGNATURES = {
     "eg_cross_entropy": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, _P, _P, _I, _I, _P, _P]),
     "eg_kld": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
+    "eg_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "eg_counter_add": (C.c_int, [_P, _I, _P]),
 }
 
 _lib = None

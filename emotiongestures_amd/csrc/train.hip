@@ -586,13 +586,14 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(const f4* __rest
 // ---- elementwise ----------------------------------------------------------------------------------------------------------
 // op 0: y = max(x,0)            op 1: dx = dy * (x > 0)            op 2: y = x > 0 ? x : s*x        op 3: dx = dy * (x > 0 ? 1 : s)
 // op 4: y = a + b               op 5: y = a * s                    op 6: y = sigmoid(x)             op 7: dx = dy * y * (1 - y)  (a = dy, b = y)
-// op 8: y = a * b               op 9: y = a + s*b                  op 10: y = exp(s * a)
+// op 8: y = a * b               op 9: y = a + s*b                  op 10: y = exp(s * a)            op 11: y = a * b[0]  (scalar kept on the device)
 __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n, int op,
                                                  float s) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float u = a[i], v = b ? b[i] : 0.f;
+        const float u = a[i], v = b ? (op == 11 ? b[0] : b[i]) : 0.f;
         float r;
         switch (op) {
+            case 11: r = u * v; break;
             case 0: r = fmaxf(u, 0.f); break;
             case 1: r = v > 0.f ? u : 0.f; break;               // a = dy, b = x
             case 2: r = u > 0.f ? u : s * u; break;
@@ -917,6 +918,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// The same update with the step count read from device memory (a captured hipGraph replays with a count that advances on the device).
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                       size_t n, float lr, float b1, float b2, float eps, float wd, const int* __restrict__ step) {
+    const int t = *step;
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] + wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+__global__ void counter_add_kernel(int* c, int d) { *c += d; }
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -1179,7 +1196,7 @@ extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, i
 }
 
 extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream) {
-    EG_REQUIRE(a && y && n > 0 && op >= 0 && op <= 10, EG_ERR_BAD_ARG, "eg_elementwise: bad argument");
+    EG_REQUIRE(a && y && n > 0 && op >= 0 && op <= 11, EG_ERR_BAD_ARG, "eg_elementwise: bad argument");
     EG_REQUIRE(b || op == 0 || op == 2 || op == 5 || op == 6 || op == 10, EG_ERR_BAD_ARG, "eg_elementwise: op %d needs a second operand", op);
     hipLaunchKernelGGL(ew_kernel, grid1((size_t)n), dim3(256), 0, ST, a, b, y, (size_t)n, op, s);
     return eg_check_launch("elementwise");
@@ -1285,6 +1302,19 @@ extern "C" int eg_kld(const float* mu, const float* logvar, float* loss, float* 
     EG_REQUIRE(mu && logvar && loss && n > 0 && d > 0 && ((dmu == nullptr) == (dlogvar == nullptr)), EG_ERR_BAD_ARG, "eg_kld: bad argument");
     hipLaunchKernelGGL(kld_kernel, dim3(1), dim3(256), 0, ST, mu, logvar, dmu, dlogvar, loss, n, d, scale);
     return eg_check_launch("kld");
+}
+
+extern "C" int eg_counter_add(int32_t* counter, int32_t delta, void* stream) {
+    EG_REQUIRE(counter, EG_ERR_BAD_ARG, "eg_counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ST, counter, delta);
+    return eg_check_launch("counter_add");
+}
+extern "C" int eg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, const int32_t* step_dev, void* stream) {
+    EG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev, EG_ERR_BAD_ARG, "eg_adam_step_dev: bad argument");
+    hipLaunchKernelGGL(adam_dev_kernel, grid1((size_t)n, 16384), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps,
+                       weight_decay, step_dev);
+    return eg_check_launch("adam_step_dev");
 }
 
 extern "C" int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,

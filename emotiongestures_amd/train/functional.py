@@ -154,7 +154,7 @@ def raw_ew(op, a, b=None, s=0.0):
     return y
 
 
-EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY, EW_EXP = range(11)
+EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY, EW_EXP, EW_SCALE_DEV = range(12)
 
 
 def raw_linear_backward(x, w, dy, need_dx=True):
@@ -756,10 +756,8 @@ class _KLD(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dm, dl = ctx.saved_tensors
-        s = float(g.reshape(-1)[0])
-        if s != 1.0:
-            dm, dl = raw_ew(EW_SCALE, dm, None, s), raw_ew(EW_SCALE, dl, None, s)
-        return dm, dl, None
+        gs = _chk(g).reshape(-1)            # the incoming scalar stays on the device (no host read-back: keeps the launch queue running ahead)
+        return raw_ew(EW_SCALE_DEV, dm, gs), raw_ew(EW_SCALE_DEV, dl, gs), None
 
 
 def kld_loss(mu, logvar, scale=1.0):
@@ -782,8 +780,7 @@ class _SmoothL1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        s = float(g.reshape(-1)[0])
-        return (dp if s == 1.0 else raw_ew(EW_SCALE, dp, None, s)), None, None, None
+        return raw_ew(EW_SCALE_DEV, dp, _chk(g).reshape(-1)), None, None, None
 
 
 def smooth_l1_loss(pred, target, beta=1.0, scale=1.0):
@@ -810,8 +807,7 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
-        s = float(g.reshape(-1)[0])
-        return (dz if s == 1.0 else raw_ew(EW_SCALE, dz, None, s)), None, None, None, None
+        return raw_ew(EW_SCALE_DEV, dz, _chk(g).reshape(-1)), None, None, None, None
 
 
 def cross_entropy(logits, labels, scale=1.0):

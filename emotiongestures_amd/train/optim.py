@@ -81,6 +81,12 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(fp.flat)
         self.exp_avg_sq = torch.zeros_like(fp.flat)
         self.t = 0
+        self.step_dev = None        # device-resident step count (train/graph.py: steps replayed from a captured hipGraph)
+
+    def use_device_step(self):
+        """Keep the step count on the device from now on: `step()` increments it with a kernel and the update reads it there."""
+        if self.step_dev is None:
+            self.step_dev = torch.tensor([self.t], dtype=torch.int32, device=self.fp.flat.device)
 
     def step(self, collected: bool = False):
         fp = self.fp
@@ -88,6 +94,8 @@ class FlatAdam:
             fp.collect()
         self.t += 1
         lib = L.load()
+        if self.step_dev is not None:
+            L.check(lib.eg_counter_add(_ptr(self.step_dev), 1, _stream(fp.flat.device)), "eg_counter_add")
         # torch.optim.Adam skips parameters whose .grad is None (no weight decay, no moment update): one launch per contiguous
         # run of parameters that did receive a gradient (a handful: the text branch / unused decoder self-attention are skipped)
         runs, lo = [], None
@@ -104,6 +112,11 @@ class FlatAdam:
         for lo, hi in runs:
             hi = min(hi, fp.flat.numel())
             sl = slice(lo, hi)
+            if self.step_dev is not None:
+                L.check(lib.eg_adam_step_dev(_ptr(fp.flat[sl]), _ptr(fp.grad[sl]), _ptr(self.exp_avg[sl]), _ptr(self.exp_avg_sq[sl]), hi - lo,
+                                             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                             _ptr(self.step_dev), _stream(fp.flat.device)), "eg_adam_step_dev")
+                continue
             L.check(lib.eg_adam_step(_ptr(fp.flat[sl]), _ptr(fp.grad[sl]), _ptr(self.exp_avg[sl]), _ptr(self.exp_avg_sq[sl]), hi - lo,
                                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                      self.t, _stream(fp.flat.device)), "eg_adam_step")

@@ -407,7 +407,7 @@ int eg_se_tail_backward_apply(const float* dout, const float* out, const float* 
                               int32_t hw, int32_t c, void* stream);
 /* o0[c] = sum_r a[r,c]; o1[c] = sum_r a[r,c]*b[r,c] (b NULL: sum a^2).  bias / LayerNorm affine gradients. */
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
-/* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) */
+/* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) | 11 a*b[0] */
 int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream);
 /* The same weight gradient for stride 1 on the split-bf16 matrix pipe (x and dy split to hi/lo bf16 while staged, 3 MFMA terms, fp32
  * accumulation, fixed-order partial sums): cin % 32 == 0, cout % 32 == 0.  workspace >= eg_conv3x3_wgrad_mfma_workspace_floats(...). */
@@ -449,6 +449,11 @@ int eg_kld(const float* mu, const float* logvar, float* loss, float* dmu, float*
 /* torch.optim.Adam step on a flat buffer (L2 weight decay added to the gradient; train_audio_classifier_K_fold.py:128) */
 int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, void* stream);
+/* The same update with the (1-based) step count read from device memory, and the counter's increment, for steps replayed from a captured
+ * hipGraph (host scalars are frozen at capture). */
+int eg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, const int32_t* step_dev, void* stream);
+int eg_counter_add(int32_t* counter, int32_t delta, void* stream);
 
 #ifdef __cplusplus
 }

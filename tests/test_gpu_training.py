@@ -570,3 +570,44 @@ def test_device_linear_weight_image_matches_host_packer_bitwise():
         host_t = torch.from_numpy(_pack_linear(w.t().contiguous(), (k + 63) // 64 * 64, (n + 63) // 64 * 64).view(np.float32).reshape(-1))
         img_t, ldw_t = F._pack_linear(w.to(DEV), transpose=True)
         assert ldw_t == (n + 63) // 64 * 64 and torch.equal(host_t.view(torch.int32), img_t.cpu().view(torch.int32)), (n, k, "T")
+
+
+def test_graphed_training_step_replays_the_eager_step():
+    """train/graph.py: forward + backward + gradient collection + Adam captured as one hipGraph.  After the same number of steps on the
+    same inputs the parameters, Adam moments and BatchNorm running statistics agree with the eager loop (the kernels are the same and
+    deterministic; only Adam's bias correction is computed on the device instead of the host)."""
+    import copy
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.graph import GraphedStep
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    inp = synth_inputs(2, 34, 126, 4, seed=9)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    label = torch.tensor([3, 5], device=DEV)
+    results = []
+    for graphed in (False, True):
+        model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+        fp = flatten_parameters(model)
+        opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+
+        def step(_inputs=None):
+            opt.zero_grad()
+            pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+            loss = F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, label))
+            loss.backward()
+            opt.step()
+            return loss
+
+        if graphed:
+            gs = GraphedStep(step, g, opt, warmup=2)
+            losses = [float(gs.run()) for _ in range(3)]
+        else:
+            losses = [float(step().detach()) for _ in range(5)][2:]
+        assert opt.t == 5
+        results.append((losses, fp.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                        model.audio_encoder.feat_extractor.layer2[0].bn2.running_var.clone(),
+                        int(model.audio_encoder.feat_extractor.bn1.num_batches_tracked)))
+    (l0, p0, m0, v0, rv0, nb0), (l1, p1, m1, v1, rv1, nb1) = results
+    assert nb0 == nb1 == 5
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    assert rel(p1, p0) < 1e-6 and rel(m1, m0) < 1e-5 and rel(v1, v0) < 1e-5 and rel(rv1, rv0) < 1e-6
