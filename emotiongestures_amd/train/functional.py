@@ -48,6 +48,17 @@ def _chk(t: torch.Tensor, name="tensor") -> torch.Tensor:
     return t.contiguous()
 
 
+def grad_out(param, shape=None) -> torch.Tensor:
+    """Where a backward kernel writes the gradient of `param`: its slice of the flat gradient buffer (optim.flatten_parameters) when it has
+    one that nothing wrote yet this step -- autograd then adopts that view as .grad and the collection copy disappears -- else fresh memory
+    (first use wins; a second use of a shared parameter is accumulated by autograd as usual)."""
+    slot = getattr(param, "_eg_slot", None)
+    if slot is not None and id(param) not in param._eg_fp.written:
+        param._eg_fp.written.add(id(param))
+        return slot.view(shape if shape is not None else slot.shape)        # a new view object: autograd may take it over without cloning
+    return torch.empty(shape if shape is not None else param.shape, dtype=torch.float32, device=param.device)
+
+
 def _scratch(dev, floats: int, tag="ws") -> torch.Tensor:
     """Reusable scratch (partials of split-K / column reductions).  Stream-ordered use only."""
     key = (str(dev), tag)
@@ -137,12 +148,12 @@ def raw_gemm_tn(a, b, out=None, accumulate=False):
     return c
 
 
-def raw_colsum(a, b=None, want0=True, want1=False):
+def raw_colsum(a, b=None, want0=True, want1=False, out0=None, out1=None):
     lib = _lib()
     rows, c = a.shape
     ws = _scratch(a.device, lib.eg_colreduce_workspace_floats(c), "col")
-    o0 = torch.empty(c, dtype=torch.float32, device=a.device) if want0 else None
-    o1 = torch.empty(c, dtype=torch.float32, device=a.device) if want1 else None
+    o0 = (out0 if out0 is not None else torch.empty(c, dtype=torch.float32, device=a.device)) if want0 else None
+    o1 = (out1 if out1 is not None else torch.empty(c, dtype=torch.float32, device=a.device)) if want1 else None
     L.check(lib.eg_colsum(_ptr(a), _ptr(b), _ptr(o0), _ptr(o1), rows, c, _ptr(ws), _stream(a.device)), "eg_colsum")
     return o0, o1
 
@@ -157,10 +168,10 @@ def raw_ew(op, a, b=None, s=0.0):
 EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY, EW_EXP, EW_SCALE_DEV = range(12)
 
 
-def raw_linear_backward(x, w, dy, need_dx=True):
-    """dx = dy w;  dw = dy^T x;  db = colsum(dy)"""
-    dw = raw_gemm_tn(dy, x)
-    db, _ = raw_colsum(dy)
+def raw_linear_backward(x, w, dy, need_dx=True, w_param=None, b_param=None):
+    """dx = dy w;  dw = dy^T x;  db = colsum(dy).  w_param / b_param: the parameters themselves (gradients go to their flat slices)."""
+    dw = raw_gemm_tn(dy, x, out=grad_out(w_param) if w_param is not None and x.shape[1] == w.shape[1] else None)
+    db, _ = raw_colsum(dy, out0=grad_out(b_param) if b_param is not None else None)
     dx = raw_linear(dy, w, w_transposed=True) if need_dx else None      # [M,N] x [N,K]
     return dx, dw, db
 
@@ -175,6 +186,7 @@ class _Linear(torch.autograd.Function):
         y = raw_linear(x2, wd, _chk(b) if b is not None else None, relu)
         ctx.save_for_backward(x2, wd, y if relu else None)
         ctx.has_b, ctx.xs, ctx.need_dx = b is not None, xs, x.requires_grad
+        ctx.params = (w, b)
         return y.view(*xs[:-1], wd.shape[0])
 
     @staticmethod
@@ -183,7 +195,7 @@ class _Linear(torch.autograd.Function):
         dy2 = _chk(dy).reshape(-1, w.shape[0])
         if y is not None:
             dy2 = raw_ew(EW_RELU_BWD, dy2, y)
-        dx, dw, db = raw_linear_backward(x2, w, dy2, ctx.need_dx)
+        dx, dw, db = raw_linear_backward(x2, w, dy2, ctx.need_dx, ctx.params[0], ctx.params[1] if ctx.has_b else None)
         return (dx.view(ctx.xs) if dx is not None else None), dw, (db if ctx.has_b else None), None
 
 
@@ -334,6 +346,7 @@ class _Conv3x3(torch.autograd.Function):
             raise ValueError("conv3x3(want_gap=True): only the NHWC tower convolutions (Cin % 32 == 0, Cout % 4 == 0) emit pooling partials")
         ctx.save_for_backward(xd, wd, y if (relu and not defer_mask) else None)      # defer_mask: the consumer (batch_norm(relu_input=True)) applies it
         ctx.stride, ctx.has_b, ctx.need_dx = stride, b is not None, x.requires_grad
+        ctx.params = (w, b)
         if want_gap:
             ctx.mark_non_differentiable(gap)
             return y, gap
@@ -366,8 +379,9 @@ class _Conv3x3(torch.autograd.Function):
             col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
             L.check(lib.eg_im2col3x3(_ptr(x), _ptr(col), B, H, W, Ci, ctx.stride, 0, _stream(dev)), "eg_im2col3x3")
             dwm = raw_gemm_tn(dy2, col)                                     # [Co, (kh,kw,ci)]
-        dw = dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
-        db = raw_colsum(dy2)[0] if ctx.has_b else None
+        dw = grad_out(ctx.params[0], (Co, Ci, 3, 3))
+        dw.copy_(dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2))               # (kh, kw, ci) -> OIHW, straight into the flat gradient slice
+        db = raw_colsum(dy2, out0=grad_out(ctx.params[1]))[0] if ctx.has_b else None
         dx = None
         if ctx.need_dx and ctx.stride == 1 and Ci == Co and Ci % 32 == 0:
             # input gradient of a square stride-1 conv = the forward kernel on the 180-degree rotated, transposed filter
@@ -439,6 +453,7 @@ class _BatchNorm(torch.autograd.Function):
                                             float(momentum), float(eps), _ptr(ws), _stream(dev)), "eg_bn_train_forward")
         ctx.save_for_backward(xd, g, mean, rstd)
         ctx.relu_input = bool(relu_input)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -449,7 +464,7 @@ class _BatchNorm(torch.autograd.Function):
         rows = x.numel() // Cc
         dev = x.device
         dyd = _chk(dy)
-        dx, dg, db = torch.empty_like(x), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        dx, dg, db = torch.empty_like(x), grad_out(ctx.params[0]), grad_out(ctx.params[1])
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
         L.check(lib.eg_bn_train_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, Cc, int(ctx.relu_input),
                                          _ptr(ws), _stream(dev)), "eg_bn_train_backward")
@@ -486,6 +501,7 @@ class _SEBlockTail(torch.autograd.Function):
         out = torch.empty_like(x)
         L.check(lib.eg_se_tail_forward(_ptr(x), _ptr(r), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(out), B, hw, Cc, st), "eg_se_tail_forward")
         ctx.save_for_backward(x, out, mean, rstd, clip, pooled, h, gate, g, bt, w1d, w2d)
+        ctx.params = (gamma, beta, w1, b1, w2, b2)
         return out
 
     @staticmethod
@@ -504,9 +520,8 @@ class _SEBlockTail(torch.autograd.Function):
                 "eg_se_tail_backward_reduce")
         L.check(lib.eg_se_gate_train_backward(_ptr(s1), _ptr(s2), _ptr(clip), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(h), _ptr(w1), _ptr(w2),
                                               _ptr(dz2), _ptr(dz1), _ptr(dgap), _ptr(u1), _ptr(u2), B, hw, Cc, st), "eg_se_gate_train_backward")
-        vec = torch.empty(5, Cc, device=dev)                                        # dgamma, dbeta, m1, m2, db2
-        dg, db, m1, m2, db2 = vec.unbind(0)
-        dw1, db1, dw2 = torch.empty(Ch, Cc, device=dev), torch.empty(Ch, device=dev), torch.empty(Cc, Ch, device=dev)
+        m1, m2 = torch.empty(2, Cc, device=dev).unbind(0)
+        dg, db, dw1, db1, dw2, db2 = (grad_out(p) for p in ctx.params)
         L.check(lib.eg_se_tail_backward_finish(_ptr(u1), _ptr(u2), _ptr(dz2), _ptr(dz1), _ptr(h), _ptr(pooled), _ptr(dg), _ptr(db), _ptr(m1), _ptr(m2),
                                                _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), B, hw, Cc, st), "eg_se_tail_backward_finish")
         dc2, dres = torch.empty_like(x), torch.empty_like(x)
@@ -576,6 +591,7 @@ class _LayerNorm(torch.autograd.Function):
         L.check(lib.eg_layernorm(_ptr(xd), _ptr(gd), _ptr(bd), _ptr(y), rows, D, float(eps), _stream(xd.device)), "eg_layernorm")
         ctx.save_for_backward(xd, gd)
         ctx.eps = eps
+        ctx.params = (g, b)
         return y
 
     @staticmethod
@@ -588,8 +604,8 @@ class _LayerNorm(torch.autograd.Function):
         dx, t = torch.empty_like(x), torch.empty_like(x)
         L.check(lib.eg_layernorm_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(dx), _ptr(t), rows, D, float(ctx.eps), _stream(x.device)),
                 "eg_layernorm_backward")
-        dg, _ = raw_colsum(t.view(rows, D))
-        db, _ = raw_colsum(dyd.view(rows, D))
+        dg, _ = raw_colsum(t.view(rows, D), out0=grad_out(ctx.params[0]))
+        db, _ = raw_colsum(dyd.view(rows, D), out0=grad_out(ctx.params[1]))
         return dx, dg, db, None
 
 

@@ -26,12 +26,17 @@ class FlatParams:
         self.params, self.flat, self.grad, self.offsets = params, flat, grad, offsets
         self.index = {id(p): i for i, p in enumerate(params)}
         self.has_grad = [False] * len(params)       # set by collect_one: parameters autograd produced a gradient for
+        self.written = set()                        # parameters whose flat gradient slice a backward kernel already wrote this step
+        for p, o in zip(params, offsets):           # the operators of train/functional.py write weight gradients straight into these slices
+            p._eg_slot = grad[o:o + p.numel()].view(p.shape)
+            p._eg_fp = self
 
     def zero_grad(self):
         """Gradients start from None: autograd then hands each parameter a fresh gradient tensor (no torch add into an old one);
         `collect` / the bucket hooks copy it into the flat buffer."""
         for p in self.params:
             p.grad = None
+        self.written.clear()
 
     def collect_one(self, p: torch.nn.Parameter):
         o = self.offsets[self.index[id(p)]]

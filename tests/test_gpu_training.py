@@ -611,3 +611,28 @@ def test_graphed_training_step_replays_the_eager_step():
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
     assert rel(p1, p0) < 1e-6 and rel(m1, m0) < 1e-5 and rel(v1, v0) < 1e-5 and rel(rv1, rv0) < 1e-6
+
+
+def test_weight_gradients_land_in_the_flat_buffer_without_a_copy():
+    """After flatten_parameters the backward kernels write Linear / conv / BatchNorm / LayerNorm / SE gradients straight into the flat
+    gradient buffer: autograd adopts those views as .grad (same address), and the values equal the unflattened model's gradients."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.optim import flatten_parameters
+    inp = synth_inputs(2, 34, 126, 4, seed=3)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    grads = []
+    for flat in (False, True):
+        model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+        fp = flatten_parameters(model) if flat else None
+        pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+        loss = F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, torch.tensor([1, 2], device=DEV)))
+        loss.backward()
+        if flat:
+            in_place = sum(1 for p, o in zip(fp.params, fp.offsets) if p.grad is not None and p.grad.data_ptr() == fp.grad[o:].data_ptr())
+            with_grad = sum(1 for p in fp.params if p.grad is not None)
+            assert in_place >= 0.9 * with_grad, (in_place, with_grad)
+            fp.collect()
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
