@@ -170,7 +170,7 @@ def self_launch(n):
     dry = os.environ.get("EG_BENCH_DRY") == "1"          # CPU test of this launcher (tests/test_bench_launcher.py)
     if not dry:
         ndev = torch.cuda.device_count()
-        if ndev < n:
+        if ndev < n and os.environ.get("EG_BENCH_BACKEND", "nccl") == "nccl":       # gloo: the one-GPU test of the data-parallel path shares the device
             raise SystemExit(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible; refusing to oversubscribe")
     port = _free_port()
     procs = []
@@ -237,7 +237,8 @@ def train_worker(args, rank, world, dev, dist, backend):
         loss.backward()
         if not timed:                   # inside a stream capture: no timing events
             gb.finish()
-            opt.step(collected=True)
+            if world == 1:
+                opt.step(collected=True)
             return loss
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -249,9 +250,18 @@ def train_worker(args, rank, world, dev, dist, backend):
 
     if args.train_graph:
         from emotiongestures_amd.train.graph import GraphedStep
-        gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, args.warmup))
-        eager_step = step
-        step = lambda: gs.run()         # noqa: E731
+        if world == 1:
+            gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, args.warmup))
+            step = lambda: gs.run()         # noqa: E731
+        else:                           # data parallel: forward + backward + collection replayed, the collective and Adam issued after it
+            gb.deferred = True
+            gs = GraphedStep(lambda _inputs: step(timed=False), g, None, warmup=max(1, args.warmup), device=dev)
+
+            def step():                 # noqa: F811
+                loss = gs.run()
+                gb.reduce_deferred()
+                opt.step(collected=True)
+                return loss
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -19,16 +19,20 @@ from .optim import FlatAdam
 
 
 class GraphedStep:
-    def __init__(self, step_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], inputs: Dict[str, torch.Tensor], optimizer: FlatAdam, warmup: int = 3):
-        """step_fn(inputs) runs zero_grad, forward, backward, the gradient collection and optimizer.step(), and returns the loss tensor.
-        `inputs` are the static device tensors the captured graph reads; `run(new_inputs)` copies fresh values into them."""
-        dev = optimizer.fp.flat.device
+    def __init__(self, step_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], inputs: Dict[str, torch.Tensor], optimizer: FlatAdam = None,
+                 warmup: int = 3, device=None):
+        """step_fn(inputs) runs zero_grad, forward, backward, the gradient collection and -- when `optimizer` is given -- optimizer.step(),
+        and returns the loss tensor.  `inputs` are the static device tensors the captured graph reads; `run(new_inputs)` copies fresh
+        values into them.  Data parallel: capture forward + backward + collection only (optimizer=None, GradBuckets.deferred = True) and run
+        `GradBuckets.reduce_deferred()` and the optimiser after each replay -- the collective stays outside the captured graph."""
+        dev = optimizer.fp.flat.device if optimizer is not None else torch.device(device)
         if dev.type != "cuda":
             raise L.EgError("GraphedStep: needs a GPU")
         if nets._P["on"]:
             raise L.EgError("GraphedStep: stochastic dropout keeps its mask counter on the host and cannot be captured")
         self.inputs, self.opt = inputs, optimizer
-        optimizer.use_device_step()
+        if optimizer is not None:
+            optimizer.use_device_step()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):               # warm-up off the capture: lazily sized scratch buffers, kernel attributes, autograd state
@@ -39,12 +43,14 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = step_fn(inputs)
-        optimizer.t -= 1                            # the capture recorded a step without executing it
+        if optimizer is not None:
+            optimizer.t -= 1                        # the capture recorded a step without executing it
 
     def run(self, new_inputs: Dict[str, torch.Tensor] = None) -> torch.Tensor:
         if new_inputs:
             for k, v in new_inputs.items():
                 self.inputs[k].copy_(v, non_blocking=True)
         self.graph.replay()
-        self.opt.t += 1
+        if self.opt is not None:
+            self.opt.t += 1
         return self.loss

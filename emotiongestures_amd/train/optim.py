@@ -155,6 +155,7 @@ class GradBuckets:
         self._handles = []
         self._unused: Optional[set] = None      # parameters that received no gradient in the first backward (static graph)
         self.launched: List[int] = []           # bucket launch order of the last backward (tests)
+        self.deferred = False                   # True: the hooks only collect (a captured hipGraph holds forward + backward); reduce_deferred() follows the replay
 
     def bucket_of(self, offset: int) -> int:
         for i, (lo, hi) in enumerate(self.buckets):
@@ -196,7 +197,7 @@ class GradBuckets:
     def _launch(self, b):
         import torch.distributed as dist
         self.launched.append(b)
-        if self.world == 1:
+        if self.world == 1 or self.deferred:
             return
         lo, hi = self.buckets[b]
         g = self.fp.grad[lo:hi]
@@ -224,6 +225,15 @@ class GradBuckets:
         if self.stream is not None:
             torch.cuda.current_stream(self.fp.grad.device).wait_stream(self.stream)
         self._pending = None
+        if not self.deferred:
+            self._scale()
+
+    def reduce_deferred(self):
+        """After a replayed forward + backward (deferred mode): the bucket all-reduces in backward order on the caller's stream, then 1/world."""
+        import torch.distributed as dist
+        if self.world > 1:
+            for lo, hi in self.buckets:
+                dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         self._scale()
 
     # ---- simple mode: everything after backward ----

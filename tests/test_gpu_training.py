@@ -636,3 +636,18 @@ def test_weight_gradients_land_in_the_flat_buffer_without_a_copy():
     assert grads[0].keys() == grads[1].keys()
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_train_two_ranks_share_one_gpu_over_gloo(graph):
+    """`bench.py --gpus 2 --train` end to end on the GPU kernels with two ranks (both on this box's one GPU, gloo instead of RCCL): the
+    launcher, the gradient buckets (eager: launched from backward order; --train-graph: deferred behind the replayed forward + backward),
+    the averaged gradient and the Adam step; the line reports n_gpus 2 and a finite loss."""
+    import json, os, subprocess, sys
+    env = dict(os.environ, EG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--train", "--train-batch", "2", "--steps", "2", "--warmup", "1"] + (["--train-graph"] if graph else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and np.isfinite(line["final_loss"])
+    assert ("hipGraph" in line["launch"]) == graph
