@@ -149,10 +149,11 @@ def parse_args():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]: one step = generator forward + 100*smooth_l1 + CE + backward + bucketed gradient "
                          "all-reduce (RCCL) + fused Adam on --train-batch clips per GPU (fp32 operators)")
-    ap.add_argument("--train-precision", choices=("f32", "bf16x3"), default="f32",
-                    help="--train: arithmetic of the 3x3 convolutions (forward + input gradient); f32 is the gradient-parity configuration")
-    ap.add_argument("--train-graph", action="store_true",
-                    help="--train: capture the whole step (forward, backward, gradient collection, Adam) as one hipGraph and replay it")
+    ap.add_argument("--train-precision", choices=("f32", "bf16x3"), default="bf16x3",
+                    help="--train: arithmetic of the convolutions and Linear products; f32 is the gradient-parity configuration (always timed as the f32_eager leg)")
+    ap.add_argument("--no-train-graph", action="store_true",
+                    help="--train: issue every kernel through autograd instead of replaying the step from one captured hipGraph")
+    ap.add_argument("--train-graph", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--train-batch", type=int, default=16, help="clips per GPU per training step (16 = global 128 on 8 GPUs, SURVEY.md §8d cfg 3)")
     return ap.parse_args()
 
@@ -202,66 +203,21 @@ def dry_worker(args, rank, world):
 
 
 def train_worker(args, rank, world, dev, dist, backend):
-    """--train: data-parallel training step of the generator (SURVEY.md §8d cfg 3, §8e): every rank its own synthetic clips,
-    gradients averaged with bucketed all-reduces launched from backward order on a side stream (emotiongestures_amd/train/optim.py)."""
+    """--train: data-parallel training step of the generator + emotion CVAE (SURVEY.md §8d cfg 3, §8e): every rank its own synthetic
+    clips, gradients averaged with bucketed all-reduces (emotiongestures_amd/train/optim.py).  The reported leg runs the arithmetic and
+    launch mode the flags name (default: split-bf16 MFMA, the step replayed from one captured hipGraph); `f32_eager` is the
+    gradient-parity configuration (fp32 operators issued through autograd) timed in the same run."""
     from emotiongestures_amd.builders import build_mirror
-    from emotiongestures_amd.synth import hash_unit, synth_inputs
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.synth import hash_unit, load_synth_weights, synth_inputs
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
     B = args.train_batch
-    F.set_precision(args.train_precision)
-    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
-    from emotiongestures_amd.synth import load_synth_weights
-    model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
-    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
-    both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
-    fp = flatten_parameters(both)
-    opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
-    gb = GradBuckets(fp, bucket_mb=25.0).attach()
     inp = synth_inputs(B, 34, 126, 4, seed=2000 + rank)
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     target = torch.from_numpy((hash_unit("train.target_pose", B * 34 * 126, 2000 + rank) - 0.5).astype(np.float32).reshape(B, 34, 126)).to(dev)
     label = g["label"].argmax(1)
     eps = torch.from_numpy(synth_inputs(B, seed=3000 + rank)["z"]).to(dev)
-    ar_ms = []
-
-    def step(timed=True):
-        opt.zero_grad()
-        gb.begin()
-        pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
-        # the emotion CVAE learns to reconstruct the generator's emotion feature map under the clip's label (its eval-time role:
-        # sample(label) replaces that map, test_emotion_gesture_diversity_iterative.py:203-205)
-        rec, mu, logvar = vae(emo.detach(), g["label"], eps)
-        loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
-                     F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
-        loss.backward()
-        if not timed:                   # inside a stream capture: no timing events
-            gb.finish()
-            if world == 1:
-                opt.step(collected=True)
-            return loss
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        gb.finish()                     # waits for the bucket all-reduces still running behind backward: the EXPOSED part
-        e1.record()
-        opt.step(collected=True)
-        ar_ms.append((e0, e1))
-        return loss
-
-    if args.train_graph:
-        from emotiongestures_amd.train.graph import GraphedStep
-        if world == 1:
-            gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, args.warmup))
-            step = lambda: gs.run()         # noqa: E731
-        else:                           # data parallel: forward + backward + collection replayed, the collective and Adam issued after it
-            gb.deferred = True
-            gs = GraphedStep(lambda _inputs: step(timed=False), g, None, warmup=max(1, args.warmup), device=dev)
-
-            def step():                 # noqa: F811
-                loss = gs.run()
-                gb.reduce_deferred()
-                opt.step(collected=True)
-                return loss
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -269,34 +225,98 @@ def train_worker(args, rank, world, dev, dist, backend):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(1, args.warmup)):
-        loss = step()
-    barrier()
-    ar_ms.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms])) if ar_ms else None
+    def leg(precision, graph):
+        F.set_precision(precision)
+        model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
+        vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
+        both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
+        fp = flatten_parameters(both)
+        opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
+        gb = GradBuckets(fp, bucket_mb=25.0).attach()
+        ar_ms = []
+
+        def step(timed=True):
+            opt.zero_grad()
+            gb.begin()
+            pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+            # the emotion CVAE learns to reconstruct the generator's emotion feature map under the clip's label (its eval-time role:
+            # sample(label) replaces that map, test_emotion_gesture_diversity_iterative.py:203-205)
+            rec, mu, logvar = vae(emo.detach(), g["label"], eps)
+            loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
+                         F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
+            loss.backward()
+            if not timed:                   # inside a stream capture: no timing events
+                gb.finish()
+                if world == 1:
+                    opt.step(collected=True)
+                return loss
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gb.finish()                     # waits for the bucket all-reduces still running behind backward: the EXPOSED part
+            e1.record()
+            opt.step(collected=True)
+            ar_ms.append((e0, e1))
+            return loss
+
+        run = step
+        if graph:
+            from emotiongestures_amd.train.graph import GraphedStep
+            if world == 1:
+                gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, args.warmup))
+                run = gs.run
+            else:                           # data parallel: forward + backward + collection replayed, the collective and Adam issued after it
+                gb.deferred = True
+                gs = GraphedStep(lambda _inputs: step(timed=False), g, None, warmup=max(1, args.warmup), device=dev)
+
+                def run():
+                    loss = gs.run()
+                    gb.reduce_deferred()
+                    opt.step(collected=True)
+                    return loss
+
+        for _ in range(max(1, args.warmup)):
+            loss = run()
+        barrier()
+        ar_ms.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = run()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms])) if ar_ms else None
+        out = {"value": round(B * world * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": precision,
+               "launch": "one captured hipGraph per step" if graph else "eager (autograd issues every kernel)", "final_loss": float(loss.detach()),
+               "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
+               "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
+        F.set_precision("f32")
+        return out
+
+    main_leg = leg(args.train_precision, not args.no_train_graph)
+    parity = None
+    if not args.no_extra_legs and (args.train_precision != "f32" or not args.no_train_graph):
+        parity = leg("f32", False)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        nparam = int(sum(p.numel() for p in fp.params))
-        print(json.dumps({
-            "metric": "training clips/sec (generator + emotion CVAE: forward + backward + all-reduce + Adam)", "value": round(B * world * args.steps / el, 2),
-            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_precision, "data": "synthetic",
+        nparam = main_leg.pop("trainable_parameters")
+        nb = main_leg.pop("buckets")
+        line = {
+            "metric": "training clips/sec (generator + emotion CVAE: forward + backward + all-reduce + Adam)", "value": main_leg["value"],
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_leg["dtype"], "data": "synthetic",
             "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
-                       "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": len(gb.buckets)},
-            "final_loss": float(loss.detach()), "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
-            "launch": "one captured hipGraph per step" if args.train_graph else "eager (autograd issues every kernel)"}))
+                       "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": nb},
+            "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"], "launch": main_leg["launch"]}
+        if parity is not None:
+            parity.pop("trainable_parameters"); parity.pop("buckets")
+            line["f32_eager"] = parity
+        print(json.dumps(line))
     return 0
 
 

@@ -645,7 +645,7 @@ def test_bench_train_two_ranks_share_one_gpu_over_gloo(graph):
     the averaged gradient and the Adam step; the line reports n_gpus 2 and a finite loss."""
     import json, os, subprocess, sys
     env = dict(os.environ, EG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--train", "--train-batch", "2", "--steps", "2", "--warmup", "1"] + (["--train-graph"] if graph else [])
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--train", "--train-batch", "2", "--steps", "2", "--warmup", "1", "--no-extra-legs"] + ([] if graph else ["--no-train-graph"])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
