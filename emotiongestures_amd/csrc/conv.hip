@@ -16,7 +16,8 @@
 #include "common.h"
 
 // (Measured and dropped in round 1: s_setprio around the MFMA cluster costs 20-50 % here -- hipcc stops interleaving the LDS
-//  reads; a persistent 32->32 kernel with register-resident weights was 35 % slower than the tiled one.)
+//  reads; a persistent 32->32 kernel with register-resident weights was 35 % slower than the tiled one.  Round 2's persistent 32->32
+//  kernel below keeps the weights in LDS and the next tile's pixels in registers instead.)
 
 namespace {
 
@@ -469,6 +470,230 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     }
 }
 
+// ---- 32 -> 32 channels, stride 1: persistent variant (the HBM-bound first stage) -------------------------------------------------
+// The tiled kernel above gives a 32-channel workgroup 108 MFMAs per wave between a cold halo load and its stores: its lifetime is
+// almost all memory latency, hidden only by co-resident workgroups (3.3-3.8 TB/s).  Here a workgroup walks a run of consecutive
+// 4 x 32-pixel tiles: all 9 taps' weights (36 KB of hi/lo images) are copied to LDS once, the NEXT tile's halo pixels (and this tile's
+// residual, for the fused SE tail) are in flight in registers while the 9 taps of the current tile run, and the taps need no barrier
+// (weights and tile are static): two barriers per tile instead of ten.  Same arithmetic and summation order as the tiled kernel.
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs a, const bf8* __restrict__ whi, const bf8* __restrict__ wlo,
+                                                                     int total_tiles, int tiles_per_wg) {
+    using G = ConvGeom<1, 4>;
+    constexpr int CIN = 32, IW = G::IW, NPIX = G::NPIX, PL = G::PL, MT = 2, NT = 2;
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr int TILE = NIMG * 4 * PL, WTAP = 4 * 32, WIMG = 9 * WTAP;
+    extern __shared__ __attribute__((aligned(16))) bf8 lds[];      // tile | weights (hi [tap][octet][co], lo) | gap scratch
+    bf8* tile = lds;
+    bf8* wl = lds + TILE;
+    float* sred = reinterpret_cast<float*>(lds + TILE + NIMG * WIMG);       // [4 waves][32]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; XCD k walks a contiguous eighth of the tile list
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int t_begin = wg * tiles_per_wg, t_end = min(total_tiles, t_begin + tiles_per_wg);
+    if (t_begin >= t_end) return;
+
+    // all weights -> LDS, once: NIMG x 18 pieces of 64 slots, dealt round-robin to the 4 waves
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img) {
+        const bf8* src = img ? wlo : whi;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int piece = p * 4 + wave_u;
+            if (piece < WIMG / 64)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(wl + img * WIMG + piece * 64), 16, 0, 0);
+        }
+    }
+
+    // staging roles (tile independent): pixel p of the 6 x 34 halo tile, channel octet oc
+    constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;
+    int piy[NIT], pix[NIT], lslot[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int p = (idx >> 5) * 8 + (idx & 7), oc = (idx >> 3) & 3;
+        piy[it] = p / IW;
+        pix[it] = p - piy[it] * IW;
+        lslot[it] = p < NPIX ? oc * PL + p : -1;
+    }
+    const int oc8 = ((tid >> 3) & 3) * 8;
+    f4 pv[NIT][2];
+    auto load_tile = [&](int L) {
+        const int b = L / a.tiles, tile_id = L - b * a.tiles;
+        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
+        const int iy0 = ty * 4 - 1, ix0 = tx * 32 - 1;
+        const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            pv[it][0] = pv[it][1] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int gy = iy0 + piy[it], gx = ix0 + pix[it];
+            if (lslot[it] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const float* src = xb + (gy * a.W + gx) * CIN + oc8;
+                pv[it][0] = *reinterpret_cast<const f4*>(src);
+                pv[it][1] = *reinterpret_cast<const f4*>(src + 4);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (lslot[it] >= 0) {
+                bf8 hi, lo;
+                split_octet<TERMS == 3>(pv[it][0], pv[it][1], hi, lo);
+                tile[lslot[it]] = hi;
+                if (TERMS == 3) tile[4 * PL + lslot[it]] = lo;
+            }
+        }
+    };
+    int pbase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int id = wave * MT + t;
+        pbase[t] = (id >> 1) * IW + (id & 1) * 16 + li;
+    }
+    // (Keeping the hi weight fragments of all 9 taps in registers -- 72 VGPRs, a quarter less LDS fragment traffic -- measured no faster
+    //  in the step and 7 % slower alone: the fragment reads are not what bounds this kernel.)
+    struct Frags { bf8 wh[NT], wlf[NT], xh[MT], xl[MT]; };
+    auto read_frags = [&](Frags& f, int tap) {
+        const bf8* Wh = wl + tap * WTAP + kq * 32 + li;
+        const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f.wh[n] = Wh[n * 16];
+            if (TERMS == 3) f.wlf[n] = Wh[WIMG + n * 16];
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            f.xh[t] = tile[kq * PL + pbase[t] + toff];
+            if (TERMS == 3) f.xl[t] = tile[(4 + kq) * PL + pbase[t] + toff];
+        }
+    };
+
+    const int hw = a.Ho * a.Wo;
+    // channel-wise epilogue constants of this lane's 2 x 4 output channels
+    f4 bi[NT], sc[NT], sh[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + kq * 4;
+        bi[n] = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
+        sc[n] = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
+        sh[n] = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    f4 rsn[MT][NT];
+    auto load_res = [&](int L) {
+        const int b = L / a.tiles, tile_id = L - b * a.tiles;
+        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
+        const float* __restrict__ rb = a.res ? a.res + (size_t)b * hw * 32 : nullptr;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int id = wave * MT + t;
+            const int oy = ty * 4 + (id >> 1), ox = tx * 32 + (id & 1) * 16 + li;
+            const bool ok = rb && oy < a.Ho && ox < a.Wo;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                rsn[t][n] = ok ? *reinterpret_cast<const f4*>(rb + (oy * a.Wo + ox) * 32 + n * 16 + kq * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_tile(t_begin);
+    load_res(t_begin);
+    wait_vmcnt_imm<0>();                       // the weight copies have landed (this wave's); the barrier below publishes all of them
+    for (int L = t_begin; L < t_end; ++L) {
+        const int b = L / a.tiles, tile_id = L - b * a.tiles;
+        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
+        const int oy0 = ty * 4, ox0 = tx * 32;
+        store_tile();
+        __syncthreads();                        // tile (and, first time, weights) visible
+        // halo AND residual of the NEXT tile: in flight during this tile's 9 taps and epilogue
+        int pixo[MT];
+        f4 rs[MT][NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int id = wave * MT + t;
+            const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
+            pixo[t] = (oy < a.Ho && ox < a.Wo) ? oy * a.Wo + ox : -1;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) rs[t][n] = rsn[t][n];
+        }
+        const bool has_res = a.res != nullptr;
+        if (L + 1 < t_end) load_res(L + 1);
+        if (L + 1 < t_end) load_tile(L + 1);
+
+        f4 acc[MT][NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+        Frags fr[2];
+        read_frags(fr[0], 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) read_frags(fr[(tap + 1) & 1], tap + 1);
+            const Frags& f = fr[tap & 1];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (TERMS == 3) {
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wlf[n], f.xh[t], acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[t][n], 0, 0, 0);
+                    }
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
+                }
+        }
+
+        float* __restrict__ yb = a.y + (size_t)b * hw * 32;
+        f4 gsum[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int co = n * 16 + kq * 4;
+            const f4 gt = a.gate ? *reinterpret_cast<const f4*>(a.gate + (size_t)b * 32 + co) : (f4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                f4 v = acc[t][n] + bi[n];
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                v = v * sc[n] + sh[n];
+                if (a.gate) v = v * gt;
+                if (has_res && pixo[t] >= 0) v += rs[t][n];
+                if (a.relu2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (pixo[t] >= 0) {
+                    *reinterpret_cast<f4*>(yb + pixo[t] * 32 + co) = v;
+                    gsum[n] += v;
+                }
+            }
+        }
+        if (a.gap) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sm = gsum[n][r];
+                    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
+                    sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+                    if (li == 0) sred[wave * 32 + n * 16 + kq * 4 + r] = sm;
+                }
+        }
+        __syncthreads();                        // every wave is done with the tile image (and the gap scratch is complete)
+        if (a.gap && tid < 32) {
+            float sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sm += sred[m * 32 + tid];
+            a.gap[((size_t)b * a.tiles + tile_id) * 32 + tid] = sm;
+        }
+    }
+}
+
 // ---- stem: Conv2d(1->C, 3x3, bias) -> ReLU -> BN, x [B,H,W] -> y NHWC ----------------------------
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
@@ -709,6 +934,34 @@ int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
     return launch_conv_bf16<CIN, NT, S, TH, WM, WN, 1>(a, whi, wlo, grid, st);
 }
 
+bool conv32_persistent_enabled() {
+    static const bool on = [] { const char* e = getenv("EG_CONV32_PERSISTENT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+template <int TERMS>
+int launch_conv32_persistent_t(const ConvArgs& a, int batch, const bf8* whi, const bf8* wlo, hipStream_t st) {
+    using G = ConvGeom<1, 4>;
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + NIMG * 9 * 128) + 4 * 32 * sizeof(float);
+    auto kern = conv3x3_c32_persistent_kernel<TERMS>;
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (32 -> 32, persistent)")) return rc;
+    const int total = a.tiles * batch;
+    int grid = total < 512 ? total : 512;                        // 2 workgroups per CU
+    int tpw = eg_cdiv(total, grid);
+    grid = eg_cdiv(total, tpw);
+    if (grid >= 8) grid = (int)eg_round_up(grid, 8);             // XCD remap needs a multiple of 8 (surplus workgroups exit at once)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, a, whi, wlo, total, tpw);
+    return eg_check_launch("conv3x3 (32 -> 32, persistent)");
+}
+int launch_conv32_persistent(const ConvArgs& a, int batch, int precision, hipStream_t st) {
+    const size_t f32_floats = (size_t)9 * 32 * 32;
+    const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
+    const bf8* wlo = whi + (size_t)9 * 4 * 32;
+    if (precision == EG_PREC_BF16X3) return launch_conv32_persistent_t<3>(a, batch, whi, wlo, st);
+    return launch_conv32_persistent_t<1>(a, batch, whi, wlo, st);
+}
+
 int conv_tile_rows(int cin, int cout, int stride) {
     if (stride == 2 || cout >= 256) return 2;
     if (cin == 32 && cout == 32) return 4;       // 4-row tiles: smaller LDS footprint, more workgroups in flight (HBM-bound layer)
@@ -757,6 +1010,8 @@ extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, 
     const int coutp = (int)eg_round_up(cout, 16);
     EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + stride * 100 + 1,
                      2.0 * 9 * cin * cout * (double)a.Ho * a.Wo * batch, st);
+    if (cin == 32 && coutp == 32 && cout == 32 && stride == 1 && th == 4 && precision != EG_PREC_F32 && !nchw_out && conv32_persistent_enabled())
+        return launch_conv32_persistent(a, batch, precision, st);
     if (cin == 32 && coutp == 32 && stride == 1 && th == 4) return launch_conv<32, 2, 1, 4, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2, 2, 2>(a, batch, precision, st);
