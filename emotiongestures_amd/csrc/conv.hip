@@ -522,10 +522,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
     }
     const int oc8 = ((tid >> 3) & 3) * 8;
     f4 pv[NIT][2];
-    auto load_tile = [&](int L) {
-        const int b = L / a.tiles, tile_id = L - b * a.tiles;
-        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
-        const int iy0 = ty * 4 - 1, ix0 = tx * 32 - 1;
+    // tile coordinates advance incrementally along the walk (an integer division per use costs ~30 VALU instructions; this kernel
+    // issues 4 non-MFMA VALU instructions per MFMA as it is: profiles/r02k_pmc_conv32_persistent.txt)
+    struct Coord { int b, ty, tx; };
+    const int tiles_y = a.tiles / a.tiles_x;
+    auto advance = [&](Coord& c) {
+        if (++c.tx == a.tiles_x) {
+            c.tx = 0;
+            if (++c.ty == tiles_y) { c.ty = 0; ++c.b; }
+        }
+    };
+    auto load_tile = [&](const Coord& c) {
+        const int b = c.b;
+        const int iy0 = c.ty * 4 - 1, ix0 = c.tx * 32 - 1;
         const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -585,10 +594,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
     }
 
     f4 rsn[MT][NT];
-    auto load_res = [&](int L) {
-        const int b = L / a.tiles, tile_id = L - b * a.tiles;
-        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
-        const float* __restrict__ rb = a.res ? a.res + (size_t)b * hw * 32 : nullptr;
+    auto load_res = [&](const Coord& c) {
+        const int ty = c.ty, tx = c.tx;
+        const float* __restrict__ rb = a.res ? a.res + (size_t)c.b * hw * 32 : nullptr;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int id = wave * MT + t;
@@ -599,13 +607,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
                 rsn[t][n] = ok ? *reinterpret_cast<const f4*>(rb + (oy * a.Wo + ox) * 32 + n * 16 + kq * 4) : (f4){0.f, 0.f, 0.f, 0.f};
         }
     };
-    load_tile(t_begin);
-    load_res(t_begin);
+    Coord cur;
+    cur.b = t_begin / a.tiles;
+    cur.ty = (t_begin - cur.b * a.tiles) / a.tiles_x;
+    cur.tx = t_begin - cur.b * a.tiles - cur.ty * a.tiles_x;
+    Coord nxt = cur;
+    load_tile(cur);
+    load_res(cur);
     wait_vmcnt_imm<0>();                       // the weight copies have landed (this wave's); the barrier below publishes all of them
-    for (int L = t_begin; L < t_end; ++L) {
-        const int b = L / a.tiles, tile_id = L - b * a.tiles;
-        const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
-        const int oy0 = ty * 4, ox0 = tx * 32;
+    for (int L = t_begin; L < t_end; ++L, cur = nxt) {
+        const int b = cur.b, tile_id = cur.ty * a.tiles_x + cur.tx;
+        const int oy0 = cur.ty * 4, ox0 = cur.tx * 32;
+        advance(nxt);
         store_tile();
         __syncthreads();                        // tile (and, first time, weights) visible
         // halo AND residual of the NEXT tile: in flight during this tile's 9 taps and epilogue
@@ -620,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
             for (int n = 0; n < NT; ++n) rs[t][n] = rsn[t][n];
         }
         const bool has_res = a.res != nullptr;
-        if (L + 1 < t_end) load_res(L + 1);
-        if (L + 1 < t_end) load_tile(L + 1);
+        if (L + 1 < t_end) load_res(nxt);
+        if (L + 1 < t_end) load_tile(nxt);
 
         f4 acc[MT][NT];
 #pragma unroll
