@@ -431,6 +431,14 @@ def conv1x1(x_nhwc, w_oi11, stride=1):
     return linear(xs, w_oi11.view(w_oi11.shape[0], -1))
 
 
+def _running_stats_written(bn):
+    """The kernel updated running_mean / running_var through raw pointers: bump their version counters (the inference engines key their
+    folded BatchNorm vectors on them), and count the batch as nn.BatchNorm does."""
+    torch.autograd.graph.increment_version(bn.running_mean)
+    torch.autograd.graph.increment_version(bn.running_var)
+    bn.num_batches_tracked += 1
+
+
 class _BatchNorm(torch.autograd.Function):
     """nn.BatchNorm{1,2}d in train() mode over the last (channel) axis; updates the running buffers in place."""
 
@@ -475,7 +483,7 @@ def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5, gap=None, relu_input
     """`bn` = a BatchNorm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked).  gap: pooling partials of the
     convolution that produced x (conv3x3(want_gap=True)); relu_input: x = relu(.) whose mask this backward applies (conv3x3(defer_mask=True))."""
     y = _BatchNorm.apply(x_channels_last, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, eps, gap, relu_input)
-    bn.num_batches_tracked += 1
+    _running_stats_written(bn)
     return y
 
 
@@ -532,7 +540,7 @@ class _SEBlockTail(torch.autograd.Function):
 
 def se_block_tail(c2, gap, res, bn, fc0, fc2, momentum=0.1, eps=1e-5):
     out = _SEBlockTail.apply(c2, gap, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, fc0.weight, fc0.bias, fc2.weight, fc2.bias, momentum, eps)
-    bn.num_batches_tracked += 1
+    _running_stats_written(bn)
     return out
 
 

@@ -53,4 +53,5 @@ class GraphedStep:
         self.graph.replay()
         if self.opt is not None:
             self.opt.t += 1
+            self.opt.fp.bump_versions()             # the replay rewrote parameters and running statistics without passing through torch
         return self.loss

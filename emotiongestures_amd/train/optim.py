@@ -26,6 +26,7 @@ class FlatParams:
         self.params, self.flat, self.grad, self.offsets = params, flat, grad, offsets
         self.index = {id(p): i for i, p in enumerate(params)}
         self.has_grad = [False] * len(params)       # set by collect_one: parameters autograd produced a gradient for
+        self.buffers: List[torch.Tensor] = []       # the model's buffers (BatchNorm running statistics): written by kernels, versions bumped with the parameters
         self.written = set()                        # parameters whose flat gradient slice a backward kernel already wrote this step
         for p, o in zip(params, offsets):           # the operators of train/functional.py write weight gradients straight into these slices
             p._eg_slot = grad[o:o + p.numel()].view(p.shape)
@@ -37,6 +38,15 @@ class FlatParams:
         for p in self.params:
             p.grad = None
         self.written.clear()
+
+    def bump_versions(self):
+        """The optimiser and the BatchNorm kernels write parameters / running statistics through raw pointers: tell torch (`_version`) so
+        that everything keyed on it -- the inference engines' packed-weight caches -- sees the change."""
+        for t, updated in zip(self.params, self.has_grad):
+            if updated:                             # parameters without a gradient are skipped by the optimiser (torch.optim.Adam semantics): unchanged
+                torch.autograd.graph.increment_version(t)
+        for t in self.buffers:
+            torch.autograd.graph.increment_version(t)
 
     def collect_one(self, p: torch.nn.Parameter):
         o = self.offsets[self.index[id(p)]]
@@ -75,7 +85,9 @@ def flatten_parameters(model: torch.nn.Module) -> FlatParams:
         flat[o:o + n].copy_(p.detach().reshape(-1))
         p.data = flat[o:o + n].view(p.shape)
         p.grad = None
-    return FlatParams(params, flat, grad, offsets)
+    fp = FlatParams(params, flat, grad, offsets)
+    fp.buffers = [b for b in model.buffers() if b.is_floating_point()]
+    return fp
 
 
 class FlatAdam:
@@ -125,6 +137,7 @@ class FlatAdam:
             L.check(lib.eg_adam_step(_ptr(fp.flat[sl]), _ptr(fp.grad[sl]), _ptr(self.exp_avg[sl]), _ptr(self.exp_avg_sq[sl]), hi - lo,
                                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                      self.t, _stream(fp.flat.device)), "eg_adam_step")
+        fp.bump_versions()
 
     def zero_grad(self):
         self.fp.zero_grad()

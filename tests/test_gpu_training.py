@@ -651,3 +651,44 @@ def test_bench_train_two_ranks_share_one_gpu_over_gloo(graph):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and np.isfinite(line["final_loss"])
     assert ("hipGraph" in line["launch"]) == graph
+
+
+def test_eval_after_training_sees_the_updated_weights_and_statistics():
+    """FlatAdam and the BatchNorm kernels write through raw pointers; the version bumps make the inference engine repack: after a few training
+    steps `model.eval()` equals a fresh mirror loaded with the trained state_dict (and differs from the untrained one)."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.graph import GraphedStep
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    inp = synth_inputs(2, 34, 126, 4, seed=13)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    label = torch.tensor([1, 2], device=DEV)        # made outside the captured region (a host -> device copy cannot be captured)
+    for graphed in (False, True):
+        model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV)
+        with torch.no_grad():
+            before = model.eval()(g["spec"], g["text"], g["pre_pose"], None)[0].clone()
+        model.train()
+        fp = flatten_parameters(model)
+        opt = FlatAdam(fp, lr=1e-3, betas=(0.5, 0.999))
+
+        def step(_inputs=None):
+            opt.zero_grad()
+            pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+            loss = F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, label))
+            loss.backward()
+            opt.step()
+            return loss
+
+        if graphed:
+            gs = GraphedStep(step, g, opt, warmup=1)
+            gs.run(); gs.run()
+        else:
+            for _ in range(3):
+                step()
+        with torch.no_grad():
+            after = model.eval()(g["spec"], g["text"], g["pre_pose"], None)[0].clone()
+        fresh = build_mirror("spatial", 34, 126, 4, 4, seed=1, precision="f32")
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        with torch.no_grad():
+            want = fresh.to(DEV).eval()(g["spec"], g["text"], g["pre_pose"], None)[0]
+        assert float((after - before).norm() / before.norm()) > 1e-3, graphed
+        assert float((after - want).norm() / want.norm()) < 1e-6, graphed
