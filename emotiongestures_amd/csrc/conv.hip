@@ -712,35 +712,34 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ y,
                                                         int B, int H, int W, int C) {
-    // lane = (pixel, channel quad); the grid stride is a multiple of C/4, so a thread keeps its channel quad and holds the
-    // 9 taps + bias + BN affine of that quad in registers for all its pixels (was: 12 vector loads per output)
-    const int cq_n = C >> 2;
-    const size_t total = (size_t)B * H * W * cq_n;
-    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int cq = (int)(i0 % cq_n);
+    // One workgroup per output row: the three input rows (zero padded) are staged in LDS once, thread = (pixel, channel quad) with the
+    // quad fixed per thread (its 9 taps + bias + BN affine stay in registers), pixels strided by 256 / (C/4).  No per-element index
+    // division (the first version spent four 64-bit divisions per output quad: 27 M VALU instructions per launch, VALU bound at 53 us).
+    extern __shared__ float rows[];                     // [3][W + 2]
+    const int cq_n = C >> 2, tid = threadIdx.x;
+    const int b = blockIdx.x / H, oy = blockIdx.x - b * H, WP = W + 2;
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = tid; i < 3 * WP; i += 256) {
+        const int r = i / WP, c = i - r * WP, gy = oy + r - 1, gx = c - 1;
+        rows[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[gy * W + gx] : 0.f;
+    }
+    const int cq = tid % cq_n, px0 = tid / cq_n, pstep = 256 / cq_n;
     f4 wv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f4*>(w + t * C + cq * 4);
     const f4 bi = *reinterpret_cast<const f4*>(bias + cq * 4);
     const f4 sc = *reinterpret_cast<const f4*>(scale + cq * 4), sh = *reinterpret_cast<const f4*>(shift + cq * 4);
-    for (size_t i = i0; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t p = i / cq_n;
-        const int ox = (int)(p % W);
-        const int oy = (int)((p / W) % H);
-        const size_t b = p / ((size_t)W * H);
-        const float* xb = x + b * H * W;
+    __syncthreads();
+    float* yrow = y + ((size_t)b * H + oy) * W * C + cq * 4;
+    for (int ox = px0; ox < W; ox += pstep) {
         f4 acc = bi;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int gy = oy + kh - 1, gx = ox + kw - 1;
-                const float xv = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[gy * W + gx] : 0.f;
-                acc += wv[kh * 3 + kw] * xv;
-            }
+            for (int kw = 0; kw < 3; ++kw) acc += wv[kh * 3 + kw] * rows[kh * WP + ox + kw];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
-        *reinterpret_cast<f4*>(y + p * C + cq * 4) = acc * sc + sh;
+        *reinterpret_cast<f4*>(yrow + (size_t)ox * C) = acc * sc + sh;
     }
 }
 
@@ -895,13 +894,14 @@ __global__ __launch_bounds__(256) void se_tail_downsample_kernel(const float* __
     for (int i = threadIdx.x; i < CIN * COUT / 4; i += 256) wl[i] = reinterpret_cast<const f4*>(dsw)[i];
     __syncthreads();
     constexpr int CQ = COUT / 4;
-    const size_t total = (size_t)B * Ho * Wo * CQ;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cq = (int)(i % CQ);
-        const size_t p = i / CQ;
-        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
-        const size_t b = p / ((size_t)Wo * Ho);
-        const float* xp = xin + ((b * Hin + (size_t)oy * S) * Win + (size_t)ox * S) * CIN;
+    // rows of the output map are dealt to the workgroups; inside a row the index splits by shifts (CQ is a power of two): no per-element
+    // 64-bit division (three per output quad in the first version)
+    for (int row = blockIdx.x; row < B * Ho; row += gridDim.x) {
+      const int b = row / Ho, oy = row - b * Ho;
+      for (int t = threadIdx.x; t < Wo * CQ; t += 256) {
+        const int cq = t % CQ, ox = t / CQ;
+        const size_t p = (size_t)row * Wo + ox;
+        const float* xp = xin + (((size_t)b * Hin + (size_t)oy * S) * Win + (size_t)ox * S) * CIN;
         f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int ci = 0; ci < CIN; ci += 4) {
@@ -910,11 +910,12 @@ __global__ __launch_bounds__(256) void se_tail_downsample_kernel(const float* __
             for (int j = 0; j < 4; ++j) acc += wl[(ci + j) * CQ + cq] * xv[j];
         }
         const f4 res = acc * *reinterpret_cast<const f4*>(dss + cq * 4) + *reinterpret_cast<const f4*>(dsh + cq * 4);
-        const f4 g = *reinterpret_cast<const f4*>(gate + b * COUT + cq * 4);
+        const f4 g = *reinterpret_cast<const f4*>(gate + (size_t)b * COUT + cq * 4);
         f4 v = *reinterpret_cast<const f4*>(y + p * COUT + cq * 4) * g + res;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         *reinterpret_cast<f4*>(out + p * COUT + cq * 4) = v;
+      }
     }
 }
 
@@ -1048,9 +1049,8 @@ extern "C" int eg_stem_conv(const float* x, const float* w9xc, const float* bias
                             float* y, int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream) {
     EG_REQUIRE(x && w9xc && bias && scale && shift && y && batch > 0, EG_ERR_BAD_ARG, "eg_stem_conv: null pointer");
     EG_REQUIRE(c % 4 == 0 && c <= 128 && 256 % (c / 4) == 0, EG_ERR_UNSUPPORTED, "eg_stem_conv: C=%d", c);
-    const size_t total = (size_t)batch * h * wdt * (c / 4);
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);     // 256 % (C/4) == 0: a thread keeps its channel quad
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w9xc, bias, scale, shift, y,
+    // 256 % (C/4) == 0: a thread keeps its channel quad; one workgroup per output row
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(batch * h), dim3(256), 3 * (wdt + 2) * sizeof(float), (hipStream_t)stream, x, w9xc, bias, scale, shift, y,
                        batch, h, wdt, c);
     return eg_check_launch("stem_conv");
 }
