@@ -14,18 +14,22 @@
 
 namespace {
 
+// Two frames per transform: frame 2j is the real part and frame 2j+1 the imaginary part of ONE 1024-point complex FFT; their spectra separate
+// as X0[k] = (Z[k] + conj Z[N-k]) / 2, X1[k] = (Z[k] - conj Z[N-k]) / 2i.  Halves the butterflies per frame (the first version transformed one
+// real frame with a zero imaginary part).  The cross-talk between the two frames is bounded by fp32 round-off of the louder one (power floor
+// ~4e-15 of its power: 60 dB below the 80 dB clamp of power_to_db).
 __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ audio, int n_samples, const float* __restrict__ melfb_t,
                                                         const float* __restrict__ window, const float* __restrict__ twiddle,
                                                         const int* __restrict__ band, float* __restrict__ melpow, int n_frames) {
-    __shared__ float re[1024], im[1024], part[256];
-    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float re[1024], im[1024];
+    const int f0 = blockIdx.x * 2, f1 = f0 + 1, b = blockIdx.y, tid = threadIdx.x;
     const float* clip = audio + (size_t)b * n_samples;
     for (int i = tid; i < 1024; i += 256) {
-        const int s = f * 512 - 512 + i;
-        const float x = (s >= 0 && s < n_samples) ? clip[s] * window[i] : 0.f;
+        const int s0 = f0 * 512 - 512 + i, s1 = s0 + 512;
+        const float wv = window[i];
         const int r = (int)(__brev((unsigned)i) >> 22);       // 10-bit reversal
-        re[r] = x;
-        im[r] = 0.f;
+        re[r] = (s0 >= 0 && s0 < n_samples) ? clip[s0] * wv : 0.f;
+        im[r] = (f1 < n_frames && s1 >= 0 && s1 < n_samples) ? clip[s1] * wv : 0.f;
     }
     __syncthreads();
 #pragma unroll 1
@@ -45,46 +49,54 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
         }
         __syncthreads();
     }
-    // power spectrum into re[0..512]
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    {
-        const int k0 = tid, k1 = tid + 256, k2 = 512;
-        p0 = re[k0] * re[k0] + im[k0] * im[k0];
-        p1 = re[k1] * re[k1] + im[k1] * im[k1];
-        if (tid == 0) p2 = re[k2] * re[k2] + im[k2] * im[k2];
+    // power spectra of the two frames, bins 0..512: thread tid takes k = tid, tid + 256 (and 512 on thread 0)
+    float pa[3], pb[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int k = u < 2 ? tid + u * 256 : 512, nk = (1024 - k) & 1023;
+        pa[u] = pb[u] = 0.f;
+        if (u < 2 || tid == 0) {
+            const float zr = re[k], zi = im[k], yr = re[nk], yi = im[nk];
+            const float r0 = 0.5f * (zr + yr), i0 = 0.5f * (zi - yi);      // X0[k]
+            const float r1 = 0.5f * (zi + yi), i1 = 0.5f * (yr - zr);      // X1[k]
+            pa[u] = r0 * r0 + i0 * i0;
+            pb[u] = r1 * r1 + i1 * i1;
+        }
     }
     __syncthreads();
-    re[tid] = p0; re[tid + 256] = p1;
-    if (tid == 0) re[512] = p2;
+    re[tid] = pa[0]; re[tid + 256] = pa[1];
+    im[tid] = pb[0]; im[tid + 256] = pb[1];
+    if (tid == 0) { re[512] = pa[2]; im[512] = pb[2]; }
     __syncthreads();
-    // mel projection: the Slaney filters are triangles, so mel m only touches bins [band[2m], band[2m+1]) (~2*513 non-zeros
-    // in total instead of 128*513); thread (m = tid&127, half = tid>>7) sums its half of that band
-    const int m = tid & 127, hf = tid >> 7;
-    const int b0 = band[2 * m], b1 = band[2 * m + 1], bm = (b0 + b1) >> 1;
-    const int kb = hf ? bm : b0, ke = hf ? b1 : bm;
+    // mel projection: the Slaney filters are triangles, so mel m only touches bins [band[2m], band[2m+1]) (~2*513 non-zeros in total instead of
+    // 128*513); thread (m = tid & 127, frame = tid >> 7) sums its band in bin order
+    const int m = tid & 127, fr = tid >> 7, f = f0 + fr;
+    const float* pw = fr ? im : re;
+    const int b0 = band[2 * m], b1 = band[2 * m + 1];
     float s = 0.f;
-    for (int k = kb; k < ke; ++k) s += melfb_t[k * 128 + m] * re[k];
-    part[tid] = s;
-    __syncthreads();
-    if (tid < 128) melpow[((size_t)b * 128 + tid) * n_frames + f] = part[tid] + part[tid + 128];
+    for (int k = b0; k < b1; ++k) s += melfb_t[k * 128 + m] * pw[k];
+    if (f < n_frames) melpow[((size_t)b * 128 + m) * n_frames + f] = s;
 }
 
-__global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ melpow, float* __restrict__ spec, int n_frames,
-                                                     int out_frames) {
-    __shared__ float red[4];
+// one workgroup of 1024 threads per clip (the clip maximum couples all its bins; with 256 threads the 64 workgroups of a 64-clip step ran 43 us)
+__global__ __launch_bounds__(1024) void mel_db_kernel(const float* __restrict__ melpow, float* __restrict__ spec, int n_frames,
+                                                      int out_frames) {
+    __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = melpow + (size_t)b * 128 * n_frames;
     float mx = 0.f;
-    for (int i = tid; i < 128 * n_frames; i += 256) mx = fmaxf(mx, p[i]);
+    for (int i = tid; i < 128 * n_frames; i += 1024) mx = fmaxf(mx, p[i]);
     mx = wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
     // power_to_db(ref=np.max): 10*log10(max(amin,S)) - 10*log10(max(amin,max S)) = 10*log10(max(amin,S)/ref); the ratio
     // form makes the peak (and an all-silent clip) exactly 0 dB, as in exact arithmetic.  max(db) = 0 => floor = -top_db.
     const float inv_ref = 1.0f / fmaxf(1e-10f, mx);
     const float floor_db = -80.f;
-    for (int i = tid; i < 128 * out_frames; i += 256) {
+    for (int i = tid; i < 128 * out_frames; i += 1024) {
         const int m = i / out_frames, f = i - m * out_frames;
         float db = 10.f * log10f(fmaxf(1e-10f, p[m * n_frames + f]) * inv_ref);
         db = fmaxf(db, floor_db);
@@ -152,10 +164,10 @@ extern "C" int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_sa
     EG_REQUIRE(workspace_bytes >= eg_mel_workspace_bytes(batch, n_samples), EG_ERR_WORKSPACE, "eg_melspectrogram: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* melpow = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(mel_power_kernel, dim3(n_frames, batch), dim3(256), 0, st, audio, n_samples, d_melfb_t, d_window, d_twiddle,
+    hipLaunchKernelGGL(mel_power_kernel, dim3((n_frames + 1) / 2, batch), dim3(256), 0, st, audio, n_samples, d_melfb_t, d_window, d_twiddle,
                        d_band, melpow, n_frames);
     int rc = eg_check_launch("mel_power");
     if (rc) return rc;
-    hipLaunchKernelGGL(mel_db_kernel, dim3(batch), dim3(256), 0, st, melpow, spec, n_frames, out_frames);
+    hipLaunchKernelGGL(mel_db_kernel, dim3(batch), dim3(1024), 0, st, melpow, spec, n_frames, out_frames);
     return eg_check_launch("mel_db");
 }
