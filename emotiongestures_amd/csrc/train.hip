@@ -134,15 +134,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
     }
 }
+// c[m][n] (+)= sum over z of partial[z][m][n], fixed order: 64 outputs per workgroup, the four waves take z = w, w + 4, ... with eight loads
+// in flight per lane, then combine in wave order.  (One thread per output walking all slices took 90-230 us for the small, deeply split
+// products: the stem's and the stride-2 convolutions' weight gradients run 57-1024 slices.)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ c, int ldc, int M, int N,
                                                         int splits, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * M * N + i];
-    float* o = c + (size_t)m * ldc + n;
-    *o = accumulate ? *o + s : s;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t mn = (size_t)M * N, i = (size_t)blockIdx.x * 64 + lane;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (i < mn) {
+        int z = w;
+        for (; z + 28 < splits; z += 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += partial[(size_t)(z + 4 * k) * mn + i];
+        }
+        for (int k = 0; z < splits; z += 4, ++k) acc[k & 7] += partial[(size_t)z * mn + i];
+    }
+    red[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w == 0 && i < mn) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+        float* o = c + (size_t)m * ldc + n;
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 // ---- im2col / col2im, 3x3 pad 1, NHWC: col[p][tap*C + c] = x[b, oy*s + kh - 1, ox*s + kw - 1, c] -------------------------
@@ -970,7 +988,7 @@ int launch_gemm_tn(bool implicit, const float* a, int lda, const float* b, int l
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m, n, (long)k, direct ? (long)k : kps, part, geo);
     if (int rc = eg_check_launch("gemm_tn")) return rc;
     if (direct) return EG_OK;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(eg_cdiv(m * n, 256)), dim3(256), 0, st, part, c, ldc, m, n, nz, accumulate);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(eg_cdiv(m * n, 64)), dim3(256), 0, st, part, c, ldc, m, n, nz, accumulate);
     return eg_check_launch("gemm_tn_reduce");
 }
 }  // namespace
