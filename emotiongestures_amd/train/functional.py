@@ -48,6 +48,17 @@ def _chk(t: torch.Tensor, name="tensor") -> torch.Tensor:
     return t.contiguous()
 
 
+_CONST = {}
+
+
+def _const_vec(dev, n: int, value: float) -> torch.Tensor:
+    key = (str(dev), n, value)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), value, dtype=torch.float32, device=dev)
+    return t
+
+
 def grad_out(param, shape=None) -> torch.Tensor:
     """Where a backward kernel writes the gradient of `param`: its slice of the flat gradient buffer (optim.flatten_parameters) when it has
     one that nothing wrote yet this step -- autograd then adopts that view as .grad and the collection copy disappears -- else fresh memory
@@ -337,7 +348,13 @@ class _Conv3x3(torch.autograd.Function):
                 L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(yc), None, B, H, W, Ci, Co, stride, int(relu), 1, prec,
                                        _stream(dev)), "eg_conv3x3")
                 y = yc.view(B, Co, Ho, Wo).permute(0, 2, 3, 1).contiguous()
-        else:               # the stem (1 input channel): im2col rows through the GEMM
+        elif Ci == 1 and stride == 1 and relu and b is not None and Co % 4 == 0 and Co <= 128 and 256 % (Co // 4) == 0:
+            # the stem (ResNetSE34V2.py:64-66: conv -> ReLU, BatchNorm follows as its own operator): the inference stem kernel with an identity affine
+            w9 = raw_transpose(wd.view(Co, 9))                                  # [9][Co] tap-major
+            one, zero = _const_vec(dev, Co, 1.0), _const_vec(dev, Co, 0.0)
+            y = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev)
+            L.check(lib.eg_stem_conv(_ptr(xd), _ptr(w9), _ptr(_chk(b)), _ptr(one), _ptr(zero), _ptr(y), B, H, W, Co, _stream(dev)), "eg_stem_conv")
+        else:               # other thin inputs: im2col rows through the GEMM
             col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
             L.check(lib.eg_im2col3x3(_ptr(xd), _ptr(col), B, H, W, Ci, stride, 0, _stream(dev)), "eg_im2col3x3")
             wm = wd.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
