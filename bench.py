@@ -122,6 +122,8 @@ def measured_traffic(tag, precision):
     else:
         return None
     hits = [v for k, v in kern.items() if k.startswith(prefix)]
+    if not hits and tag >= 1000 and tag // 1000000 == 32 and (tag // 1000) % 1000 == 32:      # the 32 -> 32 stage runs on the persistent kernel
+        hits = [v for k, v in kern.items() if k.startswith("conv3x3_c32_persistent_kernel<3>")]
     return hits[0]["bytes"] if hits else None
 
 
