@@ -539,6 +539,16 @@ def main():
                 "flop_per_launch": flop,
                 "by_kernel_ms_per_step": {kernel_name(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())},
                 "by_kernel_tflops": {kernel_name(k): round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in sorted(contraction.items())}}
+        # memory side of the one stage whose convolutions are traffic- rather than MFMA-limited (32 -> 32 channels at 128 x 124): algorithmic
+        # bytes per launch (input + output map, + the residual for the conv2 launches: average of the block's two) over the measured duration
+        c32 = 32 * 1000000 + 32 * 1000 + 100 + 1
+        if c32 in groups and B > 0:
+            amap = B * 128 * 124 * 32 * 4
+            alg = 2.5 * amap
+            hb = alg / (groups[c32][1] * 1e-3) / 1e9
+            roof["hbm_view_conv32"] = {"bound": "hbm", "kernel": kernel_name(c32), "achieved": round(hb, 1), "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(hb / 8000.0, 4), "algorithmic_bytes": int(alg), "traffic": measured_traffic(c32, args.precision),
+                                       "avg_launch_ms": round(groups[c32][1], 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_g, sd_v, inp)
 
