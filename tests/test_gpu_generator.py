@@ -260,6 +260,16 @@ def test_melspectrogram_matches_oracle():
     assert np.abs(g2 - O.melspectrogram(short)).max() <= 0.0626
     silent = mel(torch.zeros(1, 16000, device=dev())).cpu().numpy()
     assert np.all(silent == 0.0)
+    # the kernel transforms frames in pairs (even frame = real part, odd frame = imaginary part of one complex FFT): a quiet frame next to a
+    # loud one must not pick up cross-talk above the 80 dB floor -- one second of near silence (1e-4 of full scale), then full-scale noise,
+    # with the quiet / loud boundary on an odd frame index and an odd frame count (last pair half empty)
+    step = synth_audio(1, 32 * 512, seed=2)
+    step[:, :15 * 512 + 256] *= 1e-4
+    g3 = mel(torch.from_numpy(step).to(dev())).cpu().numpy()
+    r3 = O.melspectrogram(step)
+    assert g3.shape == r3.shape == (1, 128, 33)
+    d3 = np.abs(g3 - r3)
+    assert d3.max() <= 0.0626 and (d3 > 0).mean() < 0.01, (d3.max(), (d3 > 0).mean())
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
