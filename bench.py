@@ -233,6 +233,7 @@ def train_worker(args, rank, world, dev, dist, backend):
         vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
         both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
         fp = flatten_parameters(both)
+        fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
         opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
         gb = GradBuckets(fp, bucket_mb=25.0).attach()
         ar_ms = []
@@ -295,6 +296,7 @@ def train_worker(args, rank, world, dev, dist, backend):
                "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
                "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
         F.set_precision("f32")
+        F.register_weight_images(None)
         return out
 
     main_leg = leg(args.train_precision, not args.no_train_graph)

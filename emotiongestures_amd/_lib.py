@@ -125,6 +125,8 @@ SIGNATURES = {
     "eg_pack_conv3x3_device": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "eg_linear_packed_floats": (_L, [_I, _I]),
     "eg_pack_linear_device": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "eg_pack_table_blocks": (_I, [_I, _I, _I, _I]),
+    "eg_pack_table": (C.c_int, [_P, _I, _I, _P]),
     "eg_dropout": (C.c_int, [_P, _P, _L, C.c_float, C.c_uint32, C.c_uint64, _P]),
     "eg_seg_mean": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, _P, _P]),
     "eg_seg_dot": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -632,10 +632,9 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 // OIHW fp32 -> the image eg_conv3x3 reads (conv.hip: launch_conv): fp32 [tap][ci/4][coutp][4], then bf16 hi and lo images
 // [tap][ci/8][coutp][8].  flip != 0 packs the filter of the input-gradient convolution instead: w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
 // (the result then convolves `cout` input channels into `cin` output channels).  One thread per (tap, channel octet, output channel).
-__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int cout, int cin, int flip, float* __restrict__ image) {
+__device__ __forceinline__ void pack_conv3x3_item(const float* __restrict__ w, int cout, int cin, int flip, float* __restrict__ image, int idx) {
     const int CI = flip ? cout : cin, CO = flip ? cin : cout, coutp = (CO + 15) / 16 * 16;
     const int total = 9 * (CI / 8) * coutp;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int co = idx % coutp, oc = (idx / coutp) % (CI / 8), tap = idx / (coutp * (CI / 8));
     const int st = flip ? 8 - tap : tap;
@@ -658,14 +657,16 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
     himg[idx] = hi;
     limg[idx] = lo;
 }
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int cout, int cin, int flip, float* __restrict__ image) {
+    pack_conv3x3_item(w, cout, cin, flip, image, blockIdx.x * 256 + threadIdx.x);
+}
 
 // ---- nn.Linear weight image, built on the device --------------------------------------------------------------------------------------
 // [n][k] fp32 (row stride ld) -> the image eg_linear's split-bf16 modes read (gemm.hip: fill_common): fp32 [rows][kpad], then tile-planar bf16
 // hi and lo images [rows/64][kpad/8][64][8]; rows = n rounded up to 64, kpad = k rounded up to 64, zero padded.  transpose != 0 packs
 // the transposed matrix (the `weight` of dX = dY W is W^T): image row r, column q = w[q][r].  One thread per (row tile, k octet, row).
-__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, int ld, int n, int k, int transpose, float* __restrict__ image) {
+__device__ __forceinline__ void pack_linear_item(const float* __restrict__ w, int ld, int n, int k, int transpose, float* __restrict__ image, int idx) {
     const int rows = (n + 63) / 64 * 64, kpad = (k + 63) / 64 * 64, KO = kpad / 8;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * KO) return;
     const int r = idx & 63, ko = (idx >> 6) % KO, rt = idx / (64 * KO);
     const int row = rt * 64 + r;
@@ -687,6 +688,26 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
     bf8* limg = himg + (size_t)rows * KO;
     himg[idx] = hi;
     limg[idx] = lo;
+}
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, int ld, int n, int k, int transpose, float* __restrict__ image) {
+    pack_linear_item(w, ld, n, k, transpose, image, blockIdx.x * 256 + threadIdx.x);
+}
+
+// All weight images of a training step in ONE launch: a table of (source, image, shape) entries built once (parameters and images live at fixed
+// addresses), each entry owning a run of workgroups; a workgroup finds its entry by bisection over the run starts.  (A step packed ~200 weights
+// one launch each: 8 % of its launches.)
+struct PackEntry { const float* src; float* image; int kind, a, b, c, flag, first_block; };      // kind 0: Linear (n, k, ld, transpose); 1: conv3x3 (cout, cin, -, flip)
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackEntry* __restrict__ table, int count) {
+    int lo = 0, hi = count - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PackEntry e = table[lo];
+    const int idx = (blk - e.first_block) * 256 + threadIdx.x;
+    if (e.kind == 0) pack_linear_item(e.src, e.c, e.a, e.b, e.flag, e.image, idx);
+    else pack_conv3x3_item(e.src, e.a, e.b, e.flag, e.image, idx);
 }
 
 // ---- dropout: counter-based mask, nothing stored -- keep(i) = hash(seed, offset + i) >= p; y = keep ? x / (1 - p) : 0.  The backward pass
@@ -1239,6 +1260,21 @@ extern "C" int eg_pack_linear_device(const float* w, int32_t ld, int32_t n, int3
     const int total = (int)(eg_round_up(n, 64) * (eg_round_up(k, 64) / 8));
     hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, w, ld, n, k, transpose, image);
     return eg_check_launch("pack_linear");
+}
+
+// Table-driven packing (see pack_table_kernel).  `table` is device memory holding `count` 40-byte entries
+//   { const float* src; float* image; int32 kind, a, b, c, flag, first_block; }   kind 0: Linear a = n, b = k, c = ld, flag = transpose;  kind 1: conv3x3 a = cout, b = cin, flag = flip
+// with first_block the running sum of eg_pack_table_blocks(...) of the entries before it; total_blocks = that sum over all entries.
+extern "C" int32_t eg_pack_table_blocks(int32_t kind, int32_t a, int32_t b, int32_t flag) {
+    if (kind == 0) return (int32_t)((eg_round_up(a, 64) * (eg_round_up(b, 64) / 8) + 255) / 256);
+    const int ci = flag ? a : b, co = flag ? b : a;
+    return (int32_t)((9 * (ci / 8) * (int)eg_round_up(co, 16) + 255) / 256);
+}
+extern "C" int eg_pack_table(const void* table, int32_t count, int32_t total_blocks, void* stream) {
+    EG_REQUIRE(table && count > 0 && total_blocks > 0, EG_ERR_BAD_ARG, "eg_pack_table: bad argument");
+    static_assert(sizeof(PackEntry) == 40, "PackEntry layout is part of the ABI");
+    hipLaunchKernelGGL(pack_table_kernel, dim3(total_blocks), dim3(256), 0, ST, reinterpret_cast<const PackEntry*>(table), count);
+    return eg_check_launch("pack_table");
 }
 
 extern "C" int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream) {

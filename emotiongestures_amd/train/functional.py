@@ -92,11 +92,25 @@ def _pad_cols(t: torch.Tensor, mult=4) -> torch.Tensor:
 
 
 # ---- raw (non-autograd) kernels ---------------------------------------------------------------------------------------------
+_IMAGES = {"reg": None}
+
+
+def register_weight_images(images) -> None:
+    """optim.WeightImages of the model being trained (None: every use packs its own image)."""
+    _IMAGES["reg"] = images
+
+
 def _pack_linear(w, transpose=False):
-    """[N,K] fp32 (or its transpose) -> eg_linear's split-bf16 weight image, one launch; returns (image, ldw)."""
+    """[N,K] fp32 (or its transpose) -> eg_linear's split-bf16 weight image; returns (image, ldw).  Resident image (refreshed once per
+    optimiser step) when the weight is a registered parameter, else one launch."""
     lib = _lib()
     r, c = w.shape
     n, k = (c, r) if transpose else (r, c)
+    reg = _IMAGES["reg"]
+    if reg is not None:
+        img = reg.lookup(w, 0, int(transpose))
+        if img is not None:
+            return img, (k + 63) // 64 * 64
     img = torch.empty(int(lib.eg_linear_packed_floats(n, k)), dtype=torch.float32, device=w.device)
     L.check(lib.eg_pack_linear_device(_ptr(w), c, n, k, int(transpose), _ptr(img), _stream(w.device)), "eg_pack_linear_device")
     return img, (k + 63) // 64 * 64
@@ -312,6 +326,11 @@ def _pack_conv(w, flip=False):
     lib = _lib()
     co, ci = w.shape[:2]
     cie, coe = (co, ci) if flip else (ci, co)
+    reg = _IMAGES["reg"]
+    if reg is not None:
+        hit = reg.lookup(w, 1, int(flip))
+        if hit is not None:
+            return hit
     img = torch.empty(int(lib.eg_conv3x3_packed_floats(cie, (coe + 15) // 16 * 16)), dtype=torch.float32, device=w.device)
     L.check(lib.eg_pack_conv3x3_device(_ptr(w), co, ci, int(flip), _ptr(img), _stream(w.device)), "eg_pack_conv3x3_device")
     return img

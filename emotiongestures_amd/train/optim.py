@@ -26,6 +26,7 @@ class FlatParams:
         self.params, self.flat, self.grad, self.offsets = params, flat, grad, offsets
         self.index = {id(p): i for i, p in enumerate(params)}
         self.has_grad = [False] * len(params)       # set by collect_one: parameters autograd produced a gradient for
+        self.images: Optional[WeightImages] = None  # enable_weight_images(): all weight images of a step in one launch
         self.buffers: List[torch.Tensor] = []       # the model's buffers (BatchNorm running statistics): written by kernels, versions bumped with the parameters
         self.written = set()                        # parameters whose flat gradient slice a backward kernel already wrote this step
         for p, o in zip(params, offsets):           # the operators of train/functional.py write weight gradients straight into these slices
@@ -39,6 +40,14 @@ class FlatParams:
             p.grad = None
         self.written.clear()
 
+    def enable_weight_images(self):
+        """Keep the split-bf16 weight images of all Linear / conv3x3 parameters resident and refresh them once per optimiser step."""
+        from . import functional as F
+        if self.images is None:
+            self.images = WeightImages(self)
+        F.register_weight_images(self.images)
+        return self.images
+
     def bump_versions(self):
         """The optimiser and the BatchNorm kernels write parameters / running statistics through raw pointers: tell torch (`_version`) so
         that everything keyed on it -- the inference engines' packed-weight caches -- sees the change."""
@@ -47,6 +56,8 @@ class FlatParams:
                 torch.autograd.graph.increment_version(t)
         for t in self.buffers:
             torch.autograd.graph.increment_version(t)
+        if self.images is not None:
+            self.images.mark_fresh()                # the caller refreshed them from the values just written (FlatAdam.step / the captured graph)
 
     def collect_one(self, p: torch.nn.Parameter):
         o = self.offsets[self.index[id(p)]]
@@ -88,6 +99,67 @@ def flatten_parameters(model: torch.nn.Module) -> FlatParams:
     fp = FlatParams(params, flat, grad, offsets)
     fp.buffers = [b for b in model.buffers() if b.is_floating_point()]
     return fp
+
+
+class WeightImages:
+    """The split-bf16 weight images of every Linear ([n, k] and its transpose) and 3x3 convolution (filter and its rotated transpose) of
+    a flattened model, refreshed with ONE launch per optimiser step (eg_pack_table) instead of one launch per use: parameters and images
+    live at fixed addresses, so the table is built once.  `train/functional.py` looks an image up by (storage address, orientation) and
+    checks the parameter's version; a miss (reshaped weights, a stale version) falls back to the per-use packer."""
+
+    def __init__(self, fp: "FlatParams"):
+        import numpy as np
+        lib = L.load()
+        dev = fp.flat.device
+        if dev.type != "cuda":
+            raise L.EgError("WeightImages: needs a GPU")
+        entries, self.images, self.params = [], {}, []
+        first = 0
+        for p in fp.params:
+            kinds = []
+            if p.dim() == 2:
+                n, k = p.shape
+                kinds = [(0, n, k, k, 0, int(lib.eg_linear_packed_floats(n, k))), (0, k, n, k, 1, int(lib.eg_linear_packed_floats(k, n)))]
+            elif p.dim() == 4 and tuple(p.shape[2:]) == (3, 3):
+                co, ci = p.shape[:2]
+                if ci % 8 == 0:
+                    kinds.append((1, co, ci, 0, 0, int(lib.eg_conv3x3_packed_floats(ci, (co + 15) // 16 * 16))))
+                if co % 8 == 0:
+                    kinds.append((1, co, ci, 0, 1, int(lib.eg_conv3x3_packed_floats(co, (ci + 15) // 16 * 16))))
+            for kind, a, b, c, flag, floats in kinds:
+                img = torch.empty(floats, dtype=torch.float32, device=dev)
+                self.images[(p.data_ptr(), kind, flag)] = (img, p)
+                entries.append((p.data_ptr(), img.data_ptr(), kind, a, b, c, flag, first))
+                first += int(lib.eg_pack_table_blocks(kind, a, b, flag))
+            if kinds:
+                self.params.append(p)
+        self.count, self.total_blocks = len(entries), first
+        rec = np.zeros(self.count, dtype=np.dtype([("src", "<u8"), ("img", "<u8"), ("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4"), ("flag", "<i4"),
+                                                   ("first", "<i4")]))
+        for i, e in enumerate(entries):
+            rec[i] = e
+        assert rec.dtype.itemsize == 40
+        self.table = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.versions = {}
+        self.refresh()
+
+    def refresh(self):
+        """Rebuild every image from the current parameter values (one launch) and remember the versions they correspond to."""
+        if self.count:
+            L.check(L.load().eg_pack_table(_ptr(self.table), self.count, self.total_blocks, _stream(self.table.device)), "eg_pack_table")
+        self.mark_fresh()
+
+    def mark_fresh(self):
+        self.versions = {id(p): p._version for p in self.params}
+
+    def lookup(self, w: torch.Tensor, kind: int, flag: int):
+        hit = self.images.get((w.data_ptr(), kind, flag))
+        if hit is None:
+            return None
+        img, p = hit
+        if tuple(w.shape) != tuple(p.shape) or self.versions.get(id(p)) != w._version:
+            return None                 # a different view of that storage, or the parameter changed since the last refresh
+        return img
 
 
 class FlatAdam:
@@ -137,6 +209,8 @@ class FlatAdam:
             L.check(lib.eg_adam_step(_ptr(fp.flat[sl]), _ptr(fp.grad[sl]), _ptr(self.exp_avg[sl]), _ptr(self.exp_avg_sq[sl]), hi - lo,
                                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                      self.t, _stream(fp.flat.device)), "eg_adam_step")
+        if fp.images is not None:
+            fp.images.refresh()                     # one launch: every weight image of the next step, from the values just written
         fp.bump_versions()
 
     def zero_grad(self):

@@ -423,6 +423,12 @@ int eg_pack_conv3x3_device(const float* w_oihw, int32_t cout, int32_t cin, int32
  * ldw = k rounded up to 64) from w [n][k] fp32 with row stride ld.  transpose != 0: the image of w^T (w is then [k][n]): dX = dY W. */
 int64_t eg_linear_packed_floats(int32_t n, int32_t k);
 int eg_pack_linear_device(const float* w, int32_t ld, int32_t n, int32_t k, int32_t transpose, float* image, void* stream);
+/* Every weight image of a training step in one launch.  `table`: device array of `count` 40-byte entries
+ *   { const float* src; float* image; int32_t kind, a, b, c, flag, first_block; }
+ * kind 0 = eg_pack_linear_device(src, ld = c, n = a, k = b, transpose = flag, image); kind 1 = eg_pack_conv3x3_device(src, cout = a, cin = b, flip = flag, image);
+ * first_block = sum of eg_pack_table_blocks(kind, a, b, flag) over the preceding entries, total_blocks = the sum over all. */
+int32_t eg_pack_table_blocks(int32_t kind, int32_t a, int32_t b, int32_t flag);
+int eg_pack_table(const void* table, int32_t count, int32_t total_blocks, void* stream);
 /* nn.Dropout in train() mode with a counter-based mask (nothing stored): keep(i) = hash(seed, offset + i) >= p, y = keep ? x/(1-p) : 0;
  * the backward pass is the same call on dy.  The mask stream is this library's own (not torch's RNG). */
 int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);

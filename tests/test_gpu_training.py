@@ -692,3 +692,41 @@ def test_eval_after_training_sees_the_updated_weights_and_statistics():
             want = fresh.to(DEV).eval()(g["spec"], g["text"], g["pre_pose"], None)[0]
         assert float((after - before).norm() / before.norm()) > 1e-3, graphed
         assert float((after - want).norm() / want.norm()) < 1e-6, graphed
+
+
+def test_resident_weight_images_match_per_use_packing():
+    """FlatParams.enable_weight_images(): all Linear / conv3x3 weight images of a step from one table-driven launch after the optimiser.  Three
+    bf16x3 steps with the resident images equal three steps with per-use packing bit for bit; a parameter changed behind the registry's back
+    (version mismatch) falls back to per-use packing instead of using a stale image."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    inp = synth_inputs(2, 34, 126, 4, seed=17)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    label = torch.tensor([0, 7], device=DEV)
+    finals = []
+    try:
+        F.set_precision("bf16x3")
+        for resident in (False, True):
+            model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+            fp = flatten_parameters(model)
+            images = fp.enable_weight_images() if resident else None
+            opt = FlatAdam(fp, lr=1e-3, betas=(0.5, 0.999))
+            for _ in range(3):
+                opt.zero_grad()
+                pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+                loss = F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, label))
+                loss.backward()
+                opt.step()
+            finals.append(fp.flat.clone())
+            if resident:
+                assert images.count > 100
+                w = model.post_projector[0].weight
+                assert images.lookup(w.detach(), 0, 0) is not None and images.lookup(w.detach(), 0, 1) is not None
+                with torch.no_grad():
+                    w.mul_(1.0)                                         # in-place torch op: version bump the registry has not seen
+                assert images.lookup(w.detach(), 0, 0) is None
+            F.register_weight_images(None)
+    finally:
+        F.set_precision("f32")
+        F.register_weight_images(None)
+    assert torch.equal(finals[0], finals[1])
