@@ -472,7 +472,19 @@ def _running_stats_written(bn):
     folded BatchNorm vectors on them), and count the batch as nn.BatchNorm does."""
     torch.autograd.graph.increment_version(bn.running_mean)
     torch.autograd.graph.increment_version(bn.running_var)
-    bn.num_batches_tracked += 1
+    _PENDING_COUNTERS.append(bn.num_batches_tracked)
+
+
+_PENDING_COUNTERS = []
+
+
+def flush_batch_counters() -> None:
+    """num_batches_tracked += 1 for every BatchNorm that ran since the last flush, as ONE multi-tensor launch (43 separate increments per
+    generator step otherwise).  train/nets.py calls it at the end of each network's forward; direct users of batch_norm() call it themselves
+    (or read the counters only after a forward of the nets)."""
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
 
 
 class _BatchNorm(torch.autograd.Function):

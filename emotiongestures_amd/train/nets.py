@@ -101,6 +101,7 @@ def emotion_net_forward(model, mfcc):
     for i in (0, 2, 4, 6, 8):
         lin = model.emotion_eocder_fc[i]
         h = F.linear(h, lin.weight, lin.bias, relu=True)
+    F.flush_batch_counters()
     return F.linear(h, model.last_fc.weight, model.last_fc.bias)
 
 
@@ -220,6 +221,7 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     dec_out = decoder_forward(model.decoder, prior, enc_out)
     pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
     _P["on"] = False
+    F.flush_batch_counters()
     return pose, emotion_feature, semantic_feature, emotion_prediction, text_embedding
 
 
@@ -255,4 +257,5 @@ def cvae_forward(vae, Input, y, eps):
     h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, D[6].weight, D[6].bias, 1, 1, 1), 0.2), D[8])
     h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, D[9].weight, D[9].bias, 1, 1, 1), 0.2), D[11])
     h = F.conv1d_cl(h, D[12].weight, D[12].bias, 1, 1, 1)
+    F.flush_batch_counters()
     return h.transpose(1, 2), mu_out, lv_out

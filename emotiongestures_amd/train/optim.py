@@ -29,6 +29,7 @@ class FlatParams:
         self.images: Optional[WeightImages] = None  # enable_weight_images(): all weight images of a step in one launch
         self.buffers: List[torch.Tensor] = []       # the model's buffers (BatchNorm running statistics): written by kernels, versions bumped with the parameters
         self.written = set()                        # parameters whose flat gradient slice a backward kernel already wrote this step
+        self._dirty, self._zeroed = set(), False        # flatten_parameters() allocates the buffer zeroed and says so
         for p, o in zip(params, offsets):           # the operators of train/functional.py write weight gradients straight into these slices
             p._eg_slot = grad[o:o + p.numel()].view(p.shape)
             p._eg_fp = self
@@ -65,10 +66,13 @@ class FlatParams:
         sl = self.grad[o:o + n]
         i = self.index[id(p)]
         if p.grad is None:
-            sl.zero_()                                   # keeps the flat buffer (and the all-reduce) well defined
+            if i in self._dirty or not self._zeroed:     # the flat buffer starts zeroed and nothing writes the slices of gradient-less parameters:
+                sl.zero_()                               # zero again only after a step that did write this one (dynamic graphs)
+                self._dirty.discard(i)
             self.has_grad[i] = False
             return
         self.has_grad[i] = True
+        self._dirty.add(i)
         if p.grad.data_ptr() != sl.data_ptr():
             sl.copy_(p.grad.reshape(-1))                 # data movement into the flat buffer
             p.grad = sl.view(p.shape)
@@ -97,6 +101,7 @@ def flatten_parameters(model: torch.nn.Module) -> FlatParams:
         p.data = flat[o:o + n].view(p.shape)
         p.grad = None
     fp = FlatParams(params, flat, grad, offsets)
+    fp._zeroed = True
     fp.buffers = [b for b in model.buffers() if b.is_floating_point()]
     return fp
 

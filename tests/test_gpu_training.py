@@ -88,6 +88,7 @@ def test_batchnorm_layernorm_se_attention():
         bn.weight, bn.bias = g, b
         return F.batch_norm(x, bn)
     _grad_check(hip, lambda x, g, b: TF.batch_norm(x.permute(0, 3, 1, 2), rm, rv, g, b, True, 0.1, 1e-5).permute(0, 2, 3, 1), [x, g, b])
+    F.flush_batch_counters()            # the increments of a forward are issued as one multi-tensor launch (the nets flush at their end)
     assert rel(bn.running_mean, rm) < 1e-6 and rel(bn.running_var, rv) < 1e-6 and int(bn.num_batches_tracked) == 1
     # LayerNorm
     x, g, b = T("x", (68, 512), -3, 3), T("g", (512,), 0.5, 1.5), T("b", (512,))
