@@ -771,7 +771,8 @@ __global__ __launch_bounds__(256) void seg_dot_kernel(const float* __restrict__ 
 }
 
 // ---- LayerNorm backward: one wave per row ----------------------------------------------------------------------------------
-// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  also writes t = dy * xhat (for dgamma = colsum(t)); dbeta = colsum(dy)
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  also writes xhat, so that ONE column reduction gives both affine gradients:
+// (dbeta, dgamma) = (sum dy, sum dy * xhat) = eg_colsum(dy, xhat)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                                                      float* __restrict__ dx, float* __restrict__ t, int rows, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     for (int i = lane; i < D; i += 64) {
         const float xh = (xr[i] - mean) * rstd;
         dx[(size_t)row * D + i] = rstd * (gamma[i] * dr[i] - a - xh * b);
-        t[(size_t)row * D + i] = dr[i] * xh;
+        t[(size_t)row * D + i] = xh;
     }
 }
 
@@ -1311,10 +1312,10 @@ extern "C" int eg_se_scale(const float* a, const float* gate, const float* add, 
     return eg_check_launch("se_scale");
 }
 
-extern "C" int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* dy_xhat, int32_t rows, int32_t d, float eps,
+extern "C" int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* xhat, int32_t rows, int32_t d, float eps,
                                      void* stream) {
-    EG_REQUIRE(x && dy && gamma && dx && dy_xhat && rows > 0 && d > 0, EG_ERR_BAD_ARG, "eg_layernorm_backward: bad argument");
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(eg_cdiv(rows, 4)), dim3(256), 0, ST, x, dy, gamma, dx, dy_xhat, rows, d, eps);
+    EG_REQUIRE(x && dy && gamma && dx && xhat && rows > 0 && d > 0, EG_ERR_BAD_ARG, "eg_layernorm_backward: bad argument");
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(eg_cdiv(rows, 4)), dim3(256), 0, ST, x, dy, gamma, dx, xhat, rows, d, eps);
     return eg_check_launch("layernorm_backward");
 }
 

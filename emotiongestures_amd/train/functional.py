@@ -660,8 +660,7 @@ class _LayerNorm(torch.autograd.Function):
         dx, t = torch.empty_like(x), torch.empty_like(x)
         L.check(lib.eg_layernorm_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(dx), _ptr(t), rows, D, float(ctx.eps), _stream(x.device)),
                 "eg_layernorm_backward")
-        dg, _ = raw_colsum(t.view(rows, D), out0=grad_out(ctx.params[0]))
-        db, _ = raw_colsum(dyd.view(rows, D), out0=grad_out(ctx.params[1]))
+        db, dg = raw_colsum(dyd.view(rows, D), t.view(rows, D), want1=True, out0=grad_out(ctx.params[1]), out1=grad_out(ctx.params[0]))   # t = xhat
         return dx, dg, db, None
 
 

@@ -437,8 +437,9 @@ int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint
 int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, float* workspace, void* stream);
 int eg_seg_dot(const float* dy, const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream);
 int eg_se_scale(const float* a, const float* gate, const float* add, float* y, int32_t batch, int32_t hw, int32_t c, void* stream);
-/* LayerNorm backward (SubLayers.py:55-57,80-82): dx and dy*xhat (dgamma = colsum(dy*xhat), dbeta = colsum(dy)) */
-int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* dy_xhat, int32_t rows, int32_t d, float eps,
+/* LayerNorm backward (SubLayers.py:55-57,80-82): dx and xhat; the affine gradients are one column reduction,
+ * (dbeta, dgamma) = (sum dy, sum dy*xhat) = eg_colsum(dy, xhat, dbeta, dgamma, ...) */
+int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* xhat, int32_t rows, int32_t d, float eps,
                           void* stream);
 /* ScaledDotProductAttention backward (Modules.py:13-23) from the forward's probabilities; Lq, Lk <= 64-ish (LDS-resident) */
 int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
