@@ -25,11 +25,25 @@ def pack_linear_weight(w: torch.Tensor, device) -> torch.Tensor:
     """nn.Linear weight [N,K] -> EG_PACK_LINEAR image on `device` (rows and K padded to 64)."""
     n, k = w.shape
     npad, kpad = (n + 63) // 64 * 64, (k + 63) // 64 * 64
+    if w.is_cuda and w.device == torch.device(device) and w.dtype == torch.float32:
+        # already resident: build the image on the device (bit-identical to the host packer, tests/test_gpu_training.py; the host path costs
+        # seconds for EmotionNet's 65536 x 4096 layer, e.g. at every validation after a training step)
+        lib = L.load()
+        wd = w.detach().contiguous()
+        img = torch.empty(int(lib.eg_linear_packed_floats(n, k)), dtype=torch.float32, device=wd.device)
+        L.check(lib.eg_pack_linear_device(_ptr(wd), k, n, k, 0, _ptr(img), _stream(wd.device)), "eg_pack_linear_device")
+        return img, npad, kpad
     return torch.from_numpy(packing._pack_linear(w.detach().cpu().float(), npad, kpad)).to(device), npad, kpad
 
 
 def pack_conv3x3_weight(w: torch.Tensor, device):
     opad = (w.shape[0] + 15) // 16 * 16
+    if w.is_cuda and w.device == torch.device(device) and w.dtype == torch.float32 and w.shape[1] % 8 == 0:
+        lib = L.load()
+        wd = w.detach().contiguous()
+        img = torch.empty(int(lib.eg_conv3x3_packed_floats(wd.shape[1], opad)), dtype=torch.float32, device=wd.device)
+        L.check(lib.eg_pack_conv3x3_device(_ptr(wd), wd.shape[0], wd.shape[1], 0, _ptr(img), _stream(wd.device)), "eg_pack_conv3x3_device")
+        return img, opad
     return torch.from_numpy(packing._pack_conv3x3(w.detach().cpu().float(), opad)).to(device), opad
 
 
