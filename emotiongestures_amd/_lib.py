@@ -100,6 +100,8 @@ SIGNATURES = {
     "eg_conv1d": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_contrastive_workspace_bytes": (C.c_int64, [_I]),
     "eg_contrastive_loss": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _L, _P]),
+    "eg_contrastive_backward_workspace_bytes": (_L, [_I]),
+    "eg_contrastive_loss_backward": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _L, _P]),
     # ---- training-path primitives (csrc/train.hip)
     "eg_transpose": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "eg_gemm_tn_workspace_floats": (_L, [_I, _I, _L]),

@@ -615,7 +615,136 @@ __global__ __launch_bounds__(256) void contrastive_mean_kernel(const float* __re
     for (int s = 128; s > 0; s >>= 1) { if (tid < s) { rl[tid] += rl[tid + s]; rh[tid] += rh[tid + s]; } __syncthreads(); }
     if (tid == 0) { *loss = rl[0] / (float)n; *acc = (float)rh[0] / (float)n; }
 }
+// ---- backward of the loss above --------------------------------------------------------------------------------------------
+// L = mean_i (logsumexp_j c_ij - c_ii), c_ij = max(1 / (D_ij + 1e-8), 1e-8), D_ij = || fh_i - ah_j ||, fh = f / max(||f||, 1e-12) (F.normalize).
+//   G_ij = (softmax_j(c_i.) - [i == j]) / n;   dc/dD = -c^2 (0 where the clamp is active);   dD/dfh_i = (fh_i - ah_j) / D (0 at D = 0, as torch.norm)
+//   W_ij = -G_ij c_ij^2 / D_ij;   g_fh_i = sum_j W_ij (fh_i - ah_j);   g_ah_j = -sum_i W_ij (fh_i - ah_j);   g_x = (g_xh - xh (xh . g_xh)) / ||x||
+// Three launches: the 2n inverse norms; one workgroup per row i (softmax of its row, W row, face gradient); one per column j (audio gradient).
+__global__ __launch_bounds__(256) void contrastive_norms_kernel(const float* __restrict__ face, const float* __restrict__ audio, int n, int d,
+                                                                float* __restrict__ inv) {
+    __shared__ float red[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* x = (r < n ? face + (size_t)r * d : audio + (size_t)(r - n) * d);
+    float part = 0.f;
+    for (int k = tid; k < d; k += 256) part += x[k] * x[k];
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    if (tid == 0) inv[r] = 1.f / fmaxf(sqrtf(red[0]), 1e-12f);
+}
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    return red[0];
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    return red[0];
+}
+__global__ __launch_bounds__(256) void contrastive_bwd_rows_kernel(const float* __restrict__ face, const float* __restrict__ audio,
+                                                                   const float* __restrict__ inv, int n, int d, float* __restrict__ Wm,
+                                                                   float* __restrict__ gface) {
+    extern __shared__ float sh[];                 // fh_i [d], then 256 reduction slots
+    float* f = sh;
+    float* red = sh + d;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float finv = inv[i];
+    for (int k = tid; k < d; k += 256) f[k] = face[(size_t)i * d + k] * finv;
+    __syncthreads();
+    float* wrow = Wm + (size_t)i * n;
+    // pass 1: c_ij -> wrow, D_ij is recomputed in pass 3 from c (D = 1/c - 1e-8 would lose bits: recompute the distance instead)
+    float vmax = -INFINITY;
+    for (int j = tid; j < n; j += 256) {
+        const float* a = audio + (size_t)j * d;
+        const float ainv = inv[n + j];
+        float dist = 0.f;
+        for (int k = 0; k < d; ++k) { const float t = f[k] - a[k] * ainv; dist += t * t; }
+        const float c = fmaxf(1.f / (sqrtf(dist) + 1e-8f), 1e-8f);
+        wrow[j] = c;
+        vmax = fmaxf(vmax, c);
+    }
+    const float m = block_max256(vmax, red);
+    float se = 0.f;
+    for (int j = tid; j < n; j += 256) se += expf(wrow[j] - m);
+    const float denom = block_sum256(se, red);
+    // pass 3: W_ij
+    float wsum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float* a = audio + (size_t)j * d;
+        const float ainv = inv[n + j];
+        float dist = 0.f;
+        for (int k = 0; k < d; ++k) { const float t = f[k] - a[k] * ainv; dist += t * t; }
+        const float D = sqrtf(dist), c = wrow[j];
+        const float G = (expf(c - m) / denom - (j == i ? 1.f : 0.f)) / (float)n;
+        const bool live = D > 0.f && (1.f / (D + 1e-8f)) > 1e-8f;
+        const float w = live ? -G * c * c / D : 0.f;
+        wrow[j] = w;
+        wsum += w;
+    }
+    const float Wi = block_sum256(wsum, red);       // also orders the wrow writes before the reads below
+    // g_fh[k] = fh[k] * sum_j W_ij - sum_j W_ij ah_j[k]; then through the normalisation
+    float dotp = 0.f;
+    for (int k = tid; k < d; k += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc += wrow[j] * audio[(size_t)j * d + k] * inv[n + j];
+        const float g = f[k] * Wi - acc;
+        gface[(size_t)i * d + k] = g;               // g_fh for now
+        dotp += f[k] * g;
+    }
+    const float dot = block_sum256(dotp, red);
+    for (int k = tid; k < d; k += 256) gface[(size_t)i * d + k] = (gface[(size_t)i * d + k] - f[k] * dot) * finv;
+}
+__global__ __launch_bounds__(256) void contrastive_bwd_cols_kernel(const float* __restrict__ face, const float* __restrict__ audio,
+                                                                   const float* __restrict__ inv, const float* __restrict__ Wm, int n, int d,
+                                                                   float* __restrict__ gaudio) {
+    extern __shared__ float sh[];
+    float* ah = sh;
+    float* red = sh + d;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const float ainv = inv[n + j];
+    for (int k = tid; k < d; k += 256) ah[k] = audio[(size_t)j * d + k] * ainv;
+    float ws = 0.f;
+    for (int i = tid; i < n; i += 256) ws += Wm[(size_t)i * n + j];
+    const float Wj = block_sum256(ws, red);
+    float dotp = 0.f;
+    for (int k = tid; k < d; k += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += Wm[(size_t)i * n + j] * face[(size_t)i * d + k] * inv[i];
+        const float g = ah[k] * Wj - acc;           // -sum_i W_ij (fh_i[k] - ah_j[k])
+        gaudio[(size_t)j * d + k] = g;
+        dotp += ah[k] * g;
+    }
+    const float dot = block_sum256(dotp, red);
+    for (int k = tid; k < d; k += 256) gaudio[(size_t)j * d + k] = (gaudio[(size_t)j * d + k] - ah[k] * dot) * ainv;
+}
 }  // namespace
+
+extern "C" int64_t eg_contrastive_backward_workspace_bytes(int32_t n) { return n > 0 ? ((int64_t)n * n + 2 * (int64_t)n) * 4 : 0; }
+// d loss / d face, d loss / d audio for an upstream gradient of 1 (scale afterwards).
+extern "C" int eg_contrastive_loss_backward(const float* face, const float* audio, int32_t n, int32_t d, float* gface, float* gaudio, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
+    EG_REQUIRE(face && audio && gface && gaudio && workspace, EG_ERR_BAD_ARG, "eg_contrastive_loss_backward: null pointer");
+    EG_REQUIRE(n >= 1 && n <= 4096 && d >= 1 && d <= 8192, EG_ERR_BAD_ARG, "eg_contrastive_loss_backward: n=%d d=%d out of range", n, d);
+    EG_REQUIRE(workspace_bytes >= eg_contrastive_backward_workspace_bytes(n), EG_ERR_WORKSPACE, "eg_contrastive_loss_backward: workspace %lld < %lld",
+               (long long)workspace_bytes, (long long)eg_contrastive_backward_workspace_bytes(n));
+    float* Wm = static_cast<float*>(workspace);
+    float* inv = Wm + (size_t)n * n;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(d + 256) * sizeof(float);
+    hipLaunchKernelGGL(contrastive_norms_kernel, dim3(2 * n), dim3(256), 0, st, face, audio, n, d, inv);
+    if (int rc = eg_check_launch("contrastive_norms")) return rc;
+    hipLaunchKernelGGL(contrastive_bwd_rows_kernel, dim3(n), dim3(256), lds, st, face, audio, inv, n, d, Wm, gface);
+    if (int rc = eg_check_launch("contrastive_bwd_rows")) return rc;
+    hipLaunchKernelGGL(contrastive_bwd_cols_kernel, dim3(n), dim3(256), lds, st, face, audio, inv, Wm, n, d, gaudio);
+    return eg_check_launch("contrastive_bwd_cols");
+}
 
 extern "C" int64_t eg_contrastive_workspace_bytes(int32_t n) { return n > 0 ? (int64_t)n * 8 : 0; }
 

@@ -133,7 +133,8 @@ class Motion_Discriminator(nn.Module):
     per-frame Linear+ReLU, 6-layer ReLU MLP -> [B, 1] logit (no sigmoid).  Its forward needs pose_dim == d_word_vec == d_model
     (the encoder adds a d_word_vec-wide table to the raw offsets and fc1 consumes the d_model-wide encoder output as if it were
     pose_dim wide), which the upstream defaults (128 vs 282) violate; the constructor refuses such a combination up front.
-    Forward only: backward kernels are not built."""
+    eval(): the inference kernels; train(): the differentiable operators of emotiongestures_amd/train (gradient goldens from the reference:
+    tests/golden/adv_grads.npz)."""
 
     def __init__(self, frames=59, pose_dim=282, src_pad_idx=1, trg_pad_idx=1, d_word_vec=128, d_model=128, d_inner=1024, n_layers=2,
                  n_head=8, d_k=64, d_v=64, dropout=0.2, n_position=59, *, precision="f32"):
@@ -154,10 +155,12 @@ class Motion_Discriminator(nn.Module):
         self._cache = _PackCache()
 
     def forward(self, x):
-        _eval_only(self)
         B, T, D = x.shape
         if T != self.frames or D != self.d_model:
             raise ValueError(f"Motion_Discriminator.forward: expected [B, {self.frames}, {self.d_model}], got {tuple(x.shape)}")
+        if self.training:           # train() mode: differentiable HIP operators (emotiongestures_amd/train), gradients for its parameters and for x
+            from .train import nets
+            return nets.motion_discriminator_forward(self, x)
         for layer in self.encoder.layer_stack:
             layer.slf_attn.precision = layer.pos_ffn.precision = self.precision
         enc, *_ = self.encoder(x.contiguous(), None)
@@ -169,7 +172,8 @@ class Motion_Discriminator(nn.Module):
 
 class SoftmaxContrastiveLoss(nn.Module):
     """test_emotion_gesture_diversity_iterative.py:80-127 on the GPU (eg_contrastive_loss: one workgroup per row, fixed-order
-    reductions).  forward -> scalar loss tensor; evaluate -> (accuracy, cross_dist [n, n]).  Forward values only (no autograd)."""
+    reductions).  forward -> scalar loss tensor (differentiable when an input requires a gradient: eg_contrastive_loss_backward);
+    evaluate -> (accuracy, cross_dist [n, n])."""
 
     def _run(self, face_feat, audio_feat, want_cross):
         if face_feat.dim() != 2 or face_feat.shape != audio_feat.shape:
@@ -200,6 +204,9 @@ class SoftmaxContrastiveLoss(nn.Module):
         if mode != "max":
             raise ValueError(mode)
         dev = torch.device(contrastive_device)
+        if torch.is_grad_enabled() and (face_feat.requires_grad or audio_feat.requires_grad):
+            from .train import functional as TF
+            return TF.contrastive_loss(face_feat.to(dev), audio_feat.to(dev)).reshape(())
         return self._run(face_feat.to(dev), audio_feat.to(dev), False)[0]
 
 

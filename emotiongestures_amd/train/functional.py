@@ -836,6 +836,43 @@ def kld_loss(mu, logvar, scale=1.0):
     return _KLD.apply(mu, logvar, scale)
 
 
+class _Contrastive(torch.autograd.Function):
+    """SoftmaxContrastiveLoss.forward (test_emotion_gesture_diversity_iterative.py:112-127, mode 'max') with its gradient."""
+
+    @staticmethod
+    def forward(ctx, face, audio):
+        lib = _lib()
+        f, a = _chk(face), _chk(audio)
+        n, d = f.shape
+        dev = f.device
+        res = torch.empty(2, device=dev)
+        nbytes = int(lib.eg_contrastive_workspace_bytes(n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.eg_contrastive_loss(_ptr(f), _ptr(a), n, d, None, _ptr(res[0:1]), _ptr(res[1:2]), _ptr(ws), nbytes, _stream(dev)), "eg_contrastive_loss")
+        ctx.save_for_backward(f, a)
+        return res[0:1].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        f, a = ctx.saved_tensors
+        n, d = f.shape
+        dev = f.device
+        gf, ga = torch.empty_like(f), torch.empty_like(a)
+        nbytes = int(lib.eg_contrastive_backward_workspace_bytes(n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.eg_contrastive_loss_backward(_ptr(f), _ptr(a), n, d, _ptr(gf), _ptr(ga), _ptr(ws), nbytes, _stream(dev)), "eg_contrastive_loss_backward")
+        gs = _chk(g).reshape(-1)
+        return raw_ew(EW_SCALE_DEV, gf, gs), raw_ew(EW_SCALE_DEV, ga, gs)
+
+
+def contrastive_loss(face_feat, audio_feat):
+    """SoftmaxContrastiveLoss()(face_feat, audio_feat, device) as a differentiable scalar ([1] tensor)."""
+    if face_feat.dim() != 2 or face_feat.shape != audio_feat.shape:
+        raise ValueError(f"contrastive_loss: expected two [n, d] tensors, got {tuple(face_feat.shape)} and {tuple(audio_feat.shape)}")
+    return _Contrastive.apply(face_feat, audio_feat)
+
+
 class _SmoothL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, beta, scale):

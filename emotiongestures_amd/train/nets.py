@@ -142,6 +142,19 @@ def encoder_forward(enc, x):
     return x
 
 
+def motion_discriminator_forward(md, x):
+    """Motion_Discriminator.forward (Models_spatial_memory.py:658-669) in train() mode: encoder over the motion offsets, per-frame
+    Linear + ReLU, 6-layer ReLU MLP -> [B, 1] logit.  x may require a gradient (the generator's adversarial term)."""
+    B, T, D = x.shape
+    _P["on"] = bool(getattr(md, "train_dropout", False))
+    enc = encoder_forward(md.encoder, x)
+    _P["on"] = False
+    h = F.linear(enc.reshape(B * T, D), md.fc1[0].weight, md.fc1[0].bias, relu=True).reshape(B, -1)
+    for i in (0, 2, 4, 6, 8):
+        h = F.linear(h, md.fc2[i].weight, md.fc2[i].bias, relu=True)
+    return F.linear(h, md.fc2[10].weight, md.fc2[10].bias)
+
+
 def decoder_forward(dec, trg, enc_out):
     uses = _fork_n(enc_out, 2 * len(dec.layer_stack))
     x = trg

@@ -344,6 +344,11 @@ int eg_conv1d(const float* x, const float* w, const float* bias, const float* sc
 int64_t eg_contrastive_workspace_bytes(int32_t n);
 int eg_contrastive_loss(const float* face, const float* audio, int32_t n, int32_t d, float* cross, float* loss, float* acc,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* Gradients of that loss (mode 'max') with respect to both feature sets, for an upstream gradient of 1: softmax of every row of cross_dist,
+ * back through 1/(D + 1e-8), the pairwise distances and F.normalize.  workspace >= eg_contrastive_backward_workspace_bytes(n). */
+int64_t eg_contrastive_backward_workspace_bytes(int32_t n);
+int eg_contrastive_loss_backward(const float* face, const float* audio, int32_t n, int32_t d, float* gface, float* gaudio, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
 
 
 /* ===================== training-path primitives (fp32, deterministic reductions) =====================

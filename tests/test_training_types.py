@@ -130,3 +130,68 @@ def test_gpu_motion_discriminator_matches_reference(prec, tol):
     assert np.abs(out.cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max())
     with pytest.raises(ValueError):
         md(off[:, :10])
+
+
+ADV = np.load(os.path.join(HERE, "golden", "adv_grads.npz"), allow_pickle=True)
+
+
+def _check_fingerprint(case, named_grads, tol):
+    worst = 0.0
+    for k, g in named_grads.items():
+        ref_norm = float(ADV[f"{case}/g/{k}/norm"])
+        gd = g.detach().reshape(-1).double().cpu().numpy()
+        stride = max(1, gd.size // 64)
+        samp = gd[::stride][:64]
+        ref = ADV[f"{case}/g/{k}/sample"].astype(np.float64)
+        err = max(abs(np.linalg.norm(gd) - ref_norm) / (ref_norm + 1e-30), np.abs(samp - ref).max() / (np.abs(ref).max() + 1e-30))
+        worst = max(worst, err)
+        assert err < tol, (k, err)
+    return worst
+
+
+@pytest.mark.gpu
+def test_gpu_motion_discriminator_training_gradients_match_reference():
+    """Motion_Discriminator in train() mode (dropout p = 0) on the differentiable HIP operators: logit, loss, every parameter gradient and the
+    input gradient against the REFERENCE's autograd (tests/golden/make_golden_adv_grad.py); the parameters the reference leaves without a
+    gradient (position embedding table, the encoder's unused final LayerNorm) get none here either."""
+    from emotiongestures_amd import harness as H
+    from emotiongestures_amd.train import functional as F
+    dev = torch.device("cuda:0")
+    md = _disc("f32").to(dev).train()
+    off = H.calc_motion(torch.from_numpy(_motion()).to(dev)).detach().requires_grad_(True)
+    logit = md(off)
+    np.testing.assert_allclose(logit.detach().cpu().numpy(), ADV["disc/logit"], rtol=2e-5, atol=2e-5)
+    loss = F.smooth_l1_loss(logit, torch.ones_like(logit), 1.0, 1.0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ADV["disc/loss"])) <= 1e-5 * abs(float(ADV["disc/loss"]))
+    nograd = sorted(k for k, p in md.named_parameters() if p.grad is None)
+    assert nograd == sorted(str(k) for k in ADV["disc/nograd"])
+    _check_fingerprint("disc", {k: p.grad for k, p in md.named_parameters() if p.grad is not None}, 2e-4)
+    gx = off.grad.reshape(-1).double().cpu().numpy()
+    ref = ADV["disc/dx/sample"].astype(np.float64)
+    assert abs(np.linalg.norm(gx) - float(ADV["disc/dx/norm"])) <= 2e-4 * float(ADV["disc/dx/norm"])
+    assert np.abs(gx[:: max(1, gx.size // 64)][:64] - ref).max() <= 2e-4 * np.abs(ref).max()
+    md.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(md(off.detach()).cpu().numpy(), G["motion_disc.out"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,n,d,corr", [("small", 12, 64, 0.5), ("wide", 300, 32, 0.2)])
+def test_gpu_contrastive_loss_gradients_match_reference(tag, n, d, corr):
+    """SoftmaxContrastiveLoss with inputs that require a gradient: the loss and both feature gradients against the REFERENCE's autograd
+    (softmax over 1/(distance + 1e-8), through the pairwise L2 distances and F.normalize)."""
+    from emotiongestures_amd import harness as H
+    dev = torch.device("cuda:0")
+    f, a = feats(tag, n, d, 3, corr)
+    ft, at = torch.from_numpy(f).to(dev).requires_grad_(True), torch.from_numpy(a).to(dev).requires_grad_(True)
+    loss = H.SoftmaxContrastiveLoss()(ft, at, dev)
+    assert abs(float(loss.detach()) - float(ADV[f"scl/{tag}/loss"])) <= 2e-5 * abs(float(ADV[f"scl/{tag}/loss"]))
+    (loss * 1.0).backward()
+    for nm, t in (("dface", ft.grad), ("daudio", at.grad)):
+        g = t.reshape(-1).double().cpu().numpy()
+        ref_norm = float(ADV[f"scl/{tag}/{nm}/norm"])
+        assert abs(np.linalg.norm(g) - ref_norm) <= 2e-4 * ref_norm, (nm, np.linalg.norm(g), ref_norm)
+        samp = g if n <= 16 else g[:: max(1, g.size // 256)][:256]
+        ref = ADV[f"scl/{tag}/{nm}/sample"].astype(np.float64)
+        assert np.abs(samp - ref).max() <= 5e-4 * np.abs(ref).max(), nm
