@@ -145,6 +145,7 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32 parity-mode leg and the sustained (>= 2 s) leg")
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
+    ap.add_argument("--no-train-legs", action="store_true", help="skip the two training legs (16 and 128 clips per step) of the default line")
     ap.add_argument("--fold-affine", action="store_true",
                     help="fold the Dropout-only Linear chains at pack time (fewer launches and FLOPs than the reference graph; reported in config)")
     ap.add_argument("--no-fuse-se", action="store_true", help="A/B: keep the SE tail of identity blocks as a separate pass (round-1 data flow)")
@@ -182,10 +183,32 @@ def self_launch(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(f"bench.py: worker ranks failed: {bad}")
+    # poll: the first worker that fails takes its siblings down (they would otherwise sit in the rendezvous / a collective until a timeout);
+    # an overall limit bounds the whole run.  Only the children this function started are signalled.
+    deadline = time.monotonic() + float(os.environ.get("EG_BENCH_TIMEOUT_S", "3600"))
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = (r, rcs[r])
+        if failed is not None or time.monotonic() > deadline:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            if failed is None:
+                raise SystemExit(f"bench.py: workers exceeded EG_BENCH_TIMEOUT_S; terminated (exit codes {rcs})")
+            raise SystemExit(f"bench.py: worker rank {failed[0]} failed with exit code {failed[1]}; siblings terminated (exit codes {rcs})")
+        time.sleep(0.05)
     return 0
 
 
@@ -204,17 +227,20 @@ def dry_worker(args, rank, world):
     return 0
 
 
-def train_worker(args, rank, world, dev, dist, backend):
-    """--train: data-parallel training step of the generator + emotion CVAE (SURVEY.md §8d cfg 3, §8e): every rank its own synthetic
-    clips, gradients averaged with bucketed all-reduces (emotiongestures_amd/train/optim.py).  The reported leg runs the arithmetic and
-    launch mode the flags name (default: split-bf16 MFMA, the step replayed from one captured hipGraph); `f32_eager` is the
-    gradient-parity configuration (fp32 operators issued through autograd) timed in the same run."""
+TRAIN_FLOP_PER_CLIP = 3.0 * FLOP_PER_CLIP      # forward + input gradients + weight gradients of the generator; CVAE and losses not counted
+
+
+def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=None, backend="nccl", segments=0):
+    """One timed configuration of the training step (generator + emotion CVAE: forward + 100*smooth_l1 + CE + backward + bucketed gradient
+    all-reduce + fused Adam on B clips per GPU).  precision: arithmetic of the convolutions / Linear products ("f32" = the gradient-parity
+    configuration); graph: replay the step from captured hipGraph(s) instead of issuing every kernel through autograd."""
+    from emotiongestures_amd import _lib
     from emotiongestures_amd.builders import build_mirror
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.synth import hash_unit, load_synth_weights, synth_inputs
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
-    B = args.train_batch
+    lib = _lib.load()
     inp = synth_inputs(B, 34, 126, 4, seed=2000 + rank)
     g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     target = torch.from_numpy((hash_unit("train.target_pose", B * 34 * 126, 2000 + rank) - 0.5).astype(np.float32).reshape(B, 34, 126)).to(dev)
@@ -227,82 +253,104 @@ def train_worker(args, rank, world, dev, dist, backend):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def leg(precision, graph):
-        F.set_precision(precision)
-        model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
-        vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
-        both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
-        fp = flatten_parameters(both)
-        fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
-        opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
-        gb = GradBuckets(fp, bucket_mb=25.0).attach()
-        ar_ms = []
+    F.set_precision(precision)
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
+    both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
+    fp = flatten_parameters(both)
+    fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
+    opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
+    gb = GradBuckets(fp, bucket_mb=25.0).attach()
+    ar_ms = []
 
-        def step(timed=True):
-            opt.zero_grad()
-            gb.begin()
-            pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
-            # the emotion CVAE learns to reconstruct the generator's emotion feature map under the clip's label (its eval-time role:
-            # sample(label) replaces that map, test_emotion_gesture_diversity_iterative.py:203-205)
-            rec, mu, logvar = vae(emo.detach(), g["label"], eps)
-            loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
-                         F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
-            loss.backward()
-            if not timed:                   # inside a stream capture: no timing events
-                gb.finish()
-                if world == 1:
-                    opt.step(collected=True)
-                return loss
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            gb.finish()                     # waits for the bucket all-reduces still running behind backward: the EXPOSED part
-            e1.record()
+    def forward_loss():
+        pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+        # the emotion CVAE learns to reconstruct the generator's emotion feature map under the clip's label (its eval-time role:
+        # sample(label) replaces that map, test_emotion_gesture_diversity_iterative.py:203-205)
+        rec, mu, logvar = vae(emo.detach(), g["label"], eps)
+        return F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
+                     F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
+
+    def step(timed=True):
+        opt.zero_grad()
+        gb.begin()
+        loss = forward_loss()
+        loss.backward()
+        if not timed:                   # inside a stream capture: no timing events
+            gb.finish()
             opt.step(collected=True)
-            ar_ms.append((e0, e1))
             return loss
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gb.finish()                     # waits for the bucket all-reduces still running behind backward: the EXPOSED part
+        e1.record()
+        opt.step(collected=True)
+        ar_ms.append((e0, e1))
+        return loss
 
-        run = step
-        if graph:
-            from emotiongestures_amd.train.graph import GraphedStep
-            if world == 1:
-                gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, args.warmup))
-                run = gs.run
-            else:                           # data parallel: forward + backward + collection replayed, the collective and Adam issued after it
-                gb.deferred = True
-                gs = GraphedStep(lambda _inputs: step(timed=False), g, None, warmup=max(1, args.warmup), device=dev)
+    # launches of the library per step, counted on one eager step (a captured step records the same launches once)
+    first_loss = float(step().detach())          # step 1 from the synthetic initial weights: comparable across precisions / launch modes
+    torch.cuda.synchronize(dev)
+    n0 = int(lib.eg_launch_count())
+    step()
+    torch.cuda.synchronize(dev)
+    launches = int(lib.eg_launch_count()) - n0
+    ar_ms.clear()
 
-                def run():
-                    loss = gs.run()
-                    gb.reduce_deferred()
-                    opt.step(collected=True)
-                    return loss
+    run = step
+    mode = "eager (autograd issues every kernel)"
+    if graph:
+        from emotiongestures_amd.train.graph import GraphedStep, SegmentedStep
+        if world == 1:
+            gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, warmup))
+            run = gs.run
+            mode = "one captured hipGraph per step"
+        else:
+            # data parallel: the step is cut into per-bucket graph segments (forward + the backward up to bucket 0 complete, then one segment per
+            # further bucket); bucket k's all-reduce runs on the side stream while segment k+1 replays, Adam follows the last reduction
+            gb.payload = os.environ.get("EG_GRAD_PAYLOAD", "f32")          # "bf16": buckets travel as bfloat16 (half the xGMI bytes)
+            ss = SegmentedStep(forward_loss, gb, opt, device=dev, warmup=max(1, warmup))
+            run = lambda: ss.run(exposed=ar_ms)
+            mode = f"{ss.n_segments} hipGraph segments per step, bucket all-reduces between them on a side stream ({gb.payload} payload)"
 
-        for _ in range(max(1, args.warmup)):
-            loss = run()
-        barrier()
-        ar_ms.clear()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = run()
-        barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms])) if ar_ms else None
-        out = {"value": round(B * world * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": precision,
-               "launch": "one captured hipGraph per step" if graph else "eager (autograd issues every kernel)", "final_loss": float(loss.detach()),
-               "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
-               "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
-        F.set_precision("f32")
-        F.register_weight_images(None)
-        return out
+    for _ in range(max(1, warmup)):
+        loss = run()
+    barrier()
+    ar_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = run()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms])) if ar_ms else None
+    value = B * world * steps / el
+    tf = value * TRAIN_FLOP_PER_CLIP / 1e12 / world
+    out = {"value": round(value, 2), "ms_per_step": round(el / steps * 1e3, 3), "dtype": precision, "clips_per_gpu_per_step": B,
+           "launch": mode, "library_launches_per_step": launches, "first_loss": first_loss, "final_loss": float(loss.detach()),
+           "algorithmic_tflops_per_gpu": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_TFLOPS["bf16x3" if precision != "f32" else "f32"], 4),
+           "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
+           "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
+    F.set_precision("f32")
+    F.register_weight_images(None)
+    del model, vae, both, fp, opt, gb
+    torch.cuda.empty_cache()
+    return out
 
-    main_leg = leg(args.train_precision, not args.no_train_graph)
+
+def train_worker(args, rank, world, dev, dist, backend):
+    """--train: data-parallel training step of the generator + emotion CVAE (SURVEY.md §8d cfg 3, §8e): every rank its own synthetic
+    clips, gradients averaged with bucketed all-reduces (emotiongestures_amd/train/optim.py).  The reported leg runs the arithmetic and
+    launch mode the flags name (default: split-bf16 MFMA, the step replayed from captured hipGraphs); `f32_eager` is the
+    gradient-parity configuration (fp32 operators issued through autograd) timed in the same run."""
+    B = args.train_batch
+    main_leg = train_leg(dev, B, args.train_precision, not args.no_train_graph, args.steps, args.warmup, rank, world, dist, backend)
     parity = None
     if not args.no_extra_legs and (args.train_precision != "f32" or not args.no_train_graph):
-        parity = leg("f32", False)
+        parity = train_leg(dev, B, "f32", False, args.steps, args.warmup, rank, world, dist, backend)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -316,7 +364,9 @@ def train_worker(args, rank, world, dev, dist, backend):
             "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
                        "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": nb},
-            "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"], "launch": main_leg["launch"]}
+            "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"], "launch": main_leg["launch"],
+            "library_launches_per_step": main_leg["library_launches_per_step"], "algorithmic_tflops_per_gpu": main_leg["algorithmic_tflops_per_gpu"],
+            "frac_of_mfma_peak": main_leg["frac_of_mfma_peak"]}
         if parity is not None:
             parity.pop("trainable_parameters"); parity.pop("buckets")
             line["f32_eager"] = parity
@@ -541,6 +591,16 @@ def main():
                 "flop_per_launch": flop,
                 "by_kernel_ms_per_step": {kernel_name(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())},
                 "by_kernel_tflops": {kernel_name(k): round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in sorted(contraction.items())}}
+        # the family that bounds the step: all 3x3 convolutions of the audio tower together (isolated per-launch times, summed per step)
+        conv_tags = [k for k in contraction if k >= 1000]
+        if conv_tags:
+            c_ms = sum(groups[k][0] for k in conv_tags) / args.steps
+            c_fl = sum(groups[k][2] * groups[k][3] for k in conv_tags) / args.steps
+            roof["conv_family"] = {"kernels": len(conv_tags), "launches_per_step": sum(groups[k][3] for k in conv_tags) // max(args.steps, 1),
+                                   "ms_per_step_isolated": round(c_ms, 4), "gflop_per_step": round(c_fl / 1e9, 1),
+                                   "achieved": round(c_fl / (c_ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(c_fl / (c_ms * 1e-3) / 1e12 / peak, 4), "share_of_step_flop": round(c_fl / (B * FLOP_PER_CLIP), 3)}
+        roof["step_frac_of_peak"] = round(value / world * FLOP_PER_CLIP / 1e12 / peak, 4)       # whole step: clips/s x 9.235 GFLOP over the dense MFMA peak
         # memory side of the one stage whose convolutions are traffic- rather than MFMA-limited (32 -> 32 channels at 128 x 124): algorithmic
         # bytes per launch (input + output map, + the residual for the conv2 launches: average of the block's two) over the measured duration
         c32 = 32 * 1000000 + 32 * 1000 + 100 + 1
@@ -551,6 +611,19 @@ def main():
             roof["hbm_view_conv32"] = {"bound": "hbm", "kernel": kernel_name(c32), "achieved": round(hb, 1), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(hb / 8000.0, 4), "algorithmic_bytes": int(alg), "traffic": measured_traffic(c32, args.precision),
                                        "avg_launch_ms": round(groups[c32][1], 4)}
+    # ---- training legs in the default line (BASELINE configs[2] on one GPU): 16 clips per step (the 8-GPU global-batch-128 share) and 128 ----
+    train = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.no_train_legs:
+        del step, pipe
+        torch.cuda.empty_cache()
+        train = {}
+        for tb in (16, 128):
+            rec = train_leg(dev, tb, "bf16x3", True, max(5, args.steps // 2), 3)
+            par = train_leg(dev, tb, "f32", False, 3, 1)
+            for k in ("trainable_parameters", "buckets", "allreduce_exposed_ms_per_step"):
+                rec.pop(k, None)
+            rec["f32_eager"] = {k: par[k] for k in ("value", "ms_per_step", "first_loss", "library_launches_per_step", "frac_of_mfma_peak")}
+            train[f"b{tb}"] = rec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_g, sd_v, inp)
 
@@ -569,7 +642,7 @@ def main():
                        "branch_streams": timed_concurrent, "fold_affine": bool(getattr(gen, "fold_affine", False)),
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
             "pose_rel_l2_vs_cpu_oracle": parity, "parity_clips_checked": B, "fgd_vs_cpu_oracle": fgd,
-            "lanes_bitwise_equal": lanes_equal, "sustained": sustained, "f32": f32, "extra_legs": extra, "roofline": roof, "cpu_baseline": cpu,
+            "lanes_bitwise_equal": lanes_equal, "sustained": sustained, "f32": f32, "extra_legs": extra, "train": train, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     return 0

@@ -47,6 +47,7 @@ _L = C.c_int64
 # (tests/test_abi.py cross-checks this table against the header).
 SIGNATURES = {
     "eg_last_error": (C.c_char_p, []),
+    "eg_launch_count": (_L, []),
     "eg_version": (C.c_char_p, []),
     "eg_set_default_precision": (C.c_int, [C.c_int]),
     "eg_get_default_precision": (C.c_int, []),
@@ -130,6 +131,7 @@ SIGNATURES = {
     "eg_pack_table_blocks": (_I, [_I, _I, _I, _I]),
     "eg_pack_table": (C.c_int, [_P, _I, _I, _P]),
     "eg_dropout": (C.c_int, [_P, _P, _L, C.c_float, C.c_uint32, C.c_uint64, _P]),
+    "eg_dropout_dev": (C.c_int, [_P, _P, _L, C.c_float, C.c_uint32, C.c_uint64, _P, _P]),
     "eg_seg_mean": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, _P, _P]),
     "eg_seg_dot": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "eg_se_scale": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -141,6 +143,8 @@ SIGNATURES = {
     "eg_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "eg_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "eg_counter_add": (C.c_int, [_P, _I, _P]),
+    "eg_f32_to_bf16": (C.c_int, [_P, _P, _L, _P]),
+    "eg_bf16_to_f32": (C.c_int, [_P, _P, _L, C.c_float, _P]),
 }
 
 _lib = None

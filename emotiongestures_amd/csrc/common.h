@@ -4,7 +4,17 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "emogest.h"
+
+// No packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel of the library: on MI355X a v_pk_fma_f32 whose operand
+// is routed by op_sel / op_sel_hi returns wrong lanes while another wave issues MFMAs on the same SIMD (tools/hazard_probe.hip,
+// profiles/r02_hazard_probe.txt); hipcc forms exactly that instruction from `float4 * scalar` code.  The target feature is
+// switched off for every function that follows, in the DEVICE pass only (the host pass does not know the feature);
+// tests/test_isa_gate.py disassembles the built library and fails on any packed-fp32 VALU.
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef short bf8 __attribute__((ext_vector_type(8)));   // 8 bf16 (one 16x16x32 MFMA operand)
@@ -21,8 +31,11 @@ void eg_set_error(const char* fmt, ...);
         }                                                \
     } while (0)
 
-// Launch check without synchronising (Guideline 9: nothing blocking in a launch function).
+// Launch check without synchronising (Guideline 9: nothing blocking in a launch function).  Every kernel launch of the library passes
+// through here: the counter behind eg_launch_count() (launches per step of a training / inference pass, reported by bench.py).
+extern std::atomic<long long> g_eg_launches;
 static inline int eg_check_launch(const char* what) {
+    g_eg_launches.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         eg_set_error("%s: %s", what, hipGetErrorString(e));

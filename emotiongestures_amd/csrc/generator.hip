@@ -20,6 +20,8 @@ void eg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* eg_last_error(void) { return g_err; }
+std::atomic<long long> g_eg_launches{0};
+extern "C" int64_t eg_launch_count(void) { return (int64_t)g_eg_launches.load(std::memory_order_relaxed); }
 extern "C" const char* eg_version(void) { return "emogest-hip 0.1 (gfx950)"; }
 static int g_default_precision = EG_PREC_F32;
 extern "C" int eg_set_default_precision(int p) {
@@ -984,3 +986,5 @@ extern "C" int eg_cvae_forward(const EgCvae* c, const float* A, int32_t n, const
     EG_TRY(egi_copy2d(P(ws, w.z), 32, P(ws, w.zy), 64, n, 32, st));
     return cvae_decode(c, A, w, ws, n, recon, st);
 }
+
+#include "common_tail.h"

@@ -716,9 +716,15 @@ __device__ __forceinline__ unsigned int mix32(unsigned int h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
+// `epoch` (optional, device resident): a per-step counter mixed into the seed, so that a step replayed from a captured hipGraph -- whose host
+// scalars (seed, offset) are frozen -- still draws a fresh mask every replay (train/graph.py increments it inside the graph).
+__device__ __forceinline__ unsigned int dropout_seed(unsigned int seed, const int* __restrict__ epoch) {
+    return epoch ? seed ^ mix32((unsigned int)*epoch * 0x9E3779B9u + 0x7F4A7C15u) : seed;
+}
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p, float inv_keep,
-                                                      unsigned int seed, unsigned long long offset) {
+                                                      unsigned int seed, unsigned long long offset, const int* __restrict__ epoch) {
     const unsigned int thr = (unsigned int)(p * 4294967296.0);
+    seed = dropout_seed(seed, epoch);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const unsigned long long ctr = offset + i;
         const unsigned int h = mix32(mix32((unsigned int)ctr ^ seed) + (unsigned int)(ctr >> 32) * 0x9E3779B9u + 0x6A09E667u);
@@ -973,6 +979,14 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
     }
 }
 __global__ void counter_add_kernel(int* c, int d) { *c += d; }
+
+// gradient-bucket payload conversion (train/optim.GradBuckets, payload "bf16"): fp32 -> bf16 (round to nearest even) and back (x scale)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = f32_to_bf16_rne(x[i]);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = bf16_to_f32(x[i]) * scale;
+}
 
 }  // namespace
 
@@ -1279,8 +1293,12 @@ extern "C" int eg_pack_table(const void* table, int32_t count, int32_t total_blo
 }
 
 extern "C" int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream) {
+    return eg_dropout_dev(x, y, n, p, seed, offset, nullptr, stream);
+}
+extern "C" int eg_dropout_dev(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, const int32_t* epoch_dev, void* stream) {
     EG_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, EG_ERR_BAD_ARG, "eg_dropout: bad argument (p=%f)", (double)p);
-    hipLaunchKernelGGL(dropout_kernel, grid1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n, p, 1.0f / (1.0f - p), seed, (unsigned long long)offset);
+    hipLaunchKernelGGL(dropout_kernel, grid1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n, p, 1.0f / (1.0f - p), seed, (unsigned long long)offset,
+                       epoch_dev);
     return eg_check_launch("dropout");
 }
 
@@ -1359,6 +1377,17 @@ extern "C" int eg_kld(const float* mu, const float* logvar, float* loss, float* 
     return eg_check_launch("kld");
 }
 
+extern "C" int eg_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
+    EG_REQUIRE(x && y && n > 0, EG_ERR_BAD_ARG, "eg_f32_to_bf16: bad argument");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, grid1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n);
+    return eg_check_launch("f32_to_bf16");
+}
+extern "C" int eg_bf16_to_f32(const uint16_t* x, float* y, int64_t n, float scale, void* stream) {
+    EG_REQUIRE(x && y && n > 0, EG_ERR_BAD_ARG, "eg_bf16_to_f32: bad argument");
+    hipLaunchKernelGGL(bf16_to_f32_kernel, grid1((size_t)n), dim3(256), 0, ST, x, y, (size_t)n, scale);
+    return eg_check_launch("bf16_to_f32");
+}
+
 extern "C" int eg_counter_add(int32_t* counter, int32_t delta, void* stream) {
     EG_REQUIRE(counter, EG_ERR_BAD_ARG, "eg_counter_add: null pointer");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ST, counter, delta);
@@ -1380,3 +1409,5 @@ extern "C" int eg_adam_step(float* param, const float* grad, float* exp_avg, flo
                        weight_decay, (float)bc1, (float)sqrt(bc2));
     return eg_check_launch("adam_step");
 }
+
+#include "common_tail.h"

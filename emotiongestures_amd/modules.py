@@ -258,6 +258,7 @@ class ScaledDotProductAttention(nn.Module):
     def __init__(self, temperature, attn_dropout=0.1):
         super().__init__()
         self.temperature = temperature
+        self.dropout_p = float(attn_dropout)        # Modules.py:11; acts only in train() mode with train_dropout (train/nets.py)
 
     def forward(self, q, k, v, mask=None):
         _eval_only(self)
@@ -283,6 +284,7 @@ class MultiHeadAttention(nn.Module):
         self.fc = Linear(n_head * d_v, d_model, bias=False)
         self.attention = ScaledDotProductAttention(temperature=d_k ** 0.5)
         self.layer_norm = LayerNormParams(d_model, eps=1e-6)
+        self.dropout_p = float(dropout)              # SubLayers.py:26
         self.precision = _DEFAULT_PRECISION
 
     def forward(self, q, k, v, mask=None):
@@ -304,6 +306,7 @@ class PositionwiseFeedForward(nn.Module):
         super().__init__()
         self.w_1, self.w_2 = Linear(d_in, d_hid), Linear(d_hid, d_in)
         self.layer_norm = LayerNormParams(d_in, eps=1e-6)
+        self.dropout_p = float(dropout)              # SubLayers.py:72
         self.precision = _DEFAULT_PRECISION
 
     def forward(self, x):
@@ -370,6 +373,7 @@ class Encoder(nn.Module):
         self.position_enc = PositionalEncoding(d_word_vec, n_position=n_position)
         self.layer_stack = nn.ModuleList([EncoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
         self.layer_norm = LayerNormParams(d_model, eps=1e-6)
+        self.dropout_p = float(dropout)              # Models_spatial_memory.py:407
 
     def forward(self, src_seq, src_mask, return_attns=False, global_feature=False):
         _eval_only(self)

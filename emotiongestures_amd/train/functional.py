@@ -92,12 +92,38 @@ def _pad_cols(t: torch.Tensor, mult=4) -> torch.Tensor:
 
 
 # ---- raw (non-autograd) kernels ---------------------------------------------------------------------------------------------
-_IMAGES = {"reg": None}
+_IMAGES = {"reg": []}
+
+
+class _ImageRegistry:
+    """Every registered optim.WeightImages (one per flattened model: generator, discriminator, ...), searched in registration order."""
+
+    def __init__(self, sets):
+        self.sets = sets
+
+    def lookup(self, w, kind, flag):
+        for reg in self.sets:
+            hit = reg.lookup(w, kind, flag)
+            if hit is not None:
+                return hit
+        return None
 
 
 def register_weight_images(images) -> None:
-    """optim.WeightImages of the model being trained (None: every use packs its own image)."""
-    _IMAGES["reg"] = images
+    """Add the optim.WeightImages of a model being trained (several models may be registered at once: the adversarial setup trains a
+    generator and a Motion_Discriminator side by side); None clears the registry (every use then packs its own image)."""
+    if images is None:
+        _IMAGES["reg"] = []
+    elif all(images is not r for r in _IMAGES["reg"]):
+        _IMAGES["reg"] = _IMAGES["reg"] + [images]
+
+
+def unregister_weight_images(images) -> None:
+    _IMAGES["reg"] = [r for r in _IMAGES["reg"] if r is not images]
+
+
+def _image_registry():
+    return _ImageRegistry(_IMAGES["reg"]) if _IMAGES["reg"] else None
 
 
 def _pack_linear(w, transpose=False):
@@ -106,7 +132,7 @@ def _pack_linear(w, transpose=False):
     lib = _lib()
     r, c = w.shape
     n, k = (c, r) if transpose else (r, c)
-    reg = _IMAGES["reg"]
+    reg = _image_registry()
     if reg is not None:
         img = reg.lookup(w, 0, int(transpose))
         if img is not None:
@@ -284,7 +310,7 @@ def leaky_relu(x, slope=0.2):
     return _Act.apply(x, float(slope))
 
 
-_DROP = {"seed": 0, "offset": 0}
+_DROP = {"seed": 0, "offset": 0, "epoch": None}
 
 
 def manual_seed(seed: int) -> None:
@@ -292,33 +318,59 @@ def manual_seed(seed: int) -> None:
     _DROP["seed"], _DROP["offset"] = int(seed) & 0xFFFFFFFF, 0
 
 
+def use_device_dropout_epoch(dev) -> torch.Tensor:
+    """Keep a per-step mask epoch on the device (an int32 counter mixed into the seed by the kernels).  `begin_dropout_step()` then rewinds
+    the host-side offset and increments the counter with a launch, so a step captured into a hipGraph draws a fresh mask at every replay
+    although its host scalars are frozen.  Returns the counter tensor."""
+    ep = _DROP.get("epoch")
+    if ep is None or ep.device != torch.device(dev):
+        ep = _DROP["epoch"] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return ep
+
+
+def begin_dropout_step() -> None:
+    """Start of a training step in device-epoch mode (no-op otherwise): offsets restart at 0, the device epoch advances by one."""
+    ep = _DROP.get("epoch")
+    if ep is not None:
+        _DROP["offset"] = 0
+        L.check(_lib().eg_counter_add(_ptr(ep), 1, _stream(ep.device)), "eg_counter_add")
+
+
+def next_dropout_offset(numel: int) -> int:
+    off = _DROP["offset"]
+    _DROP["offset"] = off + (int(numel) + 1023) // 1024 * 1024
+    return off
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed, offset):
+    def forward(ctx, x, p, seed, offset, epoch):
         lib = _lib()
         xd = _chk(x)
         y = torch.empty_like(xd)
-        L.check(lib.eg_dropout(_ptr(xd), _ptr(y), xd.numel(), float(p), seed, offset, _stream(xd.device)), "eg_dropout")
-        ctx.cfg = (float(p), seed, offset)
+        L.check(lib.eg_dropout_dev(_ptr(xd), _ptr(y), xd.numel(), float(p), seed, offset, _ptr(epoch), _stream(xd.device)), "eg_dropout")
+        ctx.cfg = (float(p), seed, offset, epoch)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib()
-        p, seed, offset = ctx.cfg
+        p, seed, offset, epoch = ctx.cfg
         d = _chk(dy)
         dx = torch.empty_like(d)
-        L.check(lib.eg_dropout(_ptr(d), _ptr(dx), d.numel(), p, seed, offset, _stream(d.device)), "eg_dropout")
-        return dx, None, None, None
+        L.check(lib.eg_dropout_dev(_ptr(d), _ptr(dx), d.numel(), p, seed, offset, _ptr(epoch), _stream(d.device)), "eg_dropout")
+        return dx, None, None, None, None
 
 
 def dropout(x, p: float):
     """nn.Dropout(p) in train() mode (p = 0: identity, no launch)."""
     if p <= 0.0:
         return x
-    off = _DROP["offset"]
-    _DROP["offset"] = off + (x.numel() + 1023) // 1024 * 1024
-    return _Dropout.apply(x, p, _DROP["seed"], off)
+    if x.is_cuda and torch.cuda.is_current_stream_capturing() and _DROP.get("epoch") is None:
+        # the (seed, offset) pair is a host scalar: frozen into a captured graph, every replay would apply the SAME mask
+        raise L.EgError("dropout inside a stream capture needs the device-resident mask epoch (functional.use_device_dropout_epoch); "
+                        "train/graph.GraphedStep enables it when told the model trains with dropout (stochastic=True)")
+    return _Dropout.apply(x, p, _DROP["seed"], next_dropout_offset(x.numel()), _DROP.get("epoch"))
 
 
 def _pack_conv(w, flip=False):
@@ -326,7 +378,7 @@ def _pack_conv(w, flip=False):
     lib = _lib()
     co, ci = w.shape[:2]
     cie, coe = (co, ci) if flip else (ci, co)
-    reg = _IMAGES["reg"]
+    reg = _image_registry()
     if reg is not None:
         hit = reg.lookup(w, 1, int(flip))
         if hit is not None:
@@ -473,6 +525,8 @@ def _running_stats_written(bn):
     torch.autograd.graph.increment_version(bn.running_mean)
     torch.autograd.graph.increment_version(bn.running_var)
     _PENDING_COUNTERS.append(bn.num_batches_tracked)
+    if len(_PENDING_COUNTERS) >= 512:       # direct users of batch_norm() that never flush: bound the list (the nets flush once per forward)
+        flush_batch_counters()
 
 
 _PENDING_COUNTERS = []

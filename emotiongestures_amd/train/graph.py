@@ -4,8 +4,10 @@ A training step is ~2 300 small launches issued through autograd; below ~64 clip
 is slower than the GPU.  `GraphedStep` captures forward + backward + gradient collection + Adam once (torch.cuda.graph: stream capture,
 allocations from a private pool) and replays it per step: HIP graphs instead of a tracing compiler, the MI355X-native answer to a
 launch-bound loop.  Everything that varies between steps lives in device memory: the inputs (static tensors refreshed with `copy_`), the
-Adam step count (`FlatAdam.use_device_step`), BatchNorm's running statistics.  Host scalars are frozen at capture, so stochastic dropout
-(host-side mask counter) cannot be active inside a graphed step.
+Adam step count (`FlatAdam.use_device_step`), BatchNorm's running statistics, and -- `stochastic=True`, for models that train with
+`train_dropout` -- the dropout mask epoch (`functional.use_device_dropout_epoch`: a counter the captured step increments itself, so every
+replay draws a fresh mask although the host-side (seed, offset) scalars are frozen at capture).  A dropout call inside a capture without
+that epoch raises (functional.dropout).
 """
 from __future__ import annotations
 
@@ -14,13 +16,13 @@ from typing import Callable, Dict
 import torch
 
 from .. import _lib as L
-from . import nets
+from . import functional as F
 from .optim import FlatAdam
 
 
 class GraphedStep:
     def __init__(self, step_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], inputs: Dict[str, torch.Tensor], optimizer: FlatAdam = None,
-                 warmup: int = 3, device=None):
+                 warmup: int = 3, device=None, stochastic: bool = False):
         """step_fn(inputs) runs zero_grad, forward, backward, the gradient collection and -- when `optimizer` is given -- optimizer.step(),
         and returns the loss tensor.  `inputs` are the static device tensors the captured graph reads; `run(new_inputs)` copies fresh
         values into them.  Data parallel: capture forward + backward + collection only (optimizer=None, GradBuckets.deferred = True) and run
@@ -28,8 +30,8 @@ class GraphedStep:
         dev = optimizer.fp.flat.device if optimizer is not None else torch.device(device)
         if dev.type != "cuda":
             raise L.EgError("GraphedStep: needs a GPU")
-        if nets._P["on"]:
-            raise L.EgError("GraphedStep: stochastic dropout keeps its mask counter on the host and cannot be captured")
+        if stochastic:                              # the model trains with dropout: the mask epoch moves to the device BEFORE the warm-up steps
+            F.use_device_dropout_epoch(dev)
         self.inputs, self.opt = inputs, optimizer
         if optimizer is not None:
             optimizer.use_device_step()
@@ -45,6 +47,11 @@ class GraphedStep:
             self.loss = step_fn(inputs)
         if optimizer is not None:
             optimizer.t -= 1                        # the capture recorded a step without executing it
+        # The captured kernels hold raw pointers into the shared scratch buffers of train/functional.py (split-K / column-reduction / wgrad
+        # partials).  A later, larger eager request replaces such a buffer in the registry; keep the ones this graph was captured with alive
+        # for as long as the graph exists, or the caching allocator would hand their memory to someone else under a replay.
+        self._scratch_keep = dict(F._WS)
+        self._images_refreshed = F.get_precision() != "f32"        # FlatAdam.step refreshes the weight images only for the split-bf16 operators
 
     def run(self, new_inputs: Dict[str, torch.Tensor] = None) -> torch.Tensor:
         if new_inputs:
@@ -53,5 +60,162 @@ class GraphedStep:
         self.graph.replay()
         if self.opt is not None:
             self.opt.t += 1
-            self.opt.fp.bump_versions()             # the replay rewrote parameters and running statistics without passing through torch
+            self.opt.fp.bump_versions(images_fresh=self._images_refreshed)      # the replay rewrote parameters / running statistics behind torch's back
+        return self.loss
+
+
+class SegmentedStep:
+    """A data-parallel training step as a few captured hipGraph segments with the bucket all-reduces BETWEEN them.
+
+    With more than one rank a single graph of forward + backward leaves the whole gradient reduction exposed behind the replay.  Here the
+    backward is cut at the tower output (train/nets.CutContext): segment 0 = forward + the backward of everything behind the audio tower
+    (post-projector, decoder, encoder, heads, projections: ~94 % of the gradient bytes, ~40 % of the backward time); segment 1 = the tower's
+    backward.  After segment 0 replays, the buckets it completed are all-reduced on a side stream WHILE segment 1 replays on the main stream;
+    the buckets of segment 1 follow, then the tail graph (1/world scaling, fused Adam, weight-image refresh).  The collectives stay outside
+    the graphs (RCCL launches issued by torch.distributed on the side stream), so the same code runs over gloo in the tests.
+
+    loss_fn() runs the train-mode forward and returns the loss tensor (no zero_grad / backward / optimiser calls inside).
+    use_graphs=False issues the same phases eagerly (the CPU test of the bucket ordering; also the fallback while debugging)."""
+
+    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower",), warmup: int = 3, use_graphs: bool = True):
+        from . import nets
+        self.loss_fn, self.gb, self.opt, self.nets = loss_fn, buckets, optimizer, nets
+        self.ctx = nets.CutContext(cuts)
+        self.use_graphs = bool(use_graphs)
+        self.dev = torch.device(device) if device is not None else buckets.fp.grad.device
+        self.gb.deferred = True                                   # hooks only collect and record completion order; this class issues the collectives
+        self.side = torch.cuda.Stream(self.dev) if self.dev.type == "cuda" else None
+        self.ready = []                                           # per phase: buckets completed by that phase (recorded at the first run)
+        self.loss = None
+        self.graphs = None
+        if self.use_graphs:
+            if self.dev.type != "cuda":
+                raise L.EgError("SegmentedStep(use_graphs=True): needs a GPU")
+            optimizer.use_device_step()
+            warm = torch.cuda.Stream(self.dev)
+            warm.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(warm):
+                for _ in range(max(1, warmup)):
+                    self._eager_step()
+            torch.cuda.current_stream(self.dev).wait_stream(warm)
+            torch.cuda.synchronize(self.dev)
+            self._capture()
+        self.n_segments = (len(self.graphs) - 1) if self.graphs else None
+
+    # ---- the phases -------------------------------------------------------------------------------------------------
+    def _phase0(self):
+        self.opt.zero_grad()
+        self.gb.begin()
+        self.ctx.reset()
+        self.nets._CUTS["ctx"] = self.ctx
+        try:
+            self.loss = self.loss_fn()
+        finally:
+            self.nets._CUTS["ctx"] = None
+        self.loss.backward()
+        return list(self.gb.launched)
+
+    def _phase_cut(self, i):
+        before = len(self.gb.launched)
+        _name, x, leaf = self.ctx.cuts[len(self.ctx.cuts) - 1 - i]
+        x.backward(leaf.grad)
+        return list(self.gb.launched[before:])
+
+    def _phase_last_collect(self):
+        before = len(self.gb.launched)
+        self.gb.finish()                                          # deferred: zero-fills gradient-less slices, completes their buckets, no collective, no scaling
+        return list(self.gb.launched[before:])
+
+    def _tail(self):
+        self.gb._scale()
+        self.opt.step(collected=True)
+
+    def _reduce(self, bucket_ids):
+        for b in bucket_ids:
+            self.gb.reduce_bucket(b)
+
+    def _eager_step(self, exposed=None):
+        cur = torch.cuda.current_stream(self.dev) if self.side is not None else None
+        ready = [self._phase0()]
+        n_cuts = len(self.ctx.cuts)
+        for i in range(n_cuts):
+            self._overlap(ready[-1], cur)
+            ready.append(self._phase_cut(i))
+        ready[-1] = ready[-1] + self._phase_last_collect()
+        self._join(ready[-1], cur, exposed)
+        self._tail()
+        self.ready = ready
+        return self.loss
+
+    def _overlap(self, bucket_ids, cur):
+        """Reduce `bucket_ids` on the side stream; the caller goes on issuing the next phase on the main stream."""
+        if self.side is None:
+            self._reduce(bucket_ids)
+            return
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self._reduce(bucket_ids)
+
+    def _join(self, bucket_ids, cur, exposed):
+        """After the last phase: wait for the overlapped reductions, reduce what the last phase completed.  `exposed`: list receiving an event
+        pair around this (the part of the gradient reduction that is NOT hidden behind compute)."""
+        ev = None
+        if exposed is not None and self.side is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if self.side is not None:
+            cur.wait_stream(self.side)
+        self._reduce(bucket_ids)
+        if ev is not None:
+            ev[1].record()
+            exposed.append(ev)
+
+    # ---- capture / replay -------------------------------------------------------------------------------------------
+    def _capture(self):
+        pool = torch.cuda.graph_pool_handle()
+        graphs, ready = [], []
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, pool=pool):
+            ready.append(self._phase0())
+        graphs.append(g0)
+        n_cuts = len(self.ctx.cuts)
+        for i in range(n_cuts):
+            gi = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gi, pool=pool):
+                r = self._phase_cut(i)
+                if i == n_cuts - 1:
+                    r = r + self._phase_last_collect()
+            graphs.append(gi)
+            ready.append(r)
+        if n_cuts == 0:
+            ready[-1] = ready[-1] + self._phase_last_collect_captured(pool, graphs)
+        gt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gt, pool=pool):
+            self._tail()
+        graphs.append(gt)
+        self.opt.t -= 1                                           # the capture recorded an optimiser step without executing it
+        self.graphs, self.ready = graphs, ready
+        self._scratch_keep = dict(F._WS)
+        self._images_refreshed = F.get_precision() != "f32"
+
+    def _phase_last_collect_captured(self, pool, graphs):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            r = self._phase_last_collect()
+        graphs.append(g)
+        return r
+
+    def run(self, exposed=None):
+        if not self.use_graphs:
+            return self._eager_step(exposed)
+        cur = torch.cuda.current_stream(self.dev)
+        body = self.graphs[:-1]
+        for i, g in enumerate(body):
+            g.replay()
+            if i + 1 < len(body) and i < len(self.ready) - 1:
+                self._overlap(self.ready[i], cur)
+        self._join(self.ready[-1], cur, exposed)
+        self.graphs[-1].replay()
+        self.opt.t += 1
+        self.opt.fp.bump_versions(images_fresh=self._images_refreshed)
         return self.loss

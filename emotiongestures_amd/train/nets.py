@@ -29,6 +29,42 @@ def _dp(x, p):
     return F.dropout(x, p) if _P["on"] else x
 
 
+def _dropout_on(model) -> None:
+    """Entry of a network's train-mode forward: activate the Dropout placements when the model asks for them, and start a new mask epoch
+    (functional.begin_dropout_step: a no-op unless the device-resident epoch is in use, e.g. under train/graph.GraphedStep)."""
+    _P["on"] = bool(getattr(model, "train_dropout", False))
+    if _P["on"]:
+        F.begin_dropout_step()
+
+
+# Cut sites of a segmented training step (train/graph.SegmentedStep): at a named site the activation is detached and a fresh leaf carries the
+# forward on, so the backward runs in phases -- loss.backward() stops at the leaves, then each cut continues with x.backward(leaf.grad) --
+# and the gradient buckets completed by one phase are all-reduced while the next phase computes.  No arithmetic: a detach and a .grad hand-over.
+# A site is only valid where every parameter's gradient and the leaf's gradient are completed within ONE phase: the tower output is (everything
+# upstream of it is the tower alone); the encoder output is not (the emotion head reaches emotion_proj / fc1 / fc2 past it in another phase).
+_CUTS = {"ctx": None}
+
+
+class CutContext:
+    def __init__(self, names=("tower",)):
+        self.names, self.cuts = tuple(names), []
+
+    def reset(self):
+        self.cuts = []
+
+    def cut(self, name, x):
+        if name not in self.names or not x.requires_grad:
+            return x
+        leaf = x.detach().requires_grad_(True)
+        self.cuts.append((name, x, leaf))
+        return leaf
+
+
+def _cut(name, x):
+    ctx = _CUTS["ctx"]
+    return x if ctx is None else ctx.cut(name, x)
+
+
 def _fork_n(x, n):
     """n uses of x, gradients summed pairwise on the HIP add kernel."""
     outs = []
@@ -113,13 +149,13 @@ def mha_forward(m, xq, xk, xv):
     k = F.linear(xk, m.w_ks.weight)
     v = F.linear(xv, m.w_vs.weight)
     o = F.attention(q, k, v, m.n_head)
-    return F.layer_norm(F.add(_dp(F.linear(o, m.fc.weight), 0.2), xq_r), m.layer_norm)      # q = self.dropout(self.fc(q)) (SubLayers.py:54)
+    return F.layer_norm(F.add(_dp(F.linear(o, m.fc.weight), m.dropout_p), xq_r), m.layer_norm)      # q = self.dropout(self.fc(q)) (SubLayers.py:54)
 
 
 def ffn_forward(f, x):
     xa, xr = F.fork(x)
     h = F.linear(xa, f.w_1.weight, f.w_1.bias, relu=True)
-    return F.layer_norm(F.add(_dp(F.linear(h, f.w_2.weight, f.w_2.bias), 0.2), xr), f.layer_norm)         # SubLayers.py:79
+    return F.layer_norm(F.add(_dp(F.linear(h, f.w_2.weight, f.w_2.bias), f.dropout_p), xr), f.layer_norm)         # SubLayers.py:79
 
 
 class _AddRows(torch.autograd.Function):
@@ -135,7 +171,7 @@ class _AddRows(torch.autograd.Function):
 
 
 def encoder_forward(enc, x):
-    x = _dp(_AddRows.apply(x, enc.position_enc.pos_table[0, :x.shape[1]].contiguous()), 0.2)        # Models_spatial_memory.py:422
+    x = _dp(_AddRows.apply(x, enc.position_enc.pos_table[0, :x.shape[1]].contiguous()), enc.dropout_p)        # Models_spatial_memory.py:422
     for layer in enc.layer_stack:
         a, b, c = _fork_n(x, 3)
         x = ffn_forward(layer.pos_ffn, mha_forward(layer.slf_attn, a, b, c))
@@ -146,9 +182,11 @@ def motion_discriminator_forward(md, x):
     """Motion_Discriminator.forward (Models_spatial_memory.py:658-669) in train() mode: encoder over the motion offsets, per-frame
     Linear + ReLU, 6-layer ReLU MLP -> [B, 1] logit.  x may require a gradient (the generator's adversarial term)."""
     B, T, D = x.shape
-    _P["on"] = bool(getattr(md, "train_dropout", False))
-    enc = encoder_forward(md.encoder, x)
-    _P["on"] = False
+    _dropout_on(md)
+    try:
+        enc = encoder_forward(md.encoder, x)
+    finally:
+        _P["on"] = False
     h = F.linear(enc.reshape(B * T, D), md.fc1[0].weight, md.fc1[0].bias, relu=True).reshape(B, -1)
     for i in (0, 2, 4, 6, 8):
         h = F.linear(h, md.fc2[i].weight, md.fc2[i].bias, relu=True)
@@ -185,7 +223,7 @@ def prior_encoder_forward(pe, prior):
 
 def audio_encoder_forward(ae, spec):
     """Audio_ResNetEncoder.forward (Models_spatial_memory.py:118-133)."""
-    x = resnetse_forward(ae.feat_extractor, spec)                                # [B,32,31,128]
+    x = _cut("tower", resnetse_forward(ae.feat_extractor, spec))                 # [B,32,31,128]; the tower's backward is 60 % of the step and holds 6 % of the gradient bytes
     x = F.batch_norm(F.conv3x3(x, ae.final_conv1.weight, ae.final_conv1.bias), ae.bn1)          # [B,H,W,F]
     B, H, W, Fr = x.shape
     x = x.permute(0, 3, 1, 2).reshape(B, Fr, H * W)                              # channel c becomes time step c (:124)
@@ -216,25 +254,27 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     (:577,616), so it is evaluated without gradient on the inference kernels."""
     if model._variant != "spatial":
         raise NotImplementedError("train-mode forward: Models_spatial_memory variant only (TM_Memory_Net couples the batch)")
-    _P["on"] = bool(getattr(model, "train_dropout", False))
-    text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
-    spectrum_feature = audio_encoder_forward(model.audio_encoder, input_spectrum)
-    prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
-    sa, sb = F.fork(spectrum_feature)
-    emotion_feature = _seq_linear(model.emotion_proj, (0, 2), sa, drop=0.2)
-    semantic_feature = _seq_linear(model.semantic_proj, (0, 2), sb, drop=0.2)
-    B = emotion_feature.shape[0]
-    if sampled_emotion_feature is None:
-        e_cls, e_fus = F.fork(emotion_feature)
-    else:
-        e_cls, e_fus = emotion_feature, sampled_emotion_feature
-    emotion_prediction = _seq_linear(model.emotion_classifer_header, (0, 2, 4, 6), e_cls.reshape(B, -1), relu_between=True)
-    fusion = _seq_linear(model.fusion_proj, (0, 2), F.add(e_fus, semantic_feature), relu_between=True)
-    enc_out = encoder_forward(model.encoder, fusion)
-    dec_out = decoder_forward(model.decoder, prior, enc_out)
-    pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
-    _P["on"] = False
-    F.flush_batch_counters()
+    _dropout_on(model)
+    try:
+        text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
+        spectrum_feature = audio_encoder_forward(model.audio_encoder, input_spectrum)
+        prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
+        sa, sb = F.fork(spectrum_feature)
+        emotion_feature = _seq_linear(model.emotion_proj, (0, 2), sa, drop=0.2)
+        semantic_feature = _seq_linear(model.semantic_proj, (0, 2), sb, drop=0.2)
+        B = emotion_feature.shape[0]
+        if sampled_emotion_feature is None:
+            e_cls, e_fus = F.fork(emotion_feature)
+        else:
+            e_cls, e_fus = emotion_feature, sampled_emotion_feature
+        emotion_prediction = _seq_linear(model.emotion_classifer_header, (0, 2, 4, 6), e_cls.reshape(B, -1), relu_between=True)
+        fusion = _seq_linear(model.fusion_proj, (0, 2), F.add(e_fus, semantic_feature), relu_between=True)
+        enc_out = encoder_forward(model.encoder, fusion)
+        dec_out = decoder_forward(model.decoder, prior, enc_out)
+        pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
+    finally:
+        _P["on"] = False
+        F.flush_batch_counters()
     return pose, emotion_feature, semantic_feature, emotion_prediction, text_embedding
 
 

@@ -7,9 +7,9 @@
   uses lr, betas=(0.5, 0.999), weight_decay=1e-5) as one fused HIP kernel over the flat buffers (eg_adam_step).
 * `GradBuckets`: clip-level data parallelism: gradients are summed across ranks with `all_reduce` on ~25 MB
   contiguous buckets of the flat gradient buffer, launched from the LAST parameters backwards (the order backward produces
-  them) on a side stream so that the reduction of finished buckets overlaps the rest of the backward pass; the result is
-  divided by the world size in the Adam kernel's gradient (the `grad_scale` argument).  BatchNorm statistics stay per replica,
-  as with the reference's plain nn.BatchNorm under nn.DataParallel.
+  them) on a side stream so that the reduction of finished buckets overlaps the rest of the backward pass; the sum is then
+  divided by the world size with one HIP elementwise launch over the flat gradient (`_scale`).  BatchNorm statistics stay per
+  replica, as with the reference's plain nn.BatchNorm under nn.DataParallel.
 """
 from __future__ import annotations
 
@@ -49,15 +49,16 @@ class FlatParams:
         F.register_weight_images(self.images)
         return self.images
 
-    def bump_versions(self):
+    def bump_versions(self, images_fresh: bool = True):
         """The optimiser and the BatchNorm kernels write parameters / running statistics through raw pointers: tell torch (`_version`) so
-        that everything keyed on it -- the inference engines' packed-weight caches -- sees the change."""
+        that everything keyed on it -- the inference engines' packed-weight caches -- sees the change.  images_fresh: the caller rebuilt the
+        weight images from the values just written (False: they are stale now; lookups miss until the next refresh)."""
         for t, updated in zip(self.params, self.has_grad):
             if updated:                             # parameters without a gradient are skipped by the optimiser (torch.optim.Adam semantics): unchanged
                 torch.autograd.graph.increment_version(t)
         for t in self.buffers:
             torch.autograd.graph.increment_version(t)
-        if self.images is not None:
+        if self.images is not None and images_fresh:
             self.images.mark_fresh()                # the caller refreshed them from the values just written (FlatAdam.step / the captured graph)
 
     def collect_one(self, p: torch.nn.Parameter):
@@ -214,9 +215,11 @@ class FlatAdam:
             L.check(lib.eg_adam_step(_ptr(fp.flat[sl]), _ptr(fp.grad[sl]), _ptr(self.exp_avg[sl]), _ptr(self.exp_avg_sq[sl]), hi - lo,
                                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                      self.t, _stream(fp.flat.device)), "eg_adam_step")
-        if fp.images is not None:
+        from . import functional as F
+        refresh = fp.images is not None and F.get_precision() != "f32"      # the fp32 operators never read the images
+        if refresh:
             fp.images.refresh()                     # one launch: every weight image of the next step, from the values just written
-        fp.bump_versions()
+        fp.bump_versions(images_fresh=refresh)      # not refreshed: a later bf16x3 use sees a stale version and packs its own image
 
     def zero_grad(self):
         self.fp.zero_grad()
@@ -248,6 +251,8 @@ class GradBuckets:
         self._unused: Optional[set] = None      # parameters that received no gradient in the first backward (static graph)
         self.launched: List[int] = []           # bucket launch order of the last backward (tests)
         self.deferred = False                   # True: the hooks only collect (a captured hipGraph holds forward + backward); reduce_deferred() follows the replay
+        self.payload = "f32"                    # "bf16": buckets travel as bfloat16 (reduce_bucket)
+        self._stage = {}
 
     def bucket_of(self, offset: int) -> int:
         for i, (lo, hi) in enumerate(self.buckets):
@@ -296,7 +301,9 @@ class GradBuckets:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(g.device))
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                self.reduce_bucket(b)
+        elif self.payload == "bf16":
+            self.reduce_bucket(b)
         else:
             self._handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -322,11 +329,36 @@ class GradBuckets:
 
     def reduce_deferred(self):
         """After a replayed forward + backward (deferred mode): the bucket all-reduces in backward order on the caller's stream, then 1/world."""
-        import torch.distributed as dist
         if self.world > 1:
-            for lo, hi in self.buckets:
-                dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            for b in range(len(self.buckets)):
+                self.reduce_bucket(b)
         self._scale()
+
+    def reduce_bucket(self, b: int):
+        """all_reduce(SUM) of bucket b on the CURRENT stream (train/graph.SegmentedStep issues it on its side stream while the next graph
+        segment replays).  `payload = "bf16"`: the bucket travels as bfloat16 -- half the bytes on the xGMI links -- through a staging buffer
+        (fp32 -> bf16 -> all_reduce -> fp32: two HIP conversion launches; the sum itself is then taken in bf16 by the collective: every
+        gradient element carries a relative error of ~2^-9 per addend, measured in tests/test_gpu_training.py)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        lo, hi = self.buckets[b]
+        g = self.fp.grad[lo:hi]
+        if self.payload != "bf16":
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        st = self._stage.get(b)
+        if st is None:
+            st = self._stage[b] = torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device)
+        if g.is_cuda:
+            lib = L.load()
+            L.check(lib.eg_f32_to_bf16(_ptr(g), _ptr(st), hi - lo, _stream(g.device)), "eg_f32_to_bf16")
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            L.check(lib.eg_bf16_to_f32(_ptr(st), _ptr(g), hi - lo, 1.0, _stream(g.device)), "eg_bf16_to_f32")
+        else:                                               # CPU only exists for the gloo test of the bucket logic
+            st.copy_(g)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            g.copy_(st)
 
     # ---- simple mode: everything after backward ----
     def all_reduce(self):

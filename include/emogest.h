@@ -56,6 +56,9 @@ const char* eg_version(void);
 int eg_set_default_precision(int precision);
 int eg_get_default_precision(void);
 
+/* Number of kernel launches the library has issued in this process (every launch function counts; captured launches count when they are
+ * recorded, not when a hipGraph replays them).  bench.py reports launches per step from differences of this counter. */
+int64_t eg_launch_count(void);
 /* Optional per-launch timing of the contraction kernels (bench.py's roofline leg; a debugging facility, process
  * global, not thread safe).  While enabled, every eg_conv3x3 / eg_linear launch is bracketed by a hipEvent pair on its
  * own stream (no synchronisation).  eg_profile_read synchronises those events and returns, per record, a tag
@@ -437,6 +440,10 @@ int eg_pack_table(const void* table, int32_t count, int32_t total_blocks, void* 
 /* nn.Dropout in train() mode with a counter-based mask (nothing stored): keep(i) = hash(seed, offset + i) >= p, y = keep ? x/(1-p) : 0;
  * the backward pass is the same call on dy.  The mask stream is this library's own (not torch's RNG). */
 int eg_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);
+/* The same with a device-resident step counter mixed into the seed (epoch_dev may be NULL = eg_dropout): a training step replayed from a
+ * captured hipGraph freezes the host scalars (seed, offset), the counter (incremented once per step by eg_counter_add inside the graph)
+ * still gives every replay a fresh mask.  Forward and backward of one step read the same counter value. */
+int eg_dropout_dev(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, const int32_t* epoch_dev, void* stream);
 /* SELayer pieces (ResNetBlocks.py:92-96) on x [B, HW, C]: pooled mean (x scale), per-(clip, channel) dot, gate scaling (+ add[b,c]);
  * workspace (eg_colreduce_workspace_floats(c) floats) selects the two-level reduction, NULL the one-block-per-clip kernel */
 int eg_seg_mean(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, float scale, float* workspace, void* stream);
@@ -466,6 +473,10 @@ int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int eg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, const int32_t* step_dev, void* stream);
 int eg_counter_add(int32_t* counter, int32_t delta, void* stream);
+/* Gradient-bucket payload conversion for the data-parallel all-reduce (bf16 buckets, 79 MB instead of 158 MB per step over
+ * xGMI): fp32 -> bf16 round-to-nearest-even, and bf16 -> fp32 times `scale`. */
+int eg_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+int eg_bf16_to_f32(const uint16_t* x, float* y, int64_t n, float scale, void* stream);
 
 #ifdef __cplusplus
 }

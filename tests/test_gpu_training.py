@@ -438,6 +438,143 @@ def test_dropout_mask_stream_and_generator_step_with_dropout():
     assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
 
 
+def test_dropout_inside_a_captured_graph_needs_and_uses_the_device_epoch():
+    """A captured step freezes the host-side (seed, offset) of the mask stream: without the device-resident epoch a dropout call inside a
+    capture is refused; with it (GraphedStep(stochastic=True) turns it on) every replay draws a fresh mask, equal to the eager call at the
+    same epoch, and the backward pass applies the forward's mask."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.train import functional as F
+    x = torch.ones(1 << 18, device=DEV)
+    F.manual_seed(5)
+    assert F._DROP["epoch"] is None
+    g0 = torch.cuda.CUDAGraph()
+    with pytest.raises(L.EgError):
+        with torch.cuda.graph(g0):
+            F.dropout(x, 0.2)
+    try:
+        ep = F.use_device_dropout_epoch(DEV)
+
+        def body():
+            F.begin_dropout_step()
+            xr = x.detach().requires_grad_(True)
+            y = F.dropout(xr, 0.2)
+            y.sum().backward()
+            return y.detach(), xr.grad
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y, dx = body()
+        outs = []
+        for _ in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y, dx)                                   # dy = 1: dx is the same scaled mask
+            assert abs(float((y != 0).float().mean()) - 0.8) < 5e-3
+            outs.append(y.clone())
+        assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+        assert int(ep) == 1 + 3                                         # one warm-up step + three replays (the capture itself executes nothing)
+        F._DROP["offset"] = 0
+        assert torch.equal(F.dropout(x, 0.2), outs[2])                  # the eager call at the same (seed, offset, epoch)
+    finally:
+        F._DROP["epoch"] = None
+        F.manual_seed(0)
+
+
+def test_graphed_step_keeps_its_scratch_buffers_alive():
+    """The captured kernels hold raw pointers into functional._WS; a later, larger eager request replaces the registry entry.  The graph
+    keeps the buffers it was captured with, so a replay after that still writes into memory it owns (same result as before)."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.graph import GraphedStep
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    a = torch.randn(4096, 64, device=DEV)
+    b = torch.randn(4096, 96, device=DEV)
+    lin = torch.nn.Linear(8, 8).to(DEV)
+    fp = flatten_parameters(lin)
+    opt = FlatAdam(fp, lr=0.0)
+
+    def step(_inputs=None):
+        return F.raw_gemm_tn(a, b)                                      # split-K partials go through the shared "tn" scratch
+
+    gs = GraphedStep(step, {}, opt, warmup=1)
+    want = gs.run().clone()
+    kept = gs._scratch_keep[(str(a.device), "tn")]
+    ptr = kept.data_ptr()
+    big = F._scratch(a.device, kept.numel() * 4, "tn")                  # a larger eager request replaces the registry entry ...
+    assert big.data_ptr() != ptr and gs._scratch_keep[(str(a.device), "tn")].data_ptr() == ptr        # ... the graph still owns its buffer
+    junk = [torch.full((kept.numel(),), 7.0, device=DEV) for _ in range(4)]        # allocations that would have landed on a freed block
+    got = gs.run().clone()
+    assert torch.equal(got, want)
+    del junk
+
+
+def test_segmented_step_equals_the_single_graph_step():
+    """train/graph.SegmentedStep (forward + backward cut at the tower output into two hipGraph segments + a tail graph, the bucket reductions
+    between them) against GraphedStep (one graph) on one rank: same losses, parameters and moments after the same number of steps; both
+    phases complete buckets, the tower's parameters belong to the second."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.graph import GraphedStep, SegmentedStep
+    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
+    inp = synth_inputs(2, 34, 126, 4, seed=21)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    label = torch.tensor([2, 6], device=DEV)
+    res = []
+    for segmented in (False, True):
+        model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
+        fp = flatten_parameters(model)
+        opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+        gb = GradBuckets(fp, bucket_mb=25.0).attach()
+
+        def loss_fn():
+            pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+            return F.add(F.smooth_l1_loss(pose, torch.zeros_like(pose), 1.0, 100.0), F.cross_entropy(pred, label))
+
+        def step(_inputs=None):
+            opt.zero_grad()
+            gb.begin()
+            loss = loss_fn()
+            loss.backward()
+            gb.finish()
+            opt.step(collected=True)
+            return loss
+
+        if segmented:
+            ss = SegmentedStep(loss_fn, gb, opt, device=DEV, warmup=2)
+            assert ss.n_segments == 2 and all(ss.ready), ss.ready
+            tower_bucket = gb.param_bucket[fp.index[id(model.audio_encoder.feat_extractor.layer1[0].conv1.weight)]]
+            assert tower_bucket in ss.ready[1] and 0 in ss.ready[0], ss.ready
+            losses = [float(ss.run()) for _ in range(3)]
+        else:
+            gs = GraphedStep(step, g, opt, warmup=2)
+            losses = [float(gs.run()) for _ in range(3)]
+        assert opt.t == 5
+        res.append((losses, fp.flat.clone(), opt.exp_avg.clone()))
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(res[0][0], res[1][0])), (res[0][0], res[1][0])
+    assert rel(res[1][1], res[0][1]) < 1e-7 and rel(res[1][2], res[0][2]) < 1e-6
+
+
+def test_bf16_bucket_payload_round_trip_error():
+    """GradBuckets.payload = "bf16": the conversion kernels round to nearest even; one round trip of a gradient-like buffer costs a relative
+    L2 error of ~2^-9 / sqrt(3) per element (the number DESIGN.md quotes for the compressed all-reduce)."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    x = torch.randn(1 << 20, device=DEV) * torch.logspace(-6, 2, 1 << 20, device=DEV)
+    st = torch.empty(x.numel(), dtype=torch.bfloat16, device=DEV)
+    y = torch.empty_like(x)
+    L.check(lib.eg_f32_to_bf16(_ptr(x), _ptr(st), x.numel(), _stream(DEV)), "eg_f32_to_bf16")
+    L.check(lib.eg_bf16_to_f32(_ptr(st), _ptr(y), x.numel(), 0.5, _stream(DEV)), "eg_bf16_to_f32")
+    assert torch.equal(st, x.to(torch.bfloat16))                        # same rounding as torch's cast
+    assert torch.equal(y, st.float() * 0.5)
+    rel = float((2 * y - x).norm() / x.norm())
+    assert 1e-3 < rel < 2.5e-3, rel
+
+
 def test_device_conv_weight_image_matches_host_packer_bitwise():
     """eg_pack_conv3x3_device builds the same image (fp32 + bf16 hi / lo) as the load-time host packer, and with flip_transpose the image
     of the rotated, transposed filter."""

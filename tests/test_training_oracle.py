@@ -138,6 +138,29 @@ _WORKER = textwrap.dedent('''
     gb.all_reduce()
     for p, want in zip(fp.params[:6], acc):
         assert torch.allclose(p.grad, want / world, rtol=1e-5, atol=1e-6)
+    # segmented step (train/graph.SegmentedStep, phases issued eagerly here): the backward is cut at a named site; the buckets completed by the
+    # first phase are reduced before the second phase runs, and the result equals the simple mode -- also with the bf16 payload, up to bf16 rounding
+    from emotiongestures_amd.train import nets
+    from emotiongestures_amd.train.graph import SegmentedStep
+    class _Opt:                                    # FlatAdam runs only on a GPU: the optimiser is not what this test is about
+        t = 0
+        def __init__(self, fp): self.fp = fp
+        def zero_grad(self): self.fp.zero_grad()
+        def step(self, collected=False): pass
+    head, tail = nn.Sequential(*list(model.children())[:2]), nn.Sequential(*list(model.children())[2:5])
+    def loss_fn():
+        return tail(nets._cut("tower", head(x))).sum()
+    for payload, tol in (("f32", 1e-5), ("bf16", 2e-2)):
+        gb.payload = payload
+        ss = SegmentedStep(loss_fn, gb, _Opt(fp), cuts=("tower",), use_graphs=False)
+        for it in range(2):
+            ss.run()
+        assert len(ss.ready) == 2 and ss.ready[0] and ss.ready[1], ss.ready                       # both phases completed buckets
+        assert sorted(ss.ready[0] + ss.ready[1]) == list(range(len(gb.buckets))), ss.ready        # every bucket exactly once
+        assert 0 in ss.ready[0], ss.ready                                                         # the last layers' bucket belongs to the first phase
+        for p, want in zip(fp.params[:6], acc):
+            assert torch.allclose(p.grad, want / world, rtol=tol, atol=tol * float(want.abs().max()) / world), (payload, float((p.grad - want / world).abs().max()))
+    gb.payload, gb.deferred = "f32", False
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -145,7 +168,8 @@ _WORKER = textwrap.dedent('''
 
 
 def test_gradient_buckets_two_gloo_ranks(tmp_path):
-    """Flat parameter / gradient buffers + bucketed all-reduce (backward order, hooks, unused parameters) on 2 CPU ranks."""
+    """Flat parameter / gradient buffers + bucketed all-reduce (backward order, hooks, unused parameters) on 2 CPU ranks; the segmented step
+    (per-phase reductions between backward segments, fp32 and bf16 payloads) gives the same averaged gradients."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     import socket
