@@ -474,6 +474,7 @@ def main():
     value = total_clips / elapsed
 
     timed_concurrent = bool(gen.concurrent)
+    launch_desc = "eager" if pipe is None else f"hipGraph replay, {lanes} step(s) in flight"
     # every lane ran the same resident batch: their outputs must agree bit for bit (catches any cross-lane interference)
     lanes_equal = None
     if pipe is not None and lanes > 1:
@@ -614,7 +615,7 @@ def main():
     # ---- training legs in the default line (BASELINE configs[2] on one GPU): 16 clips per step (the 8-GPU global-batch-128 share) and 128 ----
     train = None
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.no_train_legs:
-        del step, pipe
+        step = pipe = None                # release the lanes' graphs and workspaces before the training legs allocate theirs
         torch.cuda.empty_cache()
         train = {}
         for tb in (16, 128):
@@ -638,7 +639,7 @@ def main():
             "config": {"workload": "TED clips: 4 s 16 kHz audio -> mel(128x124) -> CVAE sample -> generator -> 34x126 pose",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "variant": "Models_spatial_memory",
                        "parallelism": f"clip-sharded x{world}, no data-path collective",
-                       "launch": "eager" if pipe is None else f"hipGraph replay, {lanes} step(s) in flight",
+                       "launch": launch_desc,
                        "branch_streams": timed_concurrent, "fold_affine": bool(getattr(gen, "fold_affine", False)),
                        "algorithmic_gflop_per_clip": round((FLOP_PER_CLIP + MEL_FLOP_PER_CLIP + CVAE_FLOP_PER_CLIP) / 1e9, 3)},
             "pose_rel_l2_vs_cpu_oracle": parity, "parity_clips_checked": B, "fgd_vs_cpu_oracle": fgd,

@@ -231,5 +231,3 @@ extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t
                             int32_t dk, int32_t precision, void* stream) {
     return egi_attention(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, dk, precision, (hipStream_t)stream);
 }
-
-#include "common_tail.h"

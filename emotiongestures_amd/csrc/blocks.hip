@@ -86,5 +86,3 @@ extern "C" int eg_tcn_forward(const float* x, const float* w, float* y, int32_t 
     }
     return EG_OK;
 }
-
-#include "common_tail.h"

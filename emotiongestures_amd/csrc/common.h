@@ -10,11 +10,9 @@
 // No packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel of the library: on MI355X a v_pk_fma_f32 whose operand
 // is routed by op_sel / op_sel_hi returns wrong lanes while another wave issues MFMAs on the same SIMD (tools/hazard_probe.hip,
 // profiles/r02_hazard_probe.txt); hipcc forms exactly that instruction from `float4 * scalar` code.  The target feature is
-// switched off for every function that follows, in the DEVICE pass only (the host pass does not know the feature);
-// tests/test_isa_gate.py disassembles the built library and fails on any packed-fp32 VALU.
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
-#endif
+// switched off for the whole device compilation by __graft_entry__.DEVICE_FLAGS (a per-function `#pragma clang attribute target(...)`
+// was measured in round 3: it leaves the HIP headers' inline device functions with a different feature set, LLVM then refuses to
+// inline them, and the convolutions lose 8-36 %); tests/test_isa_gate.py disassembles the built library and fails on any packed-fp32 VALU.
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef short bf8 __attribute__((ext_vector_type(8)));   // 8 bf16 (one 16x16x32 MFMA operand)

@@ -881,5 +881,3 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
     }
     return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
 }
-
-#include "common_tail.h"

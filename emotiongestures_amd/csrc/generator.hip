@@ -986,5 +986,3 @@ extern "C" int eg_cvae_forward(const EgCvae* c, const float* A, int32_t n, const
     EG_TRY(egi_copy2d(P(ws, w.z), 32, P(ws, w.zy), 64, n, 32, st));
     return cvae_decode(c, A, w, ws, n, recon, st);
 }
-
-#include "common_tail.h"

@@ -171,5 +171,3 @@ extern "C" int eg_melspectrogram(const float* audio, int32_t batch, int32_t n_sa
     hipLaunchKernelGGL(mel_db_kernel, dim3(batch), dim3(1024), 0, st, melpow, spec, n_frames, out_frames);
     return eg_check_launch("mel_db");
 }
-
-#include "common_tail.h"

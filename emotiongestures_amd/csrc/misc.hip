@@ -764,5 +764,3 @@ extern "C" int eg_contrastive_loss(const float* face, const float* audio, int32_
     hipLaunchKernelGGL(contrastive_mean_kernel, dim3(1), dim3(256), 0, st, row_loss, row_hit, n, loss, acc);
     return eg_check_launch("contrastive_mean");
 }
-
-#include "common_tail.h"

@@ -1409,5 +1409,3 @@ extern "C" int eg_adam_step(float* param, const float* grad, float* exp_avg, flo
                        weight_decay, (float)bc1, (float)sqrt(bc2));
     return eg_check_launch("adam_step");
 }
-
-#include "common_tail.h"

@@ -283,5 +283,3 @@ extern "C" int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, dw_mat, n, p.S);
     return eg_check_launch("wgrad_reduce");
 }
-
-#include "common_tail.h"

@@ -81,6 +81,7 @@ DEBUG_TAPS = None       # tools/debug_block_grad.py: {id(block): dict} receives 
 
 
 FUSE_BLOCK = True           # False: the operator-by-operator block (A/B switch of tests and tools)
+TAP_FUSED = None            # tests: a dict that receives conv1's ReLU output and the block output of the FUSED block (ReLU masks)
 
 
 def se_basic_block(blk, x):
@@ -96,7 +97,10 @@ def se_basic_block(blk, x):
         res = F.batch_norm(F.conv1x1(xb, blk.downsample[0].weight, blk.stride), blk.downsample[1])
     else:
         res = xb
-    return F.se_block_tail(c2, gap2, res, blk.bn2, blk.se.fc[0], blk.se.fc[2])
+    out = F.se_block_tail(c2, gap2, res, blk.bn2, blk.se.fc[0], blk.se.fc[2])
+    if TAP_FUSED is not None:
+        TAP_FUSED.update(r1=r1.detach(), out=out.detach())
+    return out
 
 
 def _se_basic_block_unfused(blk, x):

@@ -224,6 +224,83 @@ def test_se_block_backward_on_real_activations(li, bi):
     assert rel(xh.grad, xi.grad.permute(0, 2, 3, 1)) < tol
 
 
+# ---- every site of the tower against the REFERENCE's own modules on identical inputs (tests/golden/make_golden_tower_grad.py) ----------
+TOWER_SITES = ["stem"] + [f"layer1.{i}" for i in range(3)] + [f"layer2.{i}" for i in range(4)] + [f"layer3.{i}" for i in range(6)] + ["final"]
+
+
+def _fp_check(z, key, got, tol, what):
+    """got: a tensor in the reference's layout; fingerprints as written by make_golden_tower_grad.fp()."""
+    v = got.detach().reshape(-1).double().cpu().numpy()
+    stride = max(1, v.size // 64)
+    ref_s, ref_n = z[key + "/sample"], float(z[key + "/norm"])
+    e_s = np.linalg.norm(v[::stride][:64] - ref_s) / max(np.linalg.norm(ref_s), 1e-30)
+    e_n = abs(np.linalg.norm(v) - ref_n) / max(ref_n, 1e-30)
+    assert e_s < tol and e_n < tol, f"{what}: sample rel err {e_s:.2e}, norm rel err {e_n:.2e} (tol {tol:.0e})"
+    return max(e_s, e_n)
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("site", TOWER_SITES)
+def test_tower_site_backward_matches_reference_golden(site, precision, tol):
+    """Stem, all 13 SEBasicBlocks (incl. both stride-2 entries with their downsample branch) and final_conv1 -> bn1, each fed the stored
+    crop of the reference step's REAL input activation and upstream gradient (fp16 values: bit-identical on both sides): output, input
+    gradient and every parameter gradient against the reference module run in float64.  Identical inputs leave no ReLU-mask excuse: the
+    masks the HIP path takes are compared with the reference's bit-packed ones and must agree (a disagreeing element would be reported,
+    none has been seen); tolerance 1e-4 in the fp32 configuration, 3e-4 with the split-bf16 operators."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train import nets
+    z = np.load(os.path.join(GOLDEN, "tower_grads.npz"))
+    _batch, seed = [int(v) for v in z["meta"]]
+    x = torch.from_numpy(z[f"{site}/x"].astype(np.float32))                                  # NCHW
+    g = torch.from_numpy(z[f"{site}/g"].astype(np.float32)) / float(z[f"{site}/g_scale"])
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=seed, precision="f32").to(DEV).train()
+    ae, enc = model.audio_encoder, model.audio_encoder.feat_extractor
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    gh = g.permute(0, 2, 3, 1).contiguous().to(DEV)
+    taps = {}
+    try:
+        F.set_precision(precision)
+        if site == "stem":
+            r1 = F.conv3x3(xh, enc.conv1.weight, enc.conv1.bias, 1, relu=True)
+            y = F.batch_norm(r1, enc.bn1)
+            taps["r1"] = r1.detach()
+            params = {"conv1.weight": enc.conv1.weight, "conv1.bias": enc.conv1.bias, "bn1.weight": enc.bn1.weight, "bn1.bias": enc.bn1.bias}
+        elif site == "final":
+            y = F.batch_norm(F.conv3x3(xh, ae.final_conv1.weight, ae.final_conv1.bias), ae.bn1)
+            params = {"final_conv1.weight": ae.final_conv1.weight, "final_conv1.bias": ae.final_conv1.bias, "bn1.weight": ae.bn1.weight, "bn1.bias": ae.bn1.bias}
+        else:
+            li, bi = int(site[5]), int(site[7:])
+            blk = getattr(enc, f"layer{li}")[bi]
+            assert blk.stride == int(z[f"{site}/stride"])
+            nets.TAP_FUSED = taps
+            y = nets.se_basic_block(blk, xh)                                                 # the fused block: what a training step runs
+            params = dict(blk.named_parameters())
+        y.backward(gh)
+    finally:
+        nets.TAP_FUSED = None
+        F.set_precision("f32")
+    flips = 0
+    for k in ("r1", "out"):
+        if f"{site}/mask/{k}" in z.files:
+            mine = (taps[k].permute(0, 3, 1, 2) > 0).cpu().numpy().reshape(-1)
+            ref = np.unpackbits(z[f"{site}/mask/{k}"])[:mine.size].astype(bool)
+            flips += int((mine != ref).sum())
+    assert flips == 0, f"{site}: {flips} ReLU mask elements differ from the reference's on identical inputs"
+    worst = _fp_check(z, f"{site}/out", y.permute(0, 3, 1, 2), min(tol, 1e-4) if precision == "f32" else tol, f"{site} output")
+    if site != "stem":                              # the stem's input is the spectrogram: nothing upstream takes its gradient
+        worst = max(worst, _fp_check(z, f"{site}/dx", xh.grad.permute(0, 3, 1, 2), tol, f"{site} input gradient"))
+    for k, p in params.items():
+        if f"{site}/p/{k}/norm" not in z.files:
+            continue
+        if k == "final_conv1.bias":
+            # a bias in front of a train-mode BatchNorm has an exactly zero gradient: both sides hold round-off only
+            assert p.grad is None or float(p.grad.norm()) < 1e-4 * float(z[f"{site}/p/final_conv1.weight/norm"]), k
+            continue
+        assert p.grad is not None, f"{site}: no gradient for {k}"
+        worst = max(worst, _fp_check(z, f"{site}/p/{k}", p.grad, tol, f"{site} d{k}"))
+    print(f"{site} [{precision}]: worst relative error vs the reference (float64) {worst:.2e}")
+
+
 # ---- network level -----------------------------------------------------------------------------------------------------------
 def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol):
     """Per-parameter relative L2 of the gradient.  Parameters under `tower_prefix` (the ReLU/BatchNorm convolution tower) get

@@ -57,6 +57,7 @@ def gemm(prec):
 def conv(prec):
     pc = L.precision_code(prec)
     B = 64
+    torch.manual_seed(0)
     for (cin, cout, s, H, W) in [(32, 32, 1, 128, 124), (64, 64, 1, 64, 62), (128, 128, 1, 32, 31), (32, 64, 2, 128, 124), (64, 128, 2, 64, 62)]:
         x = torch.randn(B, H, W, cin, device=dev)
         w = torch.randn(cout, cin, 3, 3) * 0.05
@@ -68,7 +69,8 @@ def conv(prec):
         us = timeit(f)
         fl = 2.0 * 9 * cin * cout * Ho * Wo * B
         by = 4.0 * B * (H * W * cin + Ho * Wo * cout)
-        print(f"conv {prec:7s} {cin:3d}->{cout:3d} s{s} {H}x{W}: {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:7.1f} GB/s (in+out)")
+        chk = (float(y.double().sum()), float(y.double().abs().sum()), float(y[B // 2, Ho // 2, Wo // 3, cout // 2]))   # equal across tilings (same summation order)
+        print(f"conv {prec:7s} {cin:3d}->{cout:3d} s{s} {H}x{W}: {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:7.1f} GB/s (in+out)  checksum {chk[0]:.6e} {chk[1]:.6e} {chk[2]:.6e}")
 
 
 if __name__ == "__main__":
