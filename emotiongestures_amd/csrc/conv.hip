@@ -1116,5 +1116,3 @@ extern "C" int eg_se_residual_relu(const float* y, const float* gate, const floa
     }
     return eg_check_launch("se_tail_downsample");
 }
-
-#include "common_tail.h"
