@@ -125,6 +125,7 @@ SIGNATURES = {
     "eg_elementwise": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, _P]),
     "eg_conv3x3_wgrad_mfma_workspace_floats": (_L, [_I, _I, _I, _I, _I]),
     "eg_conv3x3_wgrad_mfma": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "eg_conv3x3_wgrad_mfma_oihw": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_pack_conv3x3_device": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "eg_linear_packed_floats": (_L, [_I, _I]),
     "eg_pack_linear_device": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
@@ -137,12 +138,17 @@ SIGNATURES = {
     "eg_se_scale": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "eg_layernorm_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_attention_backward": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_attention_train": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, C.c_float, C.c_uint32, C.c_uint64, _P, _P]),
+    "eg_attention_backward_train": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_uint32,
+                                              C.c_uint64, _P, _P]),
     "eg_smooth_l1": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, _P, _P]),
     "eg_cross_entropy": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, _P, _P, _I, _I, _P, _P]),
     "eg_kld": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "eg_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "eg_counter_add": (C.c_int, [_P, _I, _P]),
+    "eg_linear_wgrad_mfma_workspace_floats": (_L, [_I, _I, _I]),
+    "eg_linear_wgrad_mfma": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
     "eg_f32_to_bf16": (C.c_int, [_P, _P, _L, _P]),
     "eg_bf16_to_f32": (C.c_int, [_P, _P, _L, C.c_float, _P]),
 }

@@ -101,6 +101,27 @@ __device__ __forceinline__ void split_octet(const f4& v0, const f4& v1, bf8& hi,
     if (WANT_LO) lo = __builtin_bit_cast(bf8, l);
 }
 
+// ---- counter-based dropout mask (train.hip: eg_dropout; attention.hip: the probabilities' dropout of Modules.py:21) -------------------------
+// keep(i) = hash(seed, counter i) >= p * 2^32: nothing is stored, the backward pass recomputes the mask from the same (seed, counter).
+__device__ __forceinline__ unsigned int mix32(unsigned int h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+// `epoch` (optional, device resident): a per-step counter mixed into the seed, so that a step replayed from a captured hipGraph -- whose host
+// scalars (seed, offset) are frozen -- still draws a fresh mask every replay (train/graph.py increments it inside the graph).
+__device__ __forceinline__ unsigned int dropout_seed(unsigned int seed, const int* __restrict__ epoch) {
+    return epoch ? seed ^ mix32((unsigned int)*epoch * 0x9E3779B9u + 0x7F4A7C15u) : seed;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned int seed, unsigned long long ctr, unsigned int thr) {
+    return mix32(mix32((unsigned int)ctr ^ seed) + (unsigned int)(ctr >> 32) * 0x9E3779B9u + 0x6A09E667u) >= thr;
+}
+struct EgDropout {              // p = 0 (thr = 0): identity
+    unsigned int thr = 0, seed = 0;
+    float inv_keep = 1.f;
+    unsigned long long offset = 0;
+    const int* epoch = nullptr;
+};
+
 // ---- optional launch profiler (generator.hip) ----------------------------------------------------------------
 // XCD-aware tile order for 2-D tile grids.  Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest), each
 // XCD with its own L2.  Give XCD k a contiguous run of logical tile ids (y fastest inside the run) so that the tiles sharing a

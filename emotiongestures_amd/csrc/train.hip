@@ -388,6 +388,39 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
     if (o0) o0[(size_t)seg * C + c] = (float)(s * scale);
     if (o1) o1[(size_t)seg * C + c] = (float)(q * scale);
 }
+// Small inputs (bias / LayerNorm-affine gradients, the BatchNorms of the prior encoder and the CVAE at training batch sizes): both levels in ONE
+// launch.  A workgroup owns 64 columns: 16 column quads x 16 row lanes, each thread walks rows rl, rl + 16, ... with float4 loads (a row segment of
+// 256 bytes per 16 lanes), the 16 row lanes are combined through LDS in a fixed order.  Same modes as col_partial_kernel (0, 1, 2, 3).
+__global__ __launch_bounds__(256) void col_direct_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
+                                                         float* __restrict__ o0, float* __restrict__ o1, long rows, int C, int mode, float scale) {
+    __shared__ f4 s0[256], s1[256];
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int c = blockIdx.x * 64 + 4 * cq;
+    f4 u = (f4){0.f, 0.f, 0.f, 0.f}, v = u;
+    if (c < C) {                                    // C % 4 == 0: a quad is inside or outside as a whole
+        f4 mu = u;
+        if (mode >= 2) mu = *reinterpret_cast<const f4*>(mean + c);
+#pragma unroll 4
+        for (long r = rl; r < rows; r += 16) {
+            const f4 x = *reinterpret_cast<const f4*>(a + (size_t)r * C + c);
+            if (mode == 0) { u += x; v += x * x; }
+            else if (mode == 1) { u += x; v += x * *reinterpret_cast<const f4*>(b + (size_t)r * C + c); }
+            else if (mode == 2) { u += x; v += x * (*reinterpret_cast<const f4*>(b + (size_t)r * C + c) - mu); }
+            else { const f4 d = x - mu; u += d * d; }
+        }
+    }
+    s0[tid] = u;
+    s1[tid] = v;
+    __syncthreads();
+    if (tid < 16 && blockIdx.x * 64 + 4 * tid < C) {
+        f4 su = (f4){0.f, 0.f, 0.f, 0.f}, sv = su;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { su += s0[j * 16 + tid]; sv += s1[j * 16 + tid]; }
+        const int cc = blockIdx.x * 64 + 4 * tid;
+        if (o0) *reinterpret_cast<f4*>(o0 + cc) = su * scale;
+        if (o1) *reinterpret_cast<f4*>(o1 + cc) = sv * scale;
+    }
+}
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
                                                        size_t total, int C) {
@@ -712,24 +745,12 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackEntry* __rest
 
 // ---- dropout: counter-based mask, nothing stored -- keep(i) = hash(seed, offset + i) >= p; y = keep ? x / (1 - p) : 0.  The backward pass
 // is the same kernel on dy with the same (seed, offset).  (nn.Dropout's semantics; the mask stream is this library's own, not torch's.)
-__device__ __forceinline__ unsigned int mix32(unsigned int h) {
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
-}
-// `epoch` (optional, device resident): a per-step counter mixed into the seed, so that a step replayed from a captured hipGraph -- whose host
-// scalars (seed, offset) are frozen -- still draws a fresh mask every replay (train/graph.py increments it inside the graph).
-__device__ __forceinline__ unsigned int dropout_seed(unsigned int seed, const int* __restrict__ epoch) {
-    return epoch ? seed ^ mix32((unsigned int)*epoch * 0x9E3779B9u + 0x7F4A7C15u) : seed;
-}
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p, float inv_keep,
                                                       unsigned int seed, unsigned long long offset, const int* __restrict__ epoch) {
     const unsigned int thr = (unsigned int)(p * 4294967296.0);
     seed = dropout_seed(seed, epoch);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned long long ctr = offset + i;
-        const unsigned int h = mix32(mix32((unsigned int)ctr ^ seed) + (unsigned int)(ctr >> 32) * 0x9E3779B9u + 0x6A09E667u);
-        y[i] = (h >= thr) ? x[i] * inv_keep : 0.f;
-    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = dropout_keep(seed, offset + i, thr) ? x[i] * inv_keep : 0.f;
 }
 
 // ---- SE pieces: x [B, HW, C] --------------------------------------------------------------------------------------------
@@ -1104,6 +1125,22 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
     }
     return EG_OK;
 }
+// column sums straight to their final place: one launch for small inputs, partials + finalize otherwise
+bool col_direct_ok(const float* a, const float* b, const float* o0, const float* o1, int64_t rows, int c) {
+    return (c & 3) == 0 && rows * (int64_t)c <= (int64_t)1 << 21 && eg_aligned16(a) && (!b || eg_aligned16(b)) && (!o0 || eg_aligned16(o0)) &&
+           (!o1 || eg_aligned16(o1));
+}
+int col_sums(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* workspace, float* o0, float* o1, float scale,
+             hipStream_t st) {
+    if (col_direct_ok(a, b, o0, o1, rows, c) && (!mean || eg_aligned16(mean))) {
+        hipLaunchKernelGGL(col_direct_kernel, dim3(eg_cdiv(c, 64)), dim3(256), 0, st, a, b, mean, o0, o1, (long)rows, c, mode, scale);
+        return eg_check_launch("col_direct");
+    }
+    int nblk = 0;
+    if (int rc = col_reduce(a, b, mean, rows, c, mode, workspace, &nblk, st)) return rc;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, st, workspace, nblk, c, o0, o1, scale);
+    return eg_check_launch("col_finalize");
+}
 }  // namespace
 
 // workspace for the column reductions below: partials [<= 512][2][C] + one scratch column
@@ -1128,12 +1165,9 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
                                     float* dgamma, float* dbeta, int64_t rows, int32_t c, int32_t relu_mask, float* workspace, void* stream) {
     EG_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG,
                "eg_bn_train_backward: bad argument");
-    int nblk = 0;
-    if (int rc = col_reduce(dy, x, save_mean, rows, c, 2, workspace, &nblk, ST)) return rc;        // (sum dy, sum dy*(x - mean))
     float* sum_dyx = workspace + (size_t)2 * 512 * c;           // scratch column behind the partials
-    // dbeta receives sum dy directly; sum dy*x goes to the scratch column
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, dbeta, sum_dyx, 1.0f);
-    if (int rc = eg_check_launch("col_finalize")) return rc;
+    // (sum dy, sum dy*(x - mean)): dbeta receives sum dy directly; sum dy*(x - mean) goes to the scratch column
+    if (int rc = col_sums(dy, x, save_mean, rows, c, 2, workspace, dbeta, sum_dyx, 1.0f, ST)) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, dbeta, sum_dyx, dx, dgamma,
                        (size_t)rows * c, c, 1.0f / (float)rows, relu_mask);
     return eg_check_launch("bn_bwd_apply");
@@ -1243,10 +1277,7 @@ extern "C" int eg_se_tail_backward_apply(const float* dout, const float* out, co
 // o0[c] = sum_r a[r][c];  o1[c] = sum_r a[r][c]*b[r][c] (b optional: then o1 = sum a^2)
 extern "C" int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream) {
     EG_REQUIRE(a && (o0 || o1) && workspace && rows > 0 && c > 0, EG_ERR_BAD_ARG, "eg_colsum: bad argument");
-    int nblk = 0;
-    if (int rc = col_reduce(a, b, nullptr, rows, c, b ? 1 : 0, workspace, &nblk, ST)) return rc;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, o0, o1, 1.0f);
-    return eg_check_launch("col_finalize");
+    return col_sums(a, b, nullptr, rows, c, b ? 1 : 0, workspace, o0, o1, 1.0f, ST);
 }
 
 extern "C" int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t op, float s, void* stream) {

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(WgradArgs a)
 
 // dw[i] = sum over s of part[s][i], fixed order: 64 outputs per workgroup, the four waves take s = w, w + 4, ... (eight loads in
 // flight per lane), then combine in wave order.  (One thread per output walking all S partials was 100+ us at S = 512.)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int S) {
+// ci > 0: the output is written in the reference's OIHW order (dw[co][ci][tap]) instead of the partials' [co][tap][ci]: the permute that
+// autograd's caller would otherwise run as a strided device copy per convolution.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int S, int ci) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
@@ -222,7 +224,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     red[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    if (w == 0 && i < n) dw[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (w == 0 && i < n) {
+        int o = i;
+        if (ci > 0) {
+            const int co = i / (9 * ci), rem = i - co * 9 * ci, tap = rem / ci, c = rem - tap * ci;
+            o = (co * ci + c) * 9 + tap;
+        }
+        dw[o] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
 }
 
 struct Plan { int ci_t, strips, R, chunks, units, S, upw, nct, n_cit; };
@@ -252,9 +261,23 @@ extern "C" int64_t eg_conv3x3_wgrad_mfma_workspace_floats(int32_t batch, int32_t
     return (int64_t)p.S * cout * 9 * cin;
 }
 
+namespace { int wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, float* workspace,
+                           int64_t workspace_floats, int oihw, void* stream); }
+
 // dw_mat [cout][9*cin] ((kh, kw, ci) fastest to slowest as eg_conv3x3_wgrad writes it); stride 1 only, cin % 32 == 0, cout % 32 == 0.
 extern "C" int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                      float* workspace, int64_t workspace_floats, void* stream) {
+    return wgrad_mfma(x, dy, dw_mat, batch, h, w, cin, cout, workspace, workspace_floats, 0, stream);
+}
+// the same gradient written as dw [cout][cin][3][3] (nn.Conv2d's weight layout: no permute pass behind it)
+extern "C" int eg_conv3x3_wgrad_mfma_oihw(const float* x, const float* dy, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                          float* workspace, int64_t workspace_floats, void* stream) {
+    return wgrad_mfma(x, dy, dw, batch, h, w, cin, cout, workspace, workspace_floats, 1, stream);
+}
+
+namespace {
+int wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, float* workspace,
+               int64_t workspace_floats, int oihw, void* stream) {
     EG_REQUIRE(x && dy && dw_mat && workspace && batch > 0 && h > 0 && w > 0, EG_ERR_BAD_ARG, "eg_conv3x3_wgrad_mfma: null pointer or empty shape");
     EG_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0, EG_ERR_UNSUPPORTED, "eg_conv3x3_wgrad_mfma: channels %d -> %d (multiples of 32)", cin, cout);
     EG_REQUIRE(eg_aligned16(x) && eg_aligned16(dy), EG_ERR_ALIGN, "eg_conv3x3_wgrad_mfma: activations must be 16-byte aligned");
@@ -280,6 +303,7 @@ extern "C" int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_
     }
     if (int rc = eg_check_launch("conv3x3_wgrad_mfma")) return rc;
     const int n = cout * 9 * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, dw_mat, n, p.S);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, dw_mat, n, p.S, oihw ? cin : 0);
     return eg_check_launch("wgrad_reduce");
 }
+}  // namespace

@@ -219,10 +219,25 @@ def raw_ew(op, a, b=None, s=0.0):
 EW_RELU, EW_RELU_BWD, EW_LEAKY, EW_LEAKY_BWD, EW_ADD, EW_SCALE, EW_SIGMOID, EW_SIGMOID_BWD, EW_MUL, EW_AXPY, EW_EXP, EW_SCALE_DEV = range(12)
 
 
-def raw_linear_backward(x, w, dy, need_dx=True, w_param=None, b_param=None):
-    """dx = dy w;  dw = dy^T x;  db = colsum(dy).  w_param / b_param: the parameters themselves (gradients go to their flat slices)."""
-    dw = raw_gemm_tn(dy, x, out=grad_out(w_param) if w_param is not None and x.shape[1] == w.shape[1] else None)
-    db, _ = raw_colsum(dy, out0=grad_out(b_param) if b_param is not None else None)
+def raw_linear_backward(x, w, dy, need_dx=True, w_param=None, b_param=None, want_db=True):
+    """dx = dy w;  dw = dy^T x;  db = colsum(dy).  w_param / b_param: the parameters themselves (gradients go to their flat slices).
+    Under set_precision("bf16x3") dw and db come from ONE launch of the split-bf16 MFMA kernel (csrc/lingrad.hip; + a fixed-order reduce when
+    the rows are split); the fp32 configuration keeps the fp32 TN GEMM and the column sum."""
+    in_place = w_param is not None and x.shape[1] == w.shape[1]
+    if _PREC["gemm"] != F32:
+        lib = _lib()
+        R, N = dy.shape
+        K = x.shape[1]
+        dev = dy.device
+        dw = grad_out(w_param) if in_place else torch.empty(N, K, dtype=torch.float32, device=dev)
+        db = (grad_out(b_param) if b_param is not None else torch.empty(N, dtype=torch.float32, device=dev)) if want_db else None
+        need = int(lib.eg_linear_wgrad_mfma_workspace_floats(R, N, K))
+        ws = _scratch(dev, need, "tn") if need else None
+        L.check(lib.eg_linear_wgrad_mfma(_ptr(dy), N, _ptr(x), K, _ptr(dw), K, _ptr(db), R, N, K, _ptr(ws), ws.numel() if ws is not None else 0,
+                                         _stream(dev)), "eg_linear_wgrad_mfma")
+    else:
+        dw = raw_gemm_tn(dy, x, out=grad_out(w_param) if in_place else None)
+        db = raw_colsum(dy, out0=grad_out(b_param) if b_param is not None else None)[0] if want_db else None
     dx = raw_linear(dy, w, w_transposed=True) if need_dx else None      # [M,N] x [N,K]
     return dx, dw, db
 
@@ -246,7 +261,7 @@ class _Linear(torch.autograd.Function):
         dy2 = _chk(dy).reshape(-1, w.shape[0])
         if y is not None:
             dy2 = raw_ew(EW_RELU_BWD, dy2, y)
-        dx, dw, db = raw_linear_backward(x2, w, dy2, ctx.need_dx, ctx.params[0], ctx.params[1] if ctx.has_b else None)
+        dx, dw, db = raw_linear_backward(x2, w, dy2, ctx.need_dx, ctx.params[0], ctx.params[1] if ctx.has_b else None, want_db=ctx.has_b)
         return (dx.view(ctx.xs) if dx is not None else None), dw, (db if ctx.has_b else None), None
 
 
@@ -452,11 +467,13 @@ class _Conv3x3(torch.autograd.Function):
         Ho, Wo = dyd.shape[1], dyd.shape[2]
         dev = x.device
         dy2 = dyd.view(B * Ho * Wo, Co)
-        if _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 32 == 0:       # split-bf16 MFMA weight gradient
-            dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
-            need = lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Co)
+        dw = grad_out(ctx.params[0], (Co, Ci, 3, 3))
+        dwm = None
+        if _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 32 == 0:       # split-bf16 MFMA weight gradient, written OIHW
+            need = lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Co)                # straight into the flat gradient slice
             ws = _scratch(dev, need, "wgrad")
-            L.check(lib.eg_conv3x3_wgrad_mfma(_ptr(x), _ptr(dy2), _ptr(dwm), B, H, W, Ci, Co, _ptr(ws), ws.numel(), _stream(dev)), "eg_conv3x3_wgrad_mfma")
+            L.check(lib.eg_conv3x3_wgrad_mfma_oihw(_ptr(x), _ptr(dy2), _ptr(dw), B, H, W, Ci, Co, _ptr(ws), ws.numel(), _stream(dev)),
+                    "eg_conv3x3_wgrad_mfma")
         elif Ci % 4 == 0:           # implicit GEMM over the output pixels (no im2col buffer)
             dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
             need = lib.eg_gemm_tn_workspace_floats(Co, 9 * Ci, B * Ho * Wo)
@@ -467,8 +484,8 @@ class _Conv3x3(torch.autograd.Function):
             col = torch.empty(B * Ho * Wo, 9 * Ci, dtype=torch.float32, device=dev)
             L.check(lib.eg_im2col3x3(_ptr(x), _ptr(col), B, H, W, Ci, ctx.stride, 0, _stream(dev)), "eg_im2col3x3")
             dwm = raw_gemm_tn(dy2, col)                                     # [Co, (kh,kw,ci)]
-        dw = grad_out(ctx.params[0], (Co, Ci, 3, 3))
-        dw.copy_(dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2))               # (kh, kw, ci) -> OIHW, straight into the flat gradient slice
+        if dwm is not None:
+            dw.copy_(dwm.view(Co, 3, 3, Ci).permute(0, 3, 1, 2))           # (kh, kw, ci) -> OIHW, straight into the flat gradient slice
         db = raw_colsum(dy2, out0=grad_out(ctx.params[1]))[0] if ctx.has_b else None
         dx = None
         if ctx.need_dx and ctx.stride == 1 and Ci == Co and Ci % 32 == 0:
@@ -723,10 +740,11 @@ def layer_norm(x, ln):
 
 
 class _Attention(torch.autograd.Function):
-    """ScaledDotProductAttention (Modules.py:13-23) on [B, L, H*64] projections; forward on the MFMA kernel."""
+    """ScaledDotProductAttention (Modules.py:13-23) on [B, L, H*64] projections: forward and backward on the fp32 matrix pipe, with nn.Dropout(p)
+    on the probabilities (`attn = self.dropout(F.softmax(attn, dim=-1))`, :21) from the counter-based mask stream when p > 0."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads):
+    def forward(ctx, q, k, v, heads, p, seed, offset, epoch):
         lib = _lib()
         qd, kd, vd = _chk(q), _chk(k), _chk(v)
         B, Lq, D = qd.shape
@@ -734,27 +752,35 @@ class _Attention(torch.autograd.Function):
         dev = qd.device
         out = torch.empty_like(qd)
         attn = torch.empty(B, heads, Lq, Lk, device=dev)
-        L.check(lib.eg_attention(_ptr(qd), D, _ptr(kd), D, _ptr(vd), D, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk, D // heads, F32, _stream(dev)),
-                "eg_attention")
+        L.check(lib.eg_attention_train(_ptr(qd), D, _ptr(kd), D, _ptr(vd), D, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk, D // heads, float(p), seed,
+                                       offset, _ptr(epoch), _stream(dev)), "eg_attention_train")
         ctx.save_for_backward(qd, kd, vd, attn)
-        ctx.heads = heads
+        ctx.cfg = (heads, float(p), seed, offset, epoch)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib()
         q, k, v, attn = ctx.saved_tensors
+        heads, p, seed, offset, epoch = ctx.cfg
         B, Lq, D = q.shape
         Lk = k.shape[1]
         do = _chk(dout)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        L.check(lib.eg_attention_backward(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(attn), _ptr(do), D, _ptr(dq), D, _ptr(dk), D, _ptr(dv), D, B,
-                                          ctx.heads, Lq, Lk, D // ctx.heads, _stream(q.device)), "eg_attention_backward")
-        return dq, dk, dv, None
+        L.check(lib.eg_attention_backward_train(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(attn), _ptr(do), D, _ptr(dq), D, _ptr(dk), D, _ptr(dv), D, B,
+                                                heads, Lq, Lk, D // heads, p, seed, offset, _ptr(epoch), _stream(q.device)), "eg_attention_backward_train")
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, heads):
-    return _Attention.apply(q, k, v, heads)
+def attention(q, k, v, heads, dropout_p: float = 0.0):
+    """dropout_p: nn.Dropout on the attention probabilities (train mode); the mask stream is the one of `dropout()`."""
+    if dropout_p > 0.0:
+        if q.is_cuda and torch.cuda.is_current_stream_capturing() and _DROP.get("epoch") is None:
+            raise L.EgError("attention dropout inside a stream capture needs the device-resident mask epoch (functional.use_device_dropout_epoch)")
+        B, Lq = q.shape[0], q.shape[1]
+        off = next_dropout_offset(B * heads * Lq * k.shape[1])
+        return _Attention.apply(q, k, v, heads, dropout_p, _DROP["seed"], off, _DROP.get("epoch"))
+    return _Attention.apply(q, k, v, heads, 0.0, 0, 0, None)
 
 
 class _Conv1dCL(torch.autograd.Function):

@@ -20,8 +20,8 @@ from . import functional as F
 
 # Dropout: the gradient-parity configuration (tests, goldens) runs with every Dropout at p = 0.  With
 # `model.train_dropout = True` the reference's placements are active with its probabilities, on the library's own mask stream
-# (functional.manual_seed); ScaledDotProductAttention's dropout on the probabilities (Modules.py:21, p = 0.1) is NOT applied: the
-# fused attention kernel never materialises them for a second pass.
+# (functional.manual_seed) -- including ScaledDotProductAttention's dropout on the probabilities (Modules.py:21, p = 0.1), applied inside
+# the attention kernels from the same counter-based mask (forward and backward recompute it; nothing is stored).
 _P = {"on": False}
 
 
@@ -99,7 +99,9 @@ def se_basic_block(blk, x):
         res = xb
     out = F.se_block_tail(c2, gap2, res, blk.bn2, blk.se.fc[0], blk.se.fc[2])
     if TAP_FUSED is not None:
-        TAP_FUSED.update(r1=r1.detach(), out=out.detach())
+        if r1.requires_grad:
+            r1.retain_grad()            # the (masked) gradient at conv1's ReLU output: lets a test weigh a mask element it decides differently
+        TAP_FUSED.update(r1=r1, out=out.detach())
     return out
 
 
@@ -152,7 +154,7 @@ def mha_forward(m, xq, xk, xv):
     q = F.linear(xq_p, m.w_qs.weight)
     k = F.linear(xk, m.w_ks.weight)
     v = F.linear(xv, m.w_vs.weight)
-    o = F.attention(q, k, v, m.n_head)
+    o = F.attention(q, k, v, m.n_head, m.attention.dropout_p if _P["on"] else 0.0)     # dropout on the probabilities (Modules.py:21)
     return F.layer_norm(F.add(_dp(F.linear(o, m.fc.weight), m.dropout_p), xq_r), m.layer_norm)      # q = self.dropout(self.fc(q)) (SubLayers.py:54)
 
 

@@ -422,6 +422,16 @@ int eg_elementwise(const float* a, const float* b, float* y, int64_t n, int32_t 
 int64_t eg_conv3x3_wgrad_mfma_workspace_floats(int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout);
 int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                           float* workspace, int64_t workspace_floats, void* stream);
+/* The same gradient written in nn.Conv2d's weight layout dw[cout][cin][3][3] by the final fixed-order reduction (no permute pass behind it). */
+int eg_conv3x3_wgrad_mfma_oihw(const float* x, const float* dy, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                               float* workspace, int64_t workspace_floats, void* stream);
+/* Weight and bias gradient of nn.Linear on the split-bf16 matrix pipe (3 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate):
+ *   dw[n][k] = sum_r dy[r][n] * x[r][k]   (dy [rows, n] at pitch ldy, x [rows, k] at pitch ldx, dw at pitch lddw);  db[n] = sum_r dy[r][n] (db may be NULL).
+ * F.linear's parameter gradients under autograd (every nn.Linear of Full_model/Models_spatial_memory.py, SubLayers.py:30-84).  Deterministic: rows
+ * are split over workgroups only through fixed-order partials in `workspace` (eg_linear_wgrad_mfma_workspace_floats floats; 0 = not needed). */
+int64_t eg_linear_wgrad_mfma_workspace_floats(int32_t rows, int32_t n, int32_t k);
+int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x, int32_t ldx, float* dw, int32_t lddw, float* db, int32_t rows, int32_t n, int32_t k,
+                         float* workspace, int64_t workspace_floats, void* stream);
 /* Device-side build of the weight image eg_conv3x3 reads (eg_conv3x3_packed_floats(cin', round_up(cout',16)) floats: fp32 image, then the
  * bf16 hi / lo images), for weights that change every step.  flip_transpose = 0: conv weight [cout][cin][3][3] as in the state_dict
  * (cin' = cin, cout' = cout).  flip_transpose = 1: the filter of the input-gradient convolution, w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
@@ -457,6 +467,17 @@ int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, f
 int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
                           const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
                           int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t dk_dim, void* stream);
+/* Training pair on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32) with nn.Dropout(p) on the probabilities (Modules.py:21) from the counter-based
+ * mask of eg_dropout (counter = offset + linear index of (clip, head, query, key); epoch_dev as in eg_dropout_dev, may be NULL).  The forward stores
+ * the UNMASKED probabilities in `attn` [batch, heads, lq, lk]; the backward recomputes the mask from the same (p, seed, offset, epoch).  The backward
+ * walks the queries in chunks with K / V resident in LDS: lk <= 128 (TED 34, BEAT 60, BEAT-long 120), any lq.  p = 0 is plain attention. */
+int eg_attention_train(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, float* out, int32_t ldo, float* attn,
+                       int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t dk, float p, uint32_t seed, uint64_t offset,
+                       const int32_t* epoch_dev, void* stream);
+int eg_attention_backward_train(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
+                                const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
+                                int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t dk_dim, float p, uint32_t seed, uint64_t offset,
+                                const int32_t* epoch_dev, void* stream);
 /* losses: scale * mean smooth-L1 (beta); scale * mean CE / focal(alpha[b] per sample or NULL, gamma >= 0)
  * (train_audio_classifier_K_fold.py:95-105: `alpha * (1-pt)**gamma * ce` broadcasts alpha over the batch axis) */
 int eg_smooth_l1(const float* pred, const float* target, float* loss, float* dpred, int64_t n, float beta, float scale, float* workspace,
