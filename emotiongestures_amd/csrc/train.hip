@@ -1127,7 +1127,10 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
 }
 // column sums straight to their final place: one launch for small inputs, partials + finalize otherwise
 bool col_direct_ok(const float* a, const float* b, const float* o0, const float* o1, int64_t rows, int c) {
-    return (c & 3) == 0 && rows * (int64_t)c <= (int64_t)1 << 21 && eg_aligned16(a) && (!b || eg_aligned16(b)) && (!o0 || eg_aligned16(o0)) &&
+    // rows <= 1024: a workgroup owns 64 columns for ALL rows, so the launch has only C / 64 workgroups -- right for a [544, 512] bias / LayerNorm
+    // gradient (8 workgroups x 139 KB), wrong for a long thin input (measured: 67 us for 8192 x 32 on ONE workgroup; and a 1,984-element fp32
+    // chain per thread cost 1.6e-4 on a BatchNorm beta gradient over 31,744 rows).  Longer inputs take the 64 KB partials + double-precision fold.
+    return (c & 3) == 0 && rows <= 1024 && eg_aligned16(a) && (!b || eg_aligned16(b)) && (!o0 || eg_aligned16(o0)) &&
            (!o1 || eg_aligned16(o1));
 }
 int col_sums(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* workspace, float* o0, float* o1, float scale,
