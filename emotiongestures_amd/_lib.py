@@ -147,6 +147,10 @@ SIGNATURES = {
     "eg_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "eg_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "eg_counter_add": (C.c_int, [_P, _I, _P]),
+    "eg_sp_gate_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eg_sp_gate_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eg_tm_scale_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eg_tm_scale_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eg_linear_wgrad_mfma_workspace_floats": (_L, [_I, _I, _I]),
     "eg_linear_wgrad_mfma": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
     "eg_f32_to_bf16": (C.c_int, [_P, _P, _L, _P]),

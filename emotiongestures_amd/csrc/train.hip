@@ -1001,6 +1001,98 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 }
 __global__ void counter_add_kernel(int* c, int d) { *c += d; }
 
+// ---- Models_memory.py: the two memory nets of Prior_MemoryEncoder under autograd (the MLPs around them are ordinary Linear ops) ----------------
+// SP_Memory_Net_v1 (:239-249): for the first `chunk` predicted frames  s = sigmoid(<m_b, p_bc>),  out_bc = s p_bc + (1 - s) m_b;  later frames
+// pass through.  One wave per (clip, frame); the gate s is kept for the backward pass.
+__global__ __launch_bounds__(64) void sp_gate_fwd_kernel(const float* __restrict__ m, const float* __restrict__ p, float* __restrict__ out,
+                                                         float* __restrict__ gate, int P, int D, int chunk) {
+    const int b = blockIdx.x / P, c = blockIdx.x - b * P, lane = threadIdx.x;
+    const float* pr = p + ((size_t)b * P + c) * D;
+    float* o = out + ((size_t)b * P + c) * D;
+    if (c >= chunk) {
+        for (int d = lane; d < D; d += 64) o[d] = pr[d];
+        return;
+    }
+    const float* mr = m + (size_t)b * D;
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += mr[d] * pr[d];
+    dot = wave_sum(dot);
+    const float sg = 1.f / (1.f + expf(-dot));
+    for (int d = lane; d < D; d += 64) o[d] = sg * pr[d] + (1.f - sg) * mr[d];
+    if (lane == 0) gate[b * chunk + c] = sg;
+}
+// given g = d loss / d out:  ds = <g, p - m>,  dscore = ds s (1 - s);  dp = g s + dscore m;  dm_b = sum_c (g (1 - s) + dscore p).  One wave per clip.
+__global__ __launch_bounds__(64) void sp_gate_bwd_kernel(const float* __restrict__ m, const float* __restrict__ p, const float* __restrict__ gate,
+                                                         const float* __restrict__ g, float* __restrict__ dp, float* __restrict__ dm, int P, int D,
+                                                         int chunk) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* mr = m + (size_t)b * D;
+    for (int d = lane; d < D; d += 64) dm[(size_t)b * D + d] = 0.f;
+    for (int c = 0; c < P; ++c) {
+        const float* pr = p + ((size_t)b * P + c) * D;
+        const float* gr = g + ((size_t)b * P + c) * D;
+        float* dpr = dp + ((size_t)b * P + c) * D;
+        if (c >= chunk) {
+            for (int d = lane; d < D; d += 64) dpr[d] = gr[d];
+            continue;
+        }
+        const float sg = gate[b * chunk + c];
+        float ds = 0.f;
+        for (int d = lane; d < D; d += 64) ds += gr[d] * (pr[d] - mr[d]);
+        ds = wave_sum(ds);
+        const float dscore = ds * sg * (1.f - sg);
+        for (int d = lane; d < D; d += 64) {
+            dpr[d] = gr[d] * sg + dscore * mr[d];
+            dm[(size_t)b * D + d] += gr[d] * (1.f - sg) + dscore * pr[d];         // same lane owns element d in every pass: fixed order
+        }
+    }
+}
+// TM_Memory_Net (:289-292) behind its score: w = softmax_c(score_b), out_bc = p_bc (1 + w_bc) for c < chunk; later frames pass through.
+__global__ __launch_bounds__(64) void tm_scale_fwd_kernel(const float* __restrict__ score, const float* __restrict__ p, float* __restrict__ out,
+                                                          float* __restrict__ w, int P, int D, int chunk) {
+    const int b = blockIdx.x / P, c = blockIdx.x - b * P, lane = threadIdx.x;
+    const float* pr = p + ((size_t)b * P + c) * D;
+    float* o = out + ((size_t)b * P + c) * D;
+    float wc = 0.f;
+    if (c < chunk) {
+        const float* sr = score + (size_t)b * chunk;
+        float mx = -3.0e38f;
+        for (int j = 0; j < chunk; ++j) mx = fmaxf(mx, sr[j]);
+        float se = 0.f;
+        for (int j = 0; j < chunk; ++j) se += expf(sr[j] - mx);
+        wc = expf(sr[c] - mx) / se;
+        if (lane == 0) w[b * chunk + c] = wc;
+    }
+    for (int d = lane; d < D; d += 64) o[d] = pr[d] * (1.f + wc);
+}
+// dp = g (1 + w);  dw_c = <g_c, p_c>;  dscore_c = w_c (dw_c - sum_j w_j dw_j).  One wave per clip.
+__global__ __launch_bounds__(64) void tm_scale_bwd_kernel(const float* __restrict__ w, const float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ dp, float* __restrict__ dscore, int P, int D, int chunk) {
+    __shared__ float dw[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int c = 0; c < P; ++c) {
+        const float* pr = p + ((size_t)b * P + c) * D;
+        const float* gr = g + ((size_t)b * P + c) * D;
+        float* dpr = dp + ((size_t)b * P + c) * D;
+        const float wc = c < chunk ? w[b * chunk + c] : 0.f;
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            dpr[d] = gr[d] * (1.f + wc);
+            acc += gr[d] * pr[d];
+        }
+        if (c < chunk) {
+            acc = wave_sum(acc);
+            if (lane == 0) dw[c] = acc;
+        }
+    }
+    __syncthreads();
+    if (lane < chunk) {
+        float dot = 0.f;
+        for (int j = 0; j < chunk; ++j) dot += w[b * chunk + j] * dw[j];
+        dscore[b * chunk + lane] = w[b * chunk + lane] * (dw[lane] - dot);
+    }
+}
+
 // gradient-bucket payload conversion (train/optim.GradBuckets, payload "bf16"): fp32 -> bf16 (round to nearest even) and back (x scale)
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = f32_to_bf16_rne(x[i]);
@@ -1409,6 +1501,34 @@ extern "C" int eg_kld(const float* mu, const float* logvar, float* loss, float* 
     EG_REQUIRE(mu && logvar && loss && n > 0 && d > 0 && ((dmu == nullptr) == (dlogvar == nullptr)), EG_ERR_BAD_ARG, "eg_kld: bad argument");
     hipLaunchKernelGGL(kld_kernel, dim3(1), dim3(256), 0, ST, mu, logvar, dmu, dlogvar, loss, n, d, scale);
     return eg_check_launch("kld");
+}
+
+extern "C" int eg_sp_gate_forward(const float* mem, const float* pred, float* out, float* gate, int32_t batch, int32_t frames, int32_t dim, int32_t chunk,
+                                  void* stream) {
+    EG_REQUIRE(mem && pred && out && gate && batch > 0 && frames > 0 && dim > 0 && chunk >= 0 && chunk <= frames, EG_ERR_BAD_ARG, "eg_sp_gate_forward: bad argument");
+    hipLaunchKernelGGL(sp_gate_fwd_kernel, dim3(batch * frames), dim3(64), 0, ST, mem, pred, out, gate, frames, dim, chunk);
+    return eg_check_launch("sp_gate_forward");
+}
+extern "C" int eg_sp_gate_backward(const float* mem, const float* pred, const float* gate, const float* dout, float* dpred, float* dmem, int32_t batch,
+                                   int32_t frames, int32_t dim, int32_t chunk, void* stream) {
+    EG_REQUIRE(mem && pred && gate && dout && dpred && dmem && batch > 0 && frames > 0 && dim > 0 && chunk >= 0 && chunk <= frames, EG_ERR_BAD_ARG,
+               "eg_sp_gate_backward: bad argument");
+    hipLaunchKernelGGL(sp_gate_bwd_kernel, dim3(batch), dim3(64), 0, ST, mem, pred, gate, dout, dpred, dmem, frames, dim, chunk);
+    return eg_check_launch("sp_gate_backward");
+}
+extern "C" int eg_tm_scale_forward(const float* score, const float* pred, float* out, float* w, int32_t batch, int32_t frames, int32_t dim, int32_t chunk,
+                                   void* stream) {
+    EG_REQUIRE(score && pred && out && w && batch > 0 && frames > 0 && dim > 0 && chunk > 0 && chunk <= frames && chunk <= 64, EG_ERR_BAD_ARG,
+               "eg_tm_scale_forward: bad argument");
+    hipLaunchKernelGGL(tm_scale_fwd_kernel, dim3(batch * frames), dim3(64), 0, ST, score, pred, out, w, frames, dim, chunk);
+    return eg_check_launch("tm_scale_forward");
+}
+extern "C" int eg_tm_scale_backward(const float* w, const float* pred, const float* dout, float* dpred, float* dscore, int32_t batch, int32_t frames,
+                                    int32_t dim, int32_t chunk, void* stream) {
+    EG_REQUIRE(w && pred && dout && dpred && dscore && batch > 0 && frames > 0 && dim > 0 && chunk > 0 && chunk <= frames && chunk <= 64, EG_ERR_BAD_ARG,
+               "eg_tm_scale_backward: bad argument");
+    hipLaunchKernelGGL(tm_scale_bwd_kernel, dim3(batch), dim3(64), 0, ST, w, pred, dout, dpred, dscore, frames, dim, chunk);
+    return eg_check_launch("tm_scale_backward");
 }
 
 extern "C" int eg_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {

@@ -871,6 +871,64 @@ def conv_transpose1d_cl(x_blc, w, b=None, stride=2, pad=1, out_pad=1):
     return _ConvT1dCL.apply(x_blc, w, b, stride, pad, out_pad)
 
 
+class _SPGate(torch.autograd.Function):
+    """SP_Memory_Net_v1's gate (Models_memory.py:239-249): for c < chunk  s = sigmoid(<mem_b, pred_bc>), out_bc = s pred_bc + (1 - s) mem_b."""
+
+    @staticmethod
+    def forward(ctx, mem, pred, chunk):
+        lib = _lib()
+        m, p = _chk(mem), _chk(pred)
+        B, P, D = p.shape
+        out, gate = torch.empty_like(p), torch.empty(B, max(chunk, 1), device=p.device)
+        L.check(lib.eg_sp_gate_forward(_ptr(m), _ptr(p), _ptr(out), _ptr(gate), B, P, D, chunk, _stream(p.device)), "eg_sp_gate_forward")
+        ctx.save_for_backward(m, p, gate)
+        ctx.chunk = chunk
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        m, p, gate = ctx.saved_tensors
+        B, P, D = p.shape
+        gd = _chk(g)
+        dp, dm = torch.empty_like(p), torch.empty_like(m)
+        L.check(lib.eg_sp_gate_backward(_ptr(m), _ptr(p), _ptr(gate), _ptr(gd), _ptr(dp), _ptr(dm), B, P, D, ctx.chunk, _stream(p.device)), "eg_sp_gate_backward")
+        return dm, dp, None
+
+
+def sp_memory_gate(mem, pred, chunk: int):
+    return _SPGate.apply(mem, pred, int(chunk))
+
+
+class _TMScale(torch.autograd.Function):
+    """TM_Memory_Net behind its score (Models_memory.py:290-292): w = softmax(score, dim=1), out_bc = pred_bc (1 + w_bc) for c < chunk."""
+
+    @staticmethod
+    def forward(ctx, score, pred, chunk):
+        lib = _lib()
+        sc, p = _chk(score), _chk(pred)
+        B, P, D = p.shape
+        out, w = torch.empty_like(p), torch.empty(B, chunk, device=p.device)
+        L.check(lib.eg_tm_scale_forward(_ptr(sc), _ptr(p), _ptr(out), _ptr(w), B, P, D, chunk, _stream(p.device)), "eg_tm_scale_forward")
+        ctx.save_for_backward(w, p)
+        ctx.chunk = chunk
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        w, p = ctx.saved_tensors
+        B, P, D = p.shape
+        gd = _chk(g)
+        dp, ds = torch.empty_like(p), torch.empty_like(w)
+        L.check(lib.eg_tm_scale_backward(_ptr(w), _ptr(p), _ptr(gd), _ptr(dp), _ptr(ds), B, P, D, ctx.chunk, _stream(p.device)), "eg_tm_scale_backward")
+        return ds, dp, None
+
+
+def tm_memory_scale(score, pred, chunk: int):
+    return _TMScale.apply(score, pred, int(chunk))
+
+
 class _Reparam(torch.autograd.Function):
     """z = eps * exp(0.5 * logvar) + mu (MLP_Reconstruct_v3.reparameterize, CAVE/BEAT_CVAE.py:389-399); eps is an input."""
 

@@ -217,13 +217,30 @@ def _seq_linear(seq, idx, x, relu_between=False, drop=0.0):
 
 
 def prior_encoder_forward(pe, prior):
-    """Prior_MemoryEncoder.forward (Models_spatial_memory.py:378-390), spatial variant: SP_Memory_Net_v2 returns its input
-    (:276-295), so its parameters receive no gradient and it is not evaluated here (its BatchNorm running buffers stay untouched)."""
+    """Prior_MemoryEncoder.forward.  Spatial variant (Models_spatial_memory.py:378-390): SP_Memory_Net_v2 returns its input (:276-295), so its
+    parameters receive no gradient and it is not evaluated here (its BatchNorm running buffers stay untouched).  Memory variant
+    (Models_memory.py:336-346): SP_Memory_Net_v1's sigmoid gate (:233-251), then TM_Memory_Net (:282-293), whose score mem (mem^T pe) sums over
+    the BATCH -- the clips of a training batch are coupled exactly as in the reference."""
     x = prior.transpose(1, 2).contiguous()                                       # [B, L = pose_dim, C = prior frames]
     c0, b0, c1, b1 = pe.pred_conv[0], pe.pred_conv[2], pe.pred_conv[3], pe.pred_conv[5]
     h = F.batch_norm(F.relu(F.conv1d_cl(x, c0.weight, c0.bias, 1, 1, 1)), b0)
     h = F.batch_norm(F.relu(F.conv1d_cl(h, c1.weight, c1.bias, 1, 1, 1)), b1)
-    out = torch.cat((prior, h.transpose(1, 2)), 1)                               # [B, frames, pose_dim]
+    pred = h.transpose(1, 2)                                                     # [B, frames - prior, pose_dim]
+    if hasattr(pe, "temporal_memory"):
+        B, P = prior.shape[0], prior.shape[1]
+        sm, tm = pe.spatial_memory, pe.temporal_memory
+        chunk = sm.chunk_length
+        tail = prior[:, P - chunk:, :].reshape(B, -1).contiguous()               # initial_feature[:, prior_frames - chunk:, :] (:237, :285); an input: no gradient
+        mem = _seq_linear(sm.spatial_chunk_encoder, (0, 2), tail, drop=0.2)      # [B, pose_dim]
+        pred = F.sp_memory_gate(mem, pred.contiguous(), chunk)                   # spatial (:341)
+        pa, pb = F.fork(pred)
+        mem2 = _seq_linear(tm.temporal_chunk_encoder, (0, 2), tail, drop=0.2)    # [B, pose_dim]
+        enc = _seq_linear(tm.temporal_memory_encoder, (0, 2), pa[:, :chunk, :].reshape(B, -1), drop=0.2)       # [B, chunk]
+        ma, mb = F.fork(mem2)
+        tt = F.linear(enc.t(), ma.t())                                           # (mem^T enc)^T = enc^T mem: [chunk, pose_dim]  (:288, the sum over the batch)
+        score = F.linear(mb, tt)                                                 # mem (mem^T enc): [B, chunk]  (:289)
+        pred = F.tm_memory_scale(score, pb, chunk)                               # temporal (:290-292)
+    out = torch.cat((prior, pred), 1)                                            # [B, frames, pose_dim]
     return _seq_linear(pe.post_header, (0, 2), out.contiguous(), drop=0.2)
 
 
@@ -256,10 +273,9 @@ def text_encoder_forward_nograd(te, text):
 
 
 def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_feature=None):
-    """Transformer.forward in train() mode (spatial variant).  The text branch does not feed the pose or the emotion head
-    (:577,616), so it is evaluated without gradient on the inference kernels."""
-    if model._variant != "spatial":
-        raise NotImplementedError("train-mode forward: Models_spatial_memory variant only (TM_Memory_Net couples the batch)")
+    """Transformer.forward in train() mode, both variants (Models_spatial_memory.py:566-616, Models_memory.py:521-565: they differ in the prior /
+    memory encoder only).  The text branch does not feed the pose or the emotion head (:577,616), so it is evaluated without gradient on the
+    inference kernels."""
     _dropout_on(model)
     try:
         text_embedding = text_encoder_forward_nograd(model.text_encoder, text)

@@ -494,6 +494,18 @@ int eg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int eg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, const int32_t* step_dev, void* stream);
 int eg_counter_add(int32_t* counter, int32_t delta, void* stream);
+/* The memory nets of Full_model/Models_memory.py's Prior_MemoryEncoder under autograd (the MLPs around them are ordinary Linear operators).
+ * SP_Memory_Net_v1.forward (:233-251): for the first `chunk` of the `frames` predicted frames  s = sigmoid(<mem_b, pred_bc>),
+ * out_bc = s pred_bc + (1 - s) mem_b; later frames pass through (mem [batch, dim], pred / out [batch, frames, dim], gate [batch, chunk] saved
+ * for the backward, which returns dpred and dmem).
+ * TM_Memory_Net.forward (:288-292) behind its batch-coupled score [batch, chunk] = mem (mem^T pe):  w = softmax(score, dim=1),
+ * out_bc = pred_bc (1 + w_bc) for c < chunk; the backward returns dpred and dscore. */
+int eg_sp_gate_forward(const float* mem, const float* pred, float* out, float* gate, int32_t batch, int32_t frames, int32_t dim, int32_t chunk, void* stream);
+int eg_sp_gate_backward(const float* mem, const float* pred, const float* gate, const float* dout, float* dpred, float* dmem, int32_t batch,
+                        int32_t frames, int32_t dim, int32_t chunk, void* stream);
+int eg_tm_scale_forward(const float* score, const float* pred, float* out, float* w, int32_t batch, int32_t frames, int32_t dim, int32_t chunk, void* stream);
+int eg_tm_scale_backward(const float* w, const float* pred, const float* dout, float* dpred, float* dscore, int32_t batch, int32_t frames, int32_t dim,
+                         int32_t chunk, void* stream);
 /* Gradient-bucket payload conversion for the data-parallel all-reduce (bf16 buckets, 79 MB instead of 158 MB per step over
  * xGMI): fp32 -> bf16 round-to-nearest-even, and bf16 -> fp32 times `scale`. */
 int eg_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);

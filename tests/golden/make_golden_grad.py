@@ -92,6 +92,40 @@ def gen_case(out, seed=0, batch=2):
     print("gen loss", loss.item(), "params with grad", sum(p.grad is not None for p in m.parameters()), "without", len(out["gen/nograd"]))
 
 
+def genmem_case(out, seed=3, batch=4):
+    """Full_model.Models_memory.Transformer (SP_Memory_Net_v1 gate + the batch-coupled TM_Memory_Net, Models_memory.py:233-251,282-293) in
+    train() mode at a FIXED batch of 4 (TM sums over the batch), dropout p = 0, same loss as `gen`."""
+    stub()
+    from Full_model.Models_memory import Transformer
+    args = SimpleNamespace(chunk=4, hidden_size=300, n_layers=3, freeze_wordembed=False, wordembed_dim=300, dropout_prob=0.1)
+    lang = SimpleNamespace(n_words=200, word_embedding_weights=None)
+    m = Transformer(args, lang, frames=34, pose_dim=126, prior_frames=4, d_word_vec=512, d_model=512, d_inner=2048, n_layers=3,
+                    n_head=8, d_k=64, d_v=64)
+    load_synth_weights(m, seed)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    target = torch.from_numpy(train_targets(batch, 34, 126, seed))
+    label = torch.from_numpy(inp["label"]).argmax(1)
+    pose, emo, sem, pred, txt = m(torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]), torch.from_numpy(inp["pre_pose"]), None)
+    loss = 100.0 * F.smooth_l1_loss(pose, target) + F.cross_entropy(pred, label)
+    loss.backward()
+    out["genmem/loss"] = np.float64(loss.item())
+    out["genmem/pose"] = pose.detach().numpy()
+    out["genmem/emotion_prediction"] = pred.detach().numpy()
+    out["genmem/meta"] = np.asarray([batch, seed], np.int64)
+    # only the prior / memory encoder differs from the `gen` case: keep its gradients plus a few downstream / upstream witnesses
+    keep = ("prior_seq_encoder.", "post_projector.6.", "decoder.layer_stack.0.enc_attn.w_qs", "audio_encoder.fc2.", "emotion_classifer_header.6.")
+    sub = {}
+    fingerprint(sub, "genmem", m)
+    for k, v in sub.items():
+        if k == "genmem/nograd" or any(k.startswith("genmem/g/" + pre) for pre in keep):
+            out[k] = v
+    print("genmem loss", loss.item(), "kept", sum(1 for k in out if k.startswith("genmem/g/") and k.endswith("/norm")), "gradient fingerprints; without grad", len(out["genmem/nograd"]))
+
+
 def emo_case(out, seed=31, batch=2):
     stub()
     os.chdir(REF)
@@ -161,6 +195,7 @@ def main():
     torch.set_num_threads(8)
     out = {}
     gen_case(out)
+    genmem_case(out)
     emo_case(out)
     cvae_case(out)
     path = os.path.join(ROOT, "tests", "golden", "grads.npz")

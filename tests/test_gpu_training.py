@@ -489,12 +489,95 @@ def test_cvae_train_step_gradients_match_oracle():
 def test_train_mode_is_refused_elsewhere_and_cpu_is_refused():
     from emotiongestures_amd import _lib as L
     from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.modules import MultiHeadAttention
     with pytest.raises(L.EgError):
         F.linear(torch.zeros(2, 4), torch.zeros(3, 4))
-    m = build_mirror("memory", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
-    inp = synth_inputs(4, 34, 126, 4, seed=0)
+    mha = MultiHeadAttention(8, 512, 64, 64).to(DEV).train()          # a block used on its own has no train-mode path: refused, not approximated
+    x = torch.zeros(2, 34, 512, device=DEV)
     with pytest.raises(NotImplementedError):
-        m(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV), torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+        mha(x, x, x)
+
+
+def test_memory_nets_forward_backward_match_reference_golden():
+    """SP_Memory_Net_v1's gate and the batch-coupled TM_Memory_Net (Full_model/Models_memory.py:233-251,282-293) through the train-mode prior
+    encoder's operators, against the reference's own modules under torch autograd (tests/golden/make_golden_memory_grad.py: inputs that keep the
+    sigmoid / softmax out of saturation, fixed batch of 4): outputs, gradients of both inputs, every parameter gradient."""
+    from types import SimpleNamespace
+    from emotiongestures_amd.modules import SP_Memory_Net_v1, TM_Memory_Net
+    from emotiongestures_amd.synth import load_synth_weights
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train import nets
+    z = np.load(os.path.join(GOLDEN, "memory_grads.npz"))
+    B, P, PRED, D, CHUNK, SEED = [int(v) for v in z["meta"]]
+    mk = lambda tag, n: (hash_unit(tag, n, SEED) - 0.5).astype(np.float32)
+    prior_np, pred_np, g_np = mk("mem.prior", B * P * D).reshape(B, P, D), mk("mem.pred", B * PRED * D).reshape(B, PRED, D), mk("mem.g", B * PRED * D).reshape(B, PRED, D)
+    args = SimpleNamespace(chunk=CHUNK)
+    for name, cls in (("sp", SP_Memory_Net_v1), ("tm", TM_Memory_Net)):
+        m = cls(args, P, PRED, D, 512)
+        load_synth_weights(m, SEED)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.mul_(0.2)
+        m.to(DEV)
+        prior = torch.from_numpy(prior_np).to(DEV).requires_grad_(True)
+        pred = torch.from_numpy(pred_np).to(DEV).requires_grad_(True)
+        tail = prior[:, P - CHUNK:, :].reshape(B, -1)
+        if name == "sp":
+            mem = nets._seq_linear(m.spatial_chunk_encoder, (0, 2), tail)
+            y = F.sp_memory_gate(mem, pred, CHUNK)
+        else:
+            pa, pb = F.fork(pred)
+            mem2 = nets._seq_linear(m.temporal_chunk_encoder, (0, 2), tail)
+            enc = nets._seq_linear(m.temporal_memory_encoder, (0, 2), pa[:, :CHUNK, :].reshape(B, -1))
+            ma, mb = F.fork(mem2)
+            y = F.tm_memory_scale(F.linear(mb, F.linear(enc.t(), ma.t())), pb, CHUNK)
+        y.backward(torch.from_numpy(g_np).to(DEV))
+        assert rel(y, torch.from_numpy(z[f"{name}/out"])) < 1e-6, name
+        assert rel(pred.grad, torch.from_numpy(z[f"{name}/dpred"])) < 1e-5, (name, rel(pred.grad, torch.from_numpy(z[f"{name}/dpred"])))
+        assert prior.grad is not None and rel(prior.grad, torch.from_numpy(z[f"{name}/dprior"])) < 2e-5, (name, rel(prior.grad, torch.from_numpy(z[f"{name}/dprior"])))
+        for k, p_ in m.named_parameters():
+            gv = p_.grad.detach().reshape(-1).double().cpu().numpy()
+            stride = max(1, gv.size // 64)
+            rs, rn = z[f"{name}/p/{k}/sample"], float(z[f"{name}/p/{k}/norm"])
+            e = max(np.linalg.norm(gv[::stride][:64] - rs) / np.linalg.norm(rs), abs(np.linalg.norm(gv) - rn) / rn)
+            assert e < 2e-5, f"{name} {k}: {e:.2e}"
+
+
+def test_memory_variant_train_step_matches_reference_golden():
+    """Models_memory.Transformer in train() mode at the fixed batch of 4 (TM_Memory_Net sums over the batch): loss and outputs against the
+    reference's (tests/golden/grads.npz, case genmem), the prior / memory encoder's parameter gradients and witnesses up- and downstream of it.
+    TM_Memory_Net's own gradients are ~1e-7 here (its softmax saturates at these weights: the non-saturated regime is pinned by
+    test_memory_nets_forward_backward_match_reference_golden), so they are held to an absolute bound."""
+    from emotiongestures_amd.train import functional as F
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    batch, seed = [int(v) for v in z["genmem/meta"]]
+    model = build_mirror("memory", 34, 126, 4, 4, seed=seed, precision="f32").to(DEV).train()
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    target = torch.from_numpy((hash_unit("train.target_pose", batch * 34 * 126, seed) - 0.5).astype(np.float32).reshape(batch, 34, 126)).to(DEV)
+    label = torch.from_numpy(inp["label"]).argmax(1).to(DEV)
+    pose, _e, _s, pred, _t = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV), torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+    loss = F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label))
+    loss.backward()
+    assert abs(float(loss) - float(z["genmem/loss"])) / float(z["genmem/loss"]) < 1e-5
+    assert np.abs(pose.detach().cpu().numpy() - z["genmem/pose"]).max() < 1e-4
+    assert np.abs(pred.detach().cpu().numpy() - z["genmem/emotion_prediction"]).max() < 1e-4
+    params = dict(model.named_parameters())
+    keys = sorted({k.split("/g/")[1].rsplit("/", 1)[0] for k in z.files if k.startswith("genmem/g/")})
+    assert len(keys) >= 30
+    worst = 0.0
+    for k in keys:
+        gv = params[k].grad
+        assert gv is not None, k
+        gv = gv.detach().reshape(-1).double().cpu().numpy()
+        stride = max(1, gv.size // 64)
+        rs, rn = z[f"genmem/g/{k}/sample"].astype(np.float64), float(z[f"genmem/g/{k}/norm"])
+        if "temporal_memory" in k:
+            assert np.linalg.norm(gv) < 1e-4 and rn < 1e-4, k          # saturated softmax: both sides ~1e-7
+            continue
+        e = max(np.linalg.norm(gv[::stride][:64] - rs) / np.linalg.norm(rs), abs(np.linalg.norm(gv) - rn) / rn)
+        worst = max(worst, e)
+        assert e < (2e-2 if k.startswith("audio_encoder.feat_extractor.") else 2e-4), f"{k}: {e:.2e}"
+    print(f"memory variant: {len(keys)} gradient fingerprints, worst relative error vs the reference {worst:.2e}")
 
 
 def test_dropout_mask_stream_and_generator_step_with_dropout():
