@@ -1,0 +1,107 @@
+"""The EmotionNet K-fold loop end to end on the GPU (emotiongestures_amd/train/loops.py; train_audio_classifier_K_fold.py:109-200): samples come
+from datapath.DataPreprocessor -> DictStore -> datapath.SpeechMotionDataset (the reference's record / item formats), a checkpoint written by
+the loop reloads into a fresh model with bit-identical logits, and two gloo ranks sharing this box's GPU end a data-parallel run with equal
+parameters."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+
+# n_poses 62 at 15 fps = 4.13 s of audio -> a 128-frame spectrogram: EmotionNet's [B,128,128] input (model/audio_emotion_classifer.py:39-44)
+N_POSES, STRIDE, FPS = 62, 20, 15
+
+
+def build_dataset(n_clips=6, seed=0):
+    from emotiongestures_amd import datapath as D
+    from emotiongestures_amd.synth import synth_clip
+    eids = [1, 66, 75, 82, 90, 100, 105, 115]               # one recording id per emotion class (lmdb_loader_BEAT_full.py:78-118)
+    videos = []
+    for i in range(n_clips):
+        clip = synth_clip(seed=seed + i, duration=9.0)
+        # the label is encoded in the spectrogram (a per-class band offset), so a short run has something to learn
+        k = i % 8
+        spec = clip["audio_feat"].astype(np.float32)
+        spec[16 * k:16 * k + 16, :] = np.minimum(spec[16 * k:16 * k + 16, :] + 40.0, 0.0)
+        clip["audio_feat"] = spec.astype(np.float16)
+        videos.append({"eid": "1_spk_0_%d_%d" % (eids[k], eids[k]), "clips": [clip]})
+    store = D.DictStore()
+    D.DataPreprocessor(videos, store, N_POSES, STRIDE, FPS).run()
+    ds = D.SpeechMotionDataset(store, N_POSES, STRIDE, FPS)
+    assert ds.expected_spectrogram_length == 128 and len(ds) >= 12
+    return ds
+
+
+def test_k_fold_loop_trains_validates_saves_and_reloads(tmp_path):
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    from emotiongestures_amd.train import loops
+    ds = build_dataset()
+    logs = []
+    hist = loops.train_k_fold(ds, device=DEV, n_splits=2, total_epoch=2, batch_size=4, lr=1e-4, val_every=2, save_dir=str(tmp_path), test_dataset=ds,
+                              seed=1, max_iters_per_fold=4, log=logs.append)
+    assert [h["fold"] for h in hist] == [1, 2]
+    for h in hist:
+        assert h["iterations"] == 4 and len(h["loss"]) == 4 and all(np.isfinite(h["loss"]))
+        assert [it for it, _ in h["val_acc"]] == [2, 4] and [it for it, _ in h["test_acc"]] == [2, 4]
+        assert all(0.0 <= a <= 100.0 for _, a in h["val_acc"] + h["test_acc"])
+        assert h["confusion"].sum() == (len(ds) // 4) * 4
+        assert len(h["checkpoints"]) == 2 and all(os.path.exists(p) for p in h["checkpoints"])
+        assert os.path.basename(h["checkpoints"][-1]).startswith(f"checkpoint_fold{h['fold']}_epoch")
+    assert any("Val Accuracy" in l for l in logs) and any("Test Accuracy" in l for l in logs)
+    # the last checkpoint of fold 2 was written right after iteration 4 = the model's final state: reload -> identical logits
+    model = hist[-1]["model"].eval()
+    fresh = loops.load_checkpoint(EmotionNet(precision="f32"), hist[-1]["checkpoints"][-1]).to(DEV).eval()
+    spec, _ = loops._collate(ds, np.arange(4), 128)
+    with torch.no_grad():
+        a, b = model(spec.to(DEV)), fresh(spec.to(DEV))
+    assert torch.equal(a, b)
+    # and the folds differ (fresh model per fold, different training subsets)
+    assert hist[0]["loss"] != hist[1]["loss"]
+
+
+_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, os.environ["EG_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EG_ROOT"], "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    from test_gpu_loops import build_dataset
+    from emotiongestures_amd.train import loops
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    ds = build_dataset()
+    hist = loops.train_k_fold(ds, device=dev, n_splits=2, total_epoch=1, batch_size=2, lr=1e-4, val_every=100, seed=1, max_iters_per_fold=3, folds=[1],
+                              log=lambda s: None)
+    flat = torch.cat([p.detach().reshape(-1) for p in hist[0]["model"].parameters()]).cpu()
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert torch.equal(other[0], other[1]), float((other[0] - other[1]).abs().max())       # same start (broadcast), same averaged gradients
+    assert hist[0]["iterations"] == 3 and all(np.isfinite(hist[0]["loss"]))
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok", hist[0]["loss"])
+''')
+
+
+def test_k_fold_loop_two_gloo_ranks_share_this_gpu(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\\n{o[-3000:]}"
+    # the two ranks saw different batches: their per-iteration losses differ, their parameters (checked in the workers) do not
+    assert outs[0].split("ok")[-1] != outs[1].split("ok")[-1]

@@ -66,6 +66,38 @@ def test_generator_gradients_oracle_vs_reference_golden():
     print("generator gradients: worst relative error vs the reference", worst)
 
 
+def test_memory_variant_gradients_oracle_vs_reference_golden():
+    """Models_memory.Transformer (SP_Memory_Net_v1 gate + batch-coupled TM_Memory_Net) in train mode at the fixed batch of 4: the oracle's
+    autograd against the reference's loss and the gradient fingerprints kept for this case (prior / memory encoder + witnesses)."""
+    from oracle import emogest_oracle as O
+    from emotiongestures_amd.builders import build_mirror
+    z = np.load(os.path.join(GOLDEN, "grads.npz"))
+    batch, seed = [int(v) for v in z["genmem/meta"]]
+    sd = {k: v.detach().clone() for k, v in build_mirror("memory", 34, 126, 4, 4, seed=seed).state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    target = torch.from_numpy((hash_unit("train.target_pose", batch * 34 * 126, seed) - 0.5).astype(np.float32).reshape(batch, 34, 126))
+    label = torch.from_numpy(inp["label"]).argmax(1)
+    loss, pose, pred = O.generator_train_loss(sd, O.GenCfg(variant="memory"), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                              torch.from_numpy(inp["pre_pose"]), target, label)
+    loss.backward()
+    assert abs(loss.item() - float(z["genmem/loss"])) / float(z["genmem/loss"]) < 1e-5
+    assert np.abs(pose.detach().numpy() - z["genmem/pose"]).max() < 1e-4
+    keys = sorted({k.split("/g/")[1].rsplit("/", 1)[0] for k in z.files if k.startswith("genmem/g/")})
+    assert len(keys) >= 30
+    for k in keys:
+        g = sd[k].grad.reshape(-1).double().numpy()
+        stride = max(1, g.size // NS)
+        rs, rn = z[f"genmem/g/{k}/sample"], float(z[f"genmem/g/{k}/norm"])
+        if "temporal_memory" in k:              # saturated softmax at these weights: ~1e-7 on both sides
+            assert np.linalg.norm(g) < 1e-4 and rn < 1e-4
+            continue
+        e = max(np.linalg.norm(g[::stride][:NS] - rs) / np.linalg.norm(rs), abs(np.linalg.norm(g) - rn) / rn)
+        assert e < 2e-4, f"{k}: {e:.2e}"
+
+
 def test_emotion_net_gradients_oracle_vs_reference_golden():
     from oracle import emogest_oracle as O
     import json

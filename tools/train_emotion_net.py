@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""The reference's one training loop (train_audio_classifier_K_fold.py:109-200) on the HIP training path, synthetic data:
-EmotionNet in train() mode, 100 x FocalLoss(alpha from class counts, gamma 2), Adam(lr, betas=(0.5, 0.999), weight_decay=1e-5),
-periodic validation accuracy (compute_acc, :57-62) in eval() mode on the inference kernels.
+"""Driver of the product loop `emotiongestures_amd.train.loops.train_k_fold` (the reference's train_audio_classifier_K_fold.py:109-200) on a
+synthetic BEAT-shaped data set built through the reference's own data path: clips -> datapath.DataPreprocessor -> sample store ->
+datapath.SpeechMotionDataset -> audio_classifier_collate_fn -> EmotionNet on the HIP training operators.
 
-    python tools/train_emotion_net.py [--steps 30] [--batch 8] [--lr 1e-4]
+    python tools/train_emotion_net.py [--clips 16] [--folds 2] [--epochs 2] [--batch 8] [--lr 1e-4] [--precision f32|bf16x3] [--save DIR]
 
 Synthetic task: the label is encoded in the spectrogram (a per-class band offset), so the loss must fall and accuracy rise."""
 import argparse
@@ -15,51 +15,39 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
-from emotiongestures_amd.synth import hash_unit, load_synth_weights
-from emotiongestures_amd.train import functional as F
-from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+from emotiongestures_amd import datapath as D
+from emotiongestures_amd.synth import synth_clip
+from emotiongestures_amd.train import loops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=30)
-ap.add_argument("--batch", type=int, default=8)          # the script's FocalLoss broadcasts its 8 class weights over the batch axis: batch 8
+ap.add_argument("--clips", type=int, default=16)
+ap.add_argument("--folds", type=int, default=2)
+ap.add_argument("--epochs", type=int, default=2)
+ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--lr", type=float, default=1e-4)
+ap.add_argument("--val-every", type=int, default=5)
+ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3"))
+ap.add_argument("--save", default=None)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 
-
-def batch(step, n):
-    lab = torch.from_numpy((hash_unit("lab", n, step) * 8).astype(np.int64) % 8)
-    x = (-80.0 * hash_unit("x", n * 128 * 128, step)).astype(np.float16).astype(np.float32).reshape(n, 128, 128)
-    x = torch.from_numpy(x)
-    for i, l in enumerate(lab.tolist()):
-        x[i, 16 * l:16 * l + 16, :] += 30.0
-    return x.clamp_(-80, 0), lab
-
-
-net = load_synth_weights(EmotionNet(precision="f32"), 31).to(dev).train()
-fp = flatten_parameters(net)
-opt = FlatAdam(fp, lr=args.lr, betas=(0.5, 0.999), weight_decay=1e-5)            # :128
-class_count = np.ones(8)
-train_s = 0.0
-for step in range(args.steps):
-    t0 = time.perf_counter()
-    x, lab = batch(step, args.batch)
-    for l in lab.tolist():
-        class_count[l] += 1
-    class_weights = class_count.sum() / (len(class_count) * class_count)       # :146-148
-    alpha = torch.tensor(class_weights[:args.batch] if args.batch == 8 else [1.0] * args.batch, dtype=torch.float32)
-    net.train()
-    opt.zero_grad()
-    loss = F.focal_loss(net(x.to(dev)), lab.to(dev), alpha, 2.0, 100.0)         # criterion(output, label) * 100  (:168)
-    loss.backward()
-    opt.step()
-    torch.cuda.synchronize()
-    train_s += time.perf_counter() - t0
-    if step % 5 == 4 or step == args.steps - 1:
-        tv = time.perf_counter()
-        net.eval()              # the inference engine repacks the updated weights on the host (the 65536 x 4096 first Linear dominates)
-        with torch.no_grad():
-            vx, vl = batch(10_000 + step, 16)
-            acc = float((net(vx.to(dev)).argmax(1).cpu() == vl).float().mean())
-        print(f"step {step + 1:3d}  loss {float(loss.detach()):9.3f}  val acc {100 * acc:5.1f} %  ({train_s / (step + 1) * 1e3:.0f} ms per training step; validation incl. repack {time.perf_counter() - tv:.1f} s)")
+eids = [1, 66, 75, 82, 90, 100, 105, 115]                   # one BEAT recording id per emotion class (lmdb_loader_BEAT_full.py:78-118)
+videos = []
+for i in range(args.clips):
+    clip = synth_clip(seed=i, duration=9.0)
+    k = i % 8
+    spec = clip["audio_feat"].astype(np.float32)
+    spec[16 * k:16 * k + 16, :] = np.minimum(spec[16 * k:16 * k + 16, :] + 40.0, 0.0)
+    clip["audio_feat"] = spec.astype(np.float16)
+    videos.append({"eid": "1_spk_0_%d_%d" % (eids[k], eids[k]), "clips": [clip]})
+store = D.DictStore()
+D.DataPreprocessor(videos, store, 62, 20, 15).run()          # 62 poses at 15 fps = a 128-frame spectrogram per sample
+ds = D.SpeechMotionDataset(store, 62, 20, 15)
+print(f"{len(ds)} samples, spectrogram [128, {ds.expected_spectrogram_length}]")
+t0 = time.perf_counter()
+hist = loops.train_k_fold(ds, device=dev, n_splits=args.folds, total_epoch=args.epochs, batch_size=args.batch, lr=args.lr, val_every=args.val_every,
+                          save_dir=args.save, test_dataset=ds, precision=args.precision)
+torch.cuda.synchronize()
+for h in hist:
+    print(f"fold {h['fold']}: {h['iterations']} iterations, loss {h['loss'][0]:.3f} -> {h['loss'][-1]:.3f}, val {h['val_acc'][-1:]} test {h['test_acc'][-1:]}")
+print(f"{time.perf_counter() - t0:.1f} s")
