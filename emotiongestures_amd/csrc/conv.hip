@@ -1013,9 +1013,11 @@ extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, 
                              const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin,
                              int32_t cout, int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
     EG_REQUIRE(x && w && y && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3: null pointer or empty shape");
-    EG_REQUIRE((gate == nullptr) == (residual == nullptr), EG_ERR_BAD_ARG, "eg_conv3x3_se: gate and residual come together");
-    EG_REQUIRE(!gate || (!nchw_out && stride == 1 && cout % 4 == 0 && eg_aligned16(gate) && eg_aligned16(residual) && residual != y), EG_ERR_BAD_ARG,
-               "eg_conv3x3_se: the fused SE tail needs NHWC output, stride 1, cout %% 4 == 0 and a residual buffer distinct from y");
+    // gate + residual: relu(v * gate + residual) (the fused SE tail); residual alone: v + residual, no ReLU (the training path's fused fan-in add:
+    // an input gradient that lands on a tensor with a second consumer, train/functional.py conv3x3(passthrough=True))
+    EG_REQUIRE(!gate || residual, EG_ERR_BAD_ARG, "eg_conv3x3_se: a gate needs a residual");
+    EG_REQUIRE(!residual || (!nchw_out && stride == 1 && cout % 4 == 0 && (!gate || eg_aligned16(gate)) && eg_aligned16(residual) && residual != y),
+               EG_ERR_BAD_ARG, "eg_conv3x3_se: the fused residual needs NHWC output, stride 1, cout %% 4 == 0 and a residual buffer distinct from y");
     EG_REQUIRE(eg_aligned16(x) && eg_aligned16(w) && eg_aligned16(y), EG_ERR_ALIGN, "eg_conv3x3: pointers must be 16-byte aligned");
     EG_REQUIRE(stride == 1 || stride == 2, EG_ERR_UNSUPPORTED, "eg_conv3x3: stride %d", stride);
     EG_REQUIRE(precision >= 0 && precision <= 2, EG_ERR_BAD_ARG, "eg_conv3x3: precision %d", precision);

@@ -407,7 +407,7 @@ class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(k=3, pad=1, stride s) on NHWC activations; weight OIHW as in the reference's state_dict."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False):
+    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False, passthrough=False):
         lib = _lib()
         xd, wd = _chk(x, "x"), _chk(w, "weight")
         gap = None
@@ -450,14 +450,19 @@ class _Conv3x3(torch.autograd.Function):
         ctx.save_for_backward(xd, wd, y if (relu and not defer_mask) else None)      # defer_mask: the consumer (batch_norm(relu_input=True)) applies it
         ctx.stride, ctx.has_b, ctx.need_dx = stride, b is not None, x.requires_grad
         ctx.params = (w, b)
+        ctx.passthrough = bool(passthrough)
+        outs = (y,)
         if want_gap:
             ctx.mark_non_differentiable(gap)
-            return y, gap
-        return y
+            outs += (gap,)
+        if passthrough:         # a second use of x (the block's residual branch): its gradient comes back into THIS backward and is added in the
+            outs += (x.view_as(x),)                 # dgrad launch's epilogue instead of a separate map-sized add (fork)
+        return outs if len(outs) > 1 else y
 
     @staticmethod
-    def backward(ctx, dy, _dgap=None):
+    def backward(ctx, dy, *rest):
         lib = _lib()
+        dres = rest[-1] if ctx.passthrough else None
         x, w, y = ctx.saved_tensors
         B, H, W, Ci = x.shape
         Co = w.shape[0]
@@ -493,19 +498,25 @@ class _Conv3x3(torch.autograd.Function):
             # (F.conv2d's dgrad); no 9x im2col intermediate
             wp = _pack_conv(w, flip=True)                                       # w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
             dx = torch.empty_like(x)
-            L.check(lib.eg_conv3x3(_ptr(dyd), _ptr(wp), None, None, None, _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"], _stream(dev)),
-                    "eg_conv3x3 (dgrad)")
+            res = _chk(dres) if dres is not None else None                      # the other consumer's gradient: added in the epilogue
+            L.check(lib.eg_conv3x3_se(_ptr(dyd), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"],
+                                      _stream(dev)), "eg_conv3x3 (dgrad)")
+            dres = None
         elif ctx.need_dx:
             wmat_t = w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()   # [(kh,kw,ci), co] = Wmat^T
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
             dx = torch.empty_like(x)
             L.check(lib.eg_im2col3x3(_ptr(dcol), _ptr(dx), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_col2im3x3")
-        return dx, dw, db, None, None, None, None
+        if dres is not None:        # passthrough on a path without the fused epilogue (or no dx wanted): the plain add
+            dx = raw_ew(EW_ADD, dx, _chk(dres)) if dx is not None else _chk(dres)
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False):
-    """want_gap: also return the per-(clip, tile) channel sums of the output; defer_mask: the ReLU's backward is applied by the consumer."""
-    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask)
+def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False, passthrough=False):
+    """want_gap: also return the per-(clip, tile) channel sums of the output; defer_mask: the ReLU's backward is applied by the consumer;
+    passthrough: also return an alias of the input for its second consumer (the residual branch) -- the two gradients are then summed in the
+    input-gradient launch's epilogue instead of by a `fork`."""
+    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough)
 
 
 class _Subsample(torch.autograd.Function):

@@ -89,8 +89,9 @@ def se_basic_block(blk, x):
         return _se_basic_block_unfused(blk, x)
     # fused data flow: the convolutions emit pooling partials (BatchNorm means and the SE pooling without extra passes), bn1's backward
     # carries conv1's ReLU mask, and everything behind conv2 -- bn2, SE gate, scale, residual add, ReLU -- is one operator
-    xa, xb = F.fork(x)
-    r1, gap1 = F.conv3x3(xa, blk.conv1.weight, None, blk.stride, relu=True, want_gap=True, defer_mask=True)     # conv1 -> ReLU -> bn1 (:24-26)
+    # conv1 -> ReLU -> bn1 (:24-26); the block input's second consumer (the residual branch) goes through the convolution's passthrough
+    # output: the two input gradients are summed in conv1's input-gradient launch
+    r1, gap1, xb = F.conv3x3(x, blk.conv1.weight, None, blk.stride, relu=True, want_gap=True, defer_mask=True, passthrough=True)
     b1 = F.batch_norm(r1, blk.bn1, gap=gap1, relu_input=True)
     c2, gap2 = F.conv3x3(b1, blk.conv2.weight, want_gap=True)
     if blk.downsample is not None:

@@ -236,7 +236,8 @@ int eg_conv3x3(const float* x, const float* w, const float* bias, const float* s
 int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride);
 /* eg_conv3x3 with the SEBasicBlock tail of an identity block fused into the epilogue (ResNetBlocks.py:28-36):
  *   y = relu(BN(conv(x)) * gate[b, co] + residual[pixel, co]),   gate [B, Cout] from eg_se_gate_pre, residual NHWC like y.
- * gate == residual == NULL: plain eg_conv3x3. */
+ * gate == residual == NULL: plain eg_conv3x3.  gate == NULL with a residual: y = BN(conv(x)) + residual, no ReLU -- the fused fan-in add of
+ * the training path (an input gradient landing on a tensor that has a second consumer). */
 int eg_conv3x3_se(const float* x, const float* w_packed, const float* bias, const float* scale, const float* shift, const float* gate,
                   const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
                   int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
