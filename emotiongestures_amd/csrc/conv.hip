@@ -28,6 +28,7 @@ struct ConvArgs {
     // fused SE tail (SEBasicBlock.forward, ResNetBlocks.py:28-36, identity shortcut): v = relu(v * gate[b, co] + res[pixel, co])
     // applied after the BatchNorm affine; gate comes from se_gate_pre_kernel (computed BEFORE this convolution runs)
     const float* gate = nullptr; const float* res = nullptr; int relu2 = 0;
+    unsigned int* dbg = nullptr;        // diagnostic build only (EG_CONV32_STAMP=1): per-wave phase cycle sums of the persistent 32->32 kernel
 };
 
 template <int S, int TH> struct ConvGeom {
@@ -476,17 +477,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
 // 4 x 32-pixel tiles: all 9 taps' weights (36 KB of hi/lo images) are copied to LDS once, the NEXT tile's halo pixels (and this tile's
 // residual, for the fused SE tail) are in flight in registers while the 9 taps of the current tile run, and the taps need no barrier
 // (weights and tile are static): two barriers per tile instead of ten.  Same arithmetic and summation order as the tiled kernel.
-template <int TERMS>
+// STAMP: s_memtime stamps around the six phases of a tile (a separate diagnostic instantiation; the production kernel executes none)
+template <int TERMS, int TH = 4, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs a, const bf8* __restrict__ whi, const bf8* __restrict__ wlo,
                                                                      int total_tiles, int tiles_per_wg) {
-    using G = ConvGeom<1, 4>;
-    constexpr int CIN = 32, IW = G::IW, NPIX = G::NPIX, PL = G::PL, MT = 2, NT = 2;
+    using G = ConvGeom<1, TH>;
+    constexpr int CIN = 32, IW = G::IW, NPIX = G::NPIX, PL = G::PL, MT = TH / 2, NT = 2;
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr int TILE = NIMG * 4 * PL, WTAP = 4 * 32, WIMG = 9 * WTAP;
+    static_assert(PL - NPIX >= 8 || TH == 4, "the gap scratch of the 8-row variant lives in the planes' padding slots");
     extern __shared__ __attribute__((aligned(16))) bf8 lds[];      // tile | weights (hi [tap][octet][co], lo) | gap scratch
     bf8* tile = lds;
     bf8* wl = lds + TILE;
-    float* sred = reinterpret_cast<float*>(lds + TILE + NIMG * WIMG);       // [4 waves][32]
+    // gap scratch [4 waves][32 floats]: behind the weights (4-row tiles), or -- 8-row tiles: tile + weights fill exactly half a CU's LDS -- in the
+    // padding slots NPIX .. PL-1 of the first four channel-octet planes, which no staging write and no fragment read touches
+    float* sred_base = reinterpret_cast<float*>(lds + TILE + NIMG * WIMG);
+    const int sred_pitch = (TH == 4) ? 32 : PL * 4;               // floats between two waves' scratch rows
+    float* sred = (TH == 4) ? sred_base : reinterpret_cast<float*>(tile + NPIX);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
     };
     auto load_tile = [&](const Coord& c) {
         const int b = c.b;
-        const int iy0 = c.ty * 4 - 1, ix0 = c.tx * 32 - 1;
+        const int iy0 = c.ty * TH - 1, ix0 = c.tx * 32 - 1;
         const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int id = wave * MT + t;
-            const int oy = ty * 4 + (id >> 1), ox = tx * 32 + (id & 1) * 16 + li;
+            const int oy = ty * TH + (id >> 1), ox = tx * 32 + (id & 1) * 16 + li;
             const bool ok = rb && oy < a.Ho && ox < a.Wo;
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -623,12 +630,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
     load_tile(cur);
     load_res(cur);
     wait_vmcnt_imm<0>();                       // the weight copies have landed (this wave's); the barrier below publishes all of them
+    unsigned int ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tk = 0;
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (i >= 0) ph[i] += (unsigned int)(now - tk);
+            tk = now;
+        }
+    };
     for (int L = t_begin; L < t_end; L += NWG, cur = nxt) {
         const int b = cur.b, tile_id = cur.ty * a.tiles_x + cur.tx;
-        const int oy0 = cur.ty * 4, ox0 = cur.tx * 32;
+        const int oy0 = cur.ty * TH, ox0 = cur.tx * 32;
         advance(nxt);
+        stamp(-1);
         store_tile();
+        stamp(0);
         __syncthreads();                        // tile (and, first time, weights) visible
+        stamp(1);
         // halo AND residual of the NEXT tile: in flight during this tile's 9 taps and epilogue
         int pixo[MT];
         f4 rs[MT][NT];
@@ -643,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
         const bool has_res = a.res != nullptr;
         if (L + NWG < t_end) load_res(nxt);
         if (L + NWG < t_end) load_tile(nxt);
+        stamp(2);
 
         f4 acc[MT][NT];
 #pragma unroll
@@ -667,6 +687,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
                 }
         }
 
+        if constexpr (STAMP) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[t][n]));        // the stamp must not move above the last MFMA's result
+        }
+        stamp(3);
         float* __restrict__ yb = a.y + (size_t)b * hw * 32;
         f4 gsum[NT];
 #pragma unroll
@@ -702,16 +729,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
                     float sm = gsum[n][r];
                     sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
                     sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
-                    if (li == 0) sred[wave * 32 + n * 16 + kq * 4 + r] = sm;
+                    if (li == 0) sred[wave * sred_pitch + n * 16 + kq * 4 + r] = sm;
                 }
         }
+        stamp(4);
         __syncthreads();                        // every wave is done with the tile image (and the gap scratch is complete)
+        stamp(5);
         if (a.gap && tid < 32) {
             float sm = 0.f;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) sm += sred[m * 32 + tid];
+            for (int m = 0; m < 4; ++m) sm += sred[m * sred_pitch + tid];
             a.gap[((size_t)b * a.tiles + tile_id) * 32 + tid] = sm;
         }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && a.dbg)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
     }
 }
 
@@ -961,12 +995,12 @@ bool conv32_persistent_enabled() {
     return on;
 }
 
-template <int TERMS>
+template <int TERMS, int TH>
 int launch_conv32_persistent_t(const ConvArgs& a, int batch, const bf8* whi, const bf8* wlo, hipStream_t st) {
-    using G = ConvGeom<1, 4>;
+    using G = ConvGeom<1, TH>;
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + NIMG * 9 * 128) + 4 * 32 * sizeof(float);
-    auto kern = conv3x3_c32_persistent_kernel<TERMS>;
+    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + NIMG * 9 * 128) + (TH == 4 ? 4 * 32 * sizeof(float) : 0);
+    auto kern = conv3x3_c32_persistent_kernel<TERMS, TH>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (32 -> 32, persistent)")) return rc;
     const int total = a.tiles * batch;
     int grid = total < 512 ? total : 512;                        // 2 workgroups per CU
@@ -976,17 +1010,56 @@ int launch_conv32_persistent_t(const ConvArgs& a, int batch, const bf8* whi, con
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, a, whi, wlo, total, tpw);
     return eg_check_launch("conv3x3 (32 -> 32, persistent)");
 }
-int launch_conv32_persistent(const ConvArgs& a, int batch, int precision, hipStream_t st) {
+int launch_conv32_persistent(const ConvArgs& a, int batch, int precision, int th, hipStream_t st) {
     const size_t f32_floats = (size_t)9 * 32 * 32;
     const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
     const bf8* wlo = whi + (size_t)9 * 4 * 32;
-    if (precision == EG_PREC_BF16X3) return launch_conv32_persistent_t<3>(a, batch, whi, wlo, st);
-    return launch_conv32_persistent_t<1>(a, batch, whi, wlo, st);
+    static const bool stamp = [] { const char* e = getenv("EG_CONV32_STAMP"); return e && e[0] == '1'; }();
+    if (stamp && precision == EG_PREC_BF16X3 && th == 4) {
+        // diagnostic: per-phase cycle sums of every wave, averaged and printed after the launch (synchronises: never use while timing)
+        static unsigned int* dbg = nullptr;
+        const int nwords = 512 * 4 * 8;
+        if (!dbg && hipMalloc(&dbg, nwords * sizeof(unsigned int)) != hipSuccess) return EG_ERR_HIP;
+        (void)hipMemsetAsync(dbg, 0, nwords * sizeof(unsigned int), st);
+        ConvArgs b = a;
+        b.dbg = dbg;
+        constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(2 * 4 * ConvGeom<1, 4>::PL + 2 * 9 * 128) + 4 * 32 * sizeof(float);
+        auto kern = conv3x3_c32_persistent_kernel<3, 4, true>;
+        if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (stamps)")) return rc;
+        const int total = a.tiles * batch;
+        int grid = total < 512 ? total : 512;
+        grid = eg_cdiv(total, eg_cdiv(total, grid));
+        if (grid >= 8) grid = (int)eg_round_up(grid, 8);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, b, whi, wlo, total, 0);
+        static unsigned int host[512 * 4 * 8];
+        if (hipMemcpyAsync(host, dbg, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return EG_ERR_HIP;
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        int nw = 0;
+        for (int w = 0; w < grid * 4; ++w) {
+            if (host[w * 8 + 3] == 0) continue;
+            ++nw;
+            for (int i = 0; i < 6; ++i) sum[i] += host[w * 8 + i];
+        }
+        const double tiles_per_wave = (double)total / grid;
+        fprintf(stderr, "conv32 stamps (cycles per tile and wave, %d waves, %s residual): store_tile %.0f  barrier1 %.0f  issue_loads %.0f  taps %.0f  epilogue %.0f  barrier2 %.0f\n",
+                nw, a.res ? "with" : "no", sum[0] / nw / tiles_per_wave, sum[1] / nw / tiles_per_wave, sum[2] / nw / tiles_per_wave, sum[3] / nw / tiles_per_wave,
+                sum[4] / nw / tiles_per_wave, sum[5] / nw / tiles_per_wave);
+        return eg_check_launch("conv3x3 (32 -> 32, stamps)");
+    }
+    if (th == 8) {
+        if (precision == EG_PREC_BF16X3) return launch_conv32_persistent_t<3, 8>(a, batch, whi, wlo, st);
+        return launch_conv32_persistent_t<1, 8>(a, batch, whi, wlo, st);
+    }
+    if (precision == EG_PREC_BF16X3) return launch_conv32_persistent_t<3, 4>(a, batch, whi, wlo, st);
+    return launch_conv32_persistent_t<1, 4>(a, batch, whi, wlo, st);
 }
 
 int conv_tile_rows(int cin, int cout, int stride) {
     if (stride == 2 || cout >= 256) return 2;
-    if (cin == 32 && cout == 32) return 4;       // 4-row tiles: smaller LDS footprint, more workgroups in flight (HBM-bound layer)
+    if (cin == 32 && cout == 32) {               // 4-row tiles: smaller LDS footprint, more workgroups in flight (HBM-bound layer)
+        static const int th = [] { const char* e = getenv("EG_CONV32_TH"); return (e && atoi(e) == 8) ? 8 : 4; }();      // experiment hook
+        return th;
+    }
     return (cout >= 128 || cin >= 128) ? 4 : 8;
 }
 
@@ -1034,8 +1107,8 @@ extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, 
     const int coutp = (int)eg_round_up(cout, 16);
     EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + stride * 100 + 1,
                      2.0 * 9 * cin * cout * (double)a.Ho * a.Wo * batch, st);
-    if (cin == 32 && coutp == 32 && cout == 32 && stride == 1 && th == 4 && precision != EG_PREC_F32 && !nchw_out && conv32_persistent_enabled())
-        return launch_conv32_persistent(a, batch, precision, st);
+    if (cin == 32 && coutp == 32 && cout == 32 && stride == 1 && precision != EG_PREC_F32 && !nchw_out && conv32_persistent_enabled())
+        return launch_conv32_persistent(a, batch, precision, th, st);
     if (cin == 32 && coutp == 32 && stride == 1 && th == 4) return launch_conv<32, 2, 1, 4, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2, 2, 2>(a, batch, precision, st);
