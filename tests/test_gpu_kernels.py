@@ -328,8 +328,11 @@ def test_planar_c32_stage_matches_the_nhwc_kernels(B, H, W, prec):
     L.check(lib.eg_conv3x3_c32_planar(_ptr(xp), _ptr(wp1), None, _ptr(s1), _ptr(t1), None, None, _ptr(y1p), None, _ptr(gap_p), B, H, W, 1, pc, st),
             "eg_conv3x3_c32_planar")
     y1 = _from_planes(y1p, B, H, W)
-    assert rel_l2(y1.cpu().numpy(), y1_ref.cpu().numpy()) < 1e-5
-    assert rel_l2(gap_p.sum(1).cpu().numpy(), gap_ref.sum(1).cpu().numpy()) < 1e-5
+    # bf16x3: both sides multiply the same (hi, lo) pairs.  bf16 (one term): the fp32 kernel rounds hi + lo to bf16 again while the planes
+    # hand over hi itself, which differs on near-ties -- a 2^-9 step on a few operands, far below the mode's own error vs fp32 (~2e-3)
+    tol = 1e-5 if prec == "bf16x3" else 5e-4
+    assert rel_l2(y1.cpu().numpy(), y1_ref.cpu().numpy()) < tol
+    assert rel_l2(gap_p.sum(1).cpu().numpy(), gap_ref.sum(1).cpu().numpy()) < tol
     # gate from conv1's moments: planes vs fp32 (fed the planes' values, so only the summation structure differs)
     f = lambda k, n, lo, hi: T(k, (n,), lo, hi).to(d)
     fw1, fb1, fw2, fb2 = T("se.w1", (4, 32), -0.3, 0.3).to(d), f("se.b1", 4, -0.1, 0.1), T("se.w2", (32, 4), -0.3, 0.3).to(d), f("se.b2", 32, -0.1, 0.1)
@@ -351,8 +354,8 @@ def test_planar_c32_stage_matches_the_nhwc_kernels(B, H, W, prec):
             "eg_conv3x3_c32_planar (tail, planes)")
     L.check(lib.eg_conv3x3_c32_planar(_ptr(y1p), _ptr(wp2), None, _ptr(s2), _ptr(t2), _ptr(gate_p), _ptr(xp), None, _ptr(outf), None, B, H, W, 0, pc, st),
             "eg_conv3x3_c32_planar (tail, fp32)")
-    assert rel_l2(outf.cpu().numpy(), out_ref.cpu().numpy()) < 2e-6           # same inputs, same arithmetic: fp32 output
-    assert rel_l2(_from_planes(outp, B, H, W).cpu().numpy(), out_ref.cpu().numpy()) < 1e-5
+    assert rel_l2(outf.cpu().numpy(), out_ref.cpu().numpy()) < (2e-6 if prec == "bf16x3" else tol)   # same inputs, same arithmetic: fp32 output
+    assert rel_l2(_from_planes(outp, B, H, W).cpu().numpy(), out_ref.cpu().numpy()) < tol
     # determinism: a second launch is bitwise identical
     outf2 = torch.empty_like(outf)
     L.check(lib.eg_conv3x3_c32_planar(_ptr(y1p), _ptr(wp2), None, _ptr(s2), _ptr(t2), _ptr(gate_p), _ptr(xp), None, _ptr(outf2), None, B, H, W, 0, pc, st),
