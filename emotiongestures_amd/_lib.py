@@ -117,6 +117,11 @@ SIGNATURES = {
     "eg_im2col3x3": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_subsample": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_im2col1d": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_conv1d_cl_forward": (C.c_int, [_P, _P, _P, _P] + [_I] * 9 + [_P]),
+    "eg_conv1d_cl_backward_input": (C.c_int, [_P, _P, _P, _P] + [_I] * 9 + [_P]),
+    "eg_conv1d_cl_backward_weight_workspace_floats": (_L, [_I] * 7),
+    "eg_conv1d_cl_backward_weight": (C.c_int, [_P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P]),
+    "eg_pad_cols": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "eg_colreduce_workspace_floats": (_L, [_I]),
     "eg_bn_train_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
     "eg_bn_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),

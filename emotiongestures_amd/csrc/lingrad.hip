@@ -186,13 +186,19 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_bf16_kernel(LinGradArgs a
 // dw[n][k] = sum_s part[s][n][k] (partials at row pitch ldp, output at lddw); db[n] = sum_s dbpart[s][n]; fixed order
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
                                                                   float* __restrict__ db, int N, int K, int ldp, int lddw, int S) {
-    const size_t total = (size_t)N * K, slice = (size_t)N * ldp;
+    // one thread per 4 consecutive k of a row (the partials' pitch ldp is a multiple of 4: 16-byte reads); 16-byte stores when dw allows them
+    const int q4 = ldp >> 2;
+    const size_t total = (size_t)N * q4, slice = (size_t)N * ldp;
+    const bool wide = (lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
+        const int n = (int)(i / q4), k = (int)(i - (size_t)n * q4) * 4;
         const float* p = part + (size_t)n * ldp + k;
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += p[(size_t)z * slice];
-        dw[(size_t)n * lddw + k] = s;
+        f4 s = *reinterpret_cast<const f4*>(p);
+        for (int z = 1; z < S; ++z) s += *reinterpret_cast<const f4*>(p + (size_t)z * slice);
+        float* o = dw + (size_t)n * lddw + k;
+        if (wide && k + 4 <= K) *reinterpret_cast<f4*>(o) = s;
+        else
+            for (int j = 0; j < 4 && k + j < K; ++j) o[j] = s[j];
     }
     if (db && blockIdx.x == 0)
         for (int n = threadIdx.x; n < N; n += 256) {
@@ -247,7 +253,7 @@ extern "C" int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x
     hipLaunchKernelGGL(linear_wgrad_bf16_kernel, dim3(eg_cdiv(k, 64), eg_cdiv(n, 64), p.S), dim3(256), LDS_BYTES, st, a);
     if (int rc = eg_check_launch("linear_wgrad_mfma")) return rc;
     if (p.S == 1) return EG_OK;
-    const size_t total = (size_t)n * k;
+    const size_t total = (size_t)n * (a.lddw >> 2);
     const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, a.part, a.dbpart, dw, db, n, k, a.lddw, lddw, p.S);
     return eg_check_launch("linear_wgrad_reduce");

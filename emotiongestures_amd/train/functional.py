@@ -81,13 +81,16 @@ def _scratch(dev, floats: int, tag="ws") -> torch.Tensor:
 
 
 def _pad_cols(t: torch.Tensor, mult=4) -> torch.Tensor:
-    """[R, K] -> [R, Kp] zero padded to a multiple of `mult` (pure data movement)."""
+    """[R, K] -> [R, Kp] zero padded to a multiple of `mult` (pure data movement, one launch)."""
     k = t.shape[1]
     kp = (k + mult - 1) // mult * mult
     if kp == k:
         return t
-    out = torch.zeros(t.shape[0], kp, dtype=torch.float32, device=t.device)
-    out[:, :k].copy_(t)
+    if not t.is_cuda:
+        raise L.EgError("_pad_cols: the HIP path needs a GPU tensor")
+    t = t.contiguous()
+    out = torch.empty(t.shape[0], kp, dtype=torch.float32, device=t.device)
+    L.check(_lib().eg_pad_cols(_ptr(t), _ptr(out), t.shape[0], k, kp, _stream(t.device)), "eg_pad_cols")
     return out
 
 
@@ -249,6 +252,8 @@ class _Linear(torch.autograd.Function):
         xs = x.shape
         x2 = _chk(x, "x").reshape(-1, xs[-1])
         wd = _chk(w, "weight")
+        if wd.dim() == 4:           # a 1x1 convolution's [Cout, Cin, 1, 1] (conv1x1): the same memory as the [Cout, Cin] matrix
+            wd = wd.view(wd.shape[0], wd.shape[1])
         y = raw_linear(x2, wd, _chk(b) if b is not None else None, relu)
         ctx.save_for_backward(x2, wd, y if relu else None)
         ctx.has_b, ctx.xs, ctx.need_dx = b is not None, xs, x.requires_grad
@@ -273,6 +278,7 @@ def linear(x, w, b=None, relu=False):
 class _Fork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)            # an unused branch hands None back, not a zero-filled map
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
@@ -409,6 +415,7 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False, passthrough=False):
         lib = _lib()
+        ctx.set_materialize_grads(False)            # no zero-filled "gradients" for the non-differentiable pooling partials / an unused alias
         xd, wd = _chk(x, "x"), _chk(w, "weight")
         gap = None
         B, H, W, Ci = xd.shape
@@ -466,6 +473,8 @@ class _Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         B, H, W, Ci = x.shape
         Co = w.shape[0]
+        if dy is None:              # only the alias was used downstream
+            return (_chk(dres) if dres is not None else None), None, None, None, None, None, None, None
         dyd = _chk(dy)
         if y is not None:
             dyd = raw_ew(EW_RELU_BWD, dyd, y)
@@ -544,7 +553,7 @@ class _Subsample(torch.autograd.Function):
 def conv1x1(x_nhwc, w_oi11, stride=1):
     """nn.Conv2d(k=1, stride s, bias=False): the downsample shortcut (ResNetSE34V2.py:43-47)."""
     xs = _Subsample.apply(x_nhwc, stride) if stride != 1 else x_nhwc
-    return linear(xs, w_oi11.view(w_oi11.shape[0], -1))
+    return linear(xs, w_oi11)           # the parameter itself: its gradient lands in its flat slice, its weight image is the resident one
 
 
 def _running_stats_written(bn):
@@ -795,7 +804,8 @@ def attention(q, k, v, heads, dropout_p: float = 0.0):
 
 
 class _Conv1dCL(torch.autograd.Function):
-    """nn.Conv1d on channels-last activations x [B, L, Cin] with the reference's weight [Cout, Cin, k]."""
+    """nn.Conv1d on channels-last activations x [B, L, Cin] with the reference's weight [Cout, Cin, k]: one launch forward, two backward
+    (csrc/conv1d_train.hip), gradients written straight into the parameters' flat slices."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, dilation):
@@ -805,29 +815,36 @@ class _Conv1dCL(torch.autograd.Function):
         Co, _, k = wd.shape
         Lout = (Ln + 2 * pad - dilation * (k - 1) - 1) // stride + 1
         dev = xd.device
-        col = torch.empty(B * Lout, k * Ci, device=dev)
-        L.check(lib.eg_im2col1d(_ptr(xd), _ptr(col), B, Ln, Ci, k, stride, pad, dilation, Lout, 0, _stream(dev)), "eg_im2col1d")
-        wm = wd.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()            # [co][(j, ci)]
-        y = raw_linear(col, wm, _chk(b) if b is not None else None)
-        ctx.save_for_backward(xd, wd, col, wm)
-        ctx.cfg = (stride, pad, dilation, Lout, b is not None, x.requires_grad)
-        return y.view(B, Lout, Co)
+        y = torch.empty(B, Lout, Co, device=dev)
+        L.check(lib.eg_conv1d_cl_forward(_ptr(xd), _ptr(wd), _ptr(_chk(b)) if b is not None else None, _ptr(y), B, Ln, Ci, Lout, Co, k, stride, pad, dilation,
+                                         _stream(dev)), "eg_conv1d_cl_forward")
+        ctx.save_for_backward(xd, wd)
+        ctx.cfg = (stride, pad, dilation, Lout, x.requires_grad)
+        ctx.params = (w, b)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib()
-        x, w, col, wm = ctx.saved_tensors
-        stride, pad, dilation, Lout, has_b, need_dx = ctx.cfg
+        x, w = ctx.saved_tensors
+        stride, pad, dilation, Lout, need_dx = ctx.cfg
         B, Ln, Ci = x.shape
         Co, _, k = w.shape
-        dy2 = _chk(dy).reshape(B * Lout, Co)
-        dcol, dwm, db = raw_linear_backward(col, wm, dy2, need_dx)
-        dw = dwm.view(Co, k, Ci).permute(0, 2, 1).contiguous()
+        dyd = _chk(dy)
+        st = _stream(x.device)
+        wp, bp = ctx.params
+        dw = grad_out(wp)
+        db = grad_out(bp) if bp is not None else None
+        need = int(lib.eg_conv1d_cl_backward_weight_workspace_floats(B, Ci, Lout, Co, k, stride, dilation))
+        ws = _scratch(x.device, need, "c1w") if need else None
+        L.check(lib.eg_conv1d_cl_backward_weight(_ptr(x), _ptr(dyd), _ptr(dw), _ptr(db), None, B, Ln, Ci, Lout, Co, k, stride, pad, dilation, _ptr(ws),
+                                                 ws.numel() if ws is not None else 0, st), "eg_conv1d_cl_backward_weight")
         dx = None
         if need_dx:
             dx = torch.empty_like(x)
-            L.check(lib.eg_im2col1d(_ptr(dcol), _ptr(dx), B, Ln, Ci, k, stride, pad, dilation, Lout, 1, _stream(x.device)), "eg_col2im1d")
-        return dx, dw, (db if has_b else None), None, None, None
+            L.check(lib.eg_conv1d_cl_backward_input(_ptr(dyd), _ptr(w), None, _ptr(dx), B, Ln, Ci, Lout, Co, k, stride, pad, dilation, st),
+                    "eg_conv1d_cl_backward_input")
+        return dx, dw, db, None, None, None
 
 
 def conv1d_cl(x_blc, w, b=None, stride=1, pad=0, dilation=1):
@@ -835,8 +852,9 @@ def conv1d_cl(x_blc, w, b=None, stride=1, pad=0, dilation=1):
 
 
 class _ConvT1dCL(torch.autograd.Function):
-    """nn.ConvTranspose1d(k, stride, padding, output_padding) on channels-last x [B, L, Cin]; weight [Cin, Cout, k] as in the
-    reference's state_dict.  Forward = GEMM then col2im (the transpose of a strided conv), backward = im2col then the Linear rules."""
+    """nn.ConvTranspose1d(k, stride, padding, output_padding) on channels-last x [B, L, Cin]; weight [Cin, Cout, k] as in the reference's
+    state_dict.  The adjoint of a strided conv: forward = that conv's input-gradient kernel (+ bias), input gradient = its forward kernel,
+    weight gradient = its weight-gradient kernel with x and dy exchanged."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, out_pad):
@@ -846,36 +864,38 @@ class _ConvT1dCL(torch.autograd.Function):
         _, Co, k = wd.shape
         Lout = (Ln - 1) * stride - 2 * pad + k + out_pad
         dev = xd.device
-        wm = wd.permute(2, 1, 0).reshape(k * Co, Ci).contiguous()            # [(j, co)][ci]
-        x2 = xd.reshape(B * Ln, Ci)
-        col = raw_linear(x2, wm)                                              # [B*L, k*Co]
         y = torch.empty(B, Lout, Co, device=dev)
-        L.check(lib.eg_im2col1d(_ptr(col), _ptr(y), B, Lout, Co, k, stride, pad, 1, Ln, 1, _stream(dev)), "eg_col2im1d")
-        if b is not None:
-            y = raw_linear_bias_add(y.view(B * Lout, Co), _chk(b)).view(B, Lout, Co)
-        ctx.save_for_backward(x2, wd, wm)
-        ctx.cfg = (B, Ln, Ci, Co, k, stride, pad, Lout, b is not None, x.requires_grad)
+        L.check(lib.eg_conv1d_cl_backward_input(_ptr(xd), _ptr(wd), _ptr(_chk(b)) if b is not None else None, _ptr(y), B, Lout, Co, Ln, Ci, k, stride, pad, 1,
+                                                _stream(dev)), "eg_conv1d_cl_backward_input (ConvTranspose1d forward)")
+        ctx.save_for_backward(xd, wd)
+        ctx.cfg = (stride, pad, Lout, x.requires_grad)
+        ctx.params = (w, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib()
-        x2, w, wm = ctx.saved_tensors
-        B, Ln, Ci, Co, k, stride, pad, Lout, has_b, need_dx = ctx.cfg
+        x, w = ctx.saved_tensors
+        stride, pad, Lout, need_dx = ctx.cfg
+        B, Ln, Ci = x.shape
+        _, Co, k = w.shape
         dyd = _chk(dy)
-        dev = dyd.device
-        dcol = torch.empty(B * Ln, k * Co, device=dev)
-        L.check(lib.eg_im2col1d(_ptr(dyd), _ptr(dcol), B, Lout, Co, k, stride, pad, 1, Ln, 0, _stream(dev)), "eg_im2col1d")
-        dx, dwm, _ = raw_linear_backward(x2, wm, dcol, need_dx)
-        dw = dwm.view(k, Co, Ci).permute(2, 1, 0).contiguous()
-        db = raw_colsum(dyd.view(B * Lout, Co))[0] if has_b else None
-        return (dx.view(B, Ln, Ci) if dx is not None else None), dw, db, None, None, None
-
-
-def raw_linear_bias_add(y2, bias):
-    """y[r, :] + bias (row broadcast) on the row-periodic add kernel."""
-    from .. import ops
-    return ops.add_rows(y2.contiguous(), bias.view(1, -1).contiguous(), period=1)
+        st = _stream(x.device)
+        wp, bp = ctx.params
+        dw = grad_out(wp)
+        db = grad_out(bp) if bp is not None else None
+        need = int(lib.eg_conv1d_cl_backward_weight_workspace_floats(B, Co, Ln, Ci, k, stride, 1))
+        ws = _scratch(x.device, need, "c1w") if need else None
+        if need and db is not None:     # the tiled kernel sums dy-side biases only: the layer's bias gradient (a sum over the x side here) on its own
+            raw_colsum(dyd.view(B * Lout, Co), out0=db)
+        L.check(lib.eg_conv1d_cl_backward_weight(_ptr(dyd), _ptr(x), _ptr(dw), None, None if need else _ptr(db), B, Lout, Co, Ln, Ci, k, stride, pad, 1,
+                                                 _ptr(ws), ws.numel() if ws is not None else 0, st), "eg_conv1d_cl_backward_weight (ConvTranspose1d)")
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(x)
+            L.check(lib.eg_conv1d_cl_forward(_ptr(dyd), _ptr(w), None, _ptr(dx), B, Lout, Co, Ln, Ci, k, stride, pad, 1, st),
+                    "eg_conv1d_cl_forward (ConvTranspose1d input gradient)")
+        return dx, dw, db, None, None, None
 
 
 def conv_transpose1d_cl(x_blc, w, b=None, stride=2, pad=1, out_pad=1):

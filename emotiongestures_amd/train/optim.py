@@ -123,8 +123,8 @@ class WeightImages:
         first = 0
         for p in fp.params:
             kinds = []
-            if p.dim() == 2:
-                n, k = p.shape
+            if p.dim() == 2 or (p.dim() == 4 and tuple(p.shape[2:]) == (1, 1)):        # nn.Linear, or a 1x1 convolution used as one
+                n, k = p.shape[:2]
                 kinds = [(0, n, k, k, 0, int(lib.eg_linear_packed_floats(n, k))), (0, k, n, k, 1, int(lib.eg_linear_packed_floats(k, n)))]
             elif p.dim() == 4 and tuple(p.shape[2:]) == (3, 3):
                 co, ci = p.shape[:2]
@@ -163,7 +163,8 @@ class WeightImages:
         if hit is None:
             return None
         img, p = hit
-        if tuple(w.shape) != tuple(p.shape) or self.versions.get(id(p)) != w._version:
+        same = tuple(w.shape) == tuple(p.shape) or (p.dim() == 4 and tuple(p.shape[2:]) == (1, 1) and tuple(w.shape) == tuple(p.shape[:2]))
+        if not same or self.versions.get(id(p)) != w._version:
             return None                 # a different view of that storage, or the parameter changed since the last refresh
         return img
 

@@ -399,6 +399,27 @@ int eg_subsample(const float* x, float* y, int32_t batch, int32_t h, int32_t w, 
 /* 1-D channels-last im2col: x [B,L,C] -> col [B*Lout, k*C] at l*stride + j*dilation - pad_left; backward = transpose */
 int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t len, int32_t c, int32_t k, int32_t stride, int32_t pad_left,
                 int32_t dilation, int32_t lout, int32_t backward, void* stream);
+/* The small 1-D convolutions of the training step (emotion CVAE Conv1d / ConvTranspose1d stacks, CAVE/BEAT_CVAE.py:318-332,355-369; the prior
+ * encoder's pred_conv, Full_model/Models_spatial_memory.py:224-231) on channels-last activations, one fp32 launch per product, fixed-order sums:
+ *   forward          y[b, lo, co]  = bias[co] + sum_{ci, j} x[b, lo*stride - pad + j*dilation, ci] * w[co][ci][j]     (w: nn.Conv1d's [cout][cin][k])
+ *   backward_input   dx[b, li, ci] = bias[ci] + sum_{co, j : li + pad - j*dilation = lo*stride} dy[b, lo, co] * w[co][ci][j]
+ *   backward_weight  dw[co][ci][j] = sum_{b, lo} dy[b, lo, co] * x[b, lo*stride - pad + j*dilation, ci];  db_dy[co] = sum dy;  db_x[ci] = sum x
+ * x / dx: [batch, len, cin], y / dy: [batch, len_out, cout]; bias, db_dy, db_x may be NULL; 1 <= k <= 8.  nn.ConvTranspose1d (weight
+ * [cin][cout][k]) is the adjoint: forward = backward_input with the layer's bias, input gradient = forward, weight gradient = backward_weight
+ * with x and dy exchanged (db_x = the layer's bias gradient). */
+int eg_conv1d_cl_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t len, int32_t cin, int32_t len_out,
+                         int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t dilation, void* stream);
+int eg_conv1d_cl_backward_input(const float* dy, const float* w, const float* bias, float* dx, int32_t batch, int32_t len, int32_t cin,
+                                int32_t len_out, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t dilation, void* stream);
+/* workspace: eg_conv1d_cl_backward_weight_workspace_floats(...) floats (0 for small shapes: one launch); per-workgroup partials, folded in a fixed
+ * order by a second launch.  db_x != NULL always takes the one-launch kernel. */
+int64_t eg_conv1d_cl_backward_weight_workspace_floats(int32_t batch, int32_t cin, int32_t len_out, int32_t cout, int32_t k, int32_t stride,
+                                                      int32_t dilation);
+int eg_conv1d_cl_backward_weight(const float* x, const float* dy, float* dw, float* db_dy, float* db_x, int32_t batch, int32_t len, int32_t cin,
+                                 int32_t len_out, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t dilation, float* workspace,
+                                 int64_t workspace_floats, void* stream);
+/* [rows, k] -> [rows, k_padded] zero padded (rows of the GEMM operands are read in 16-byte pieces) */
+int eg_pad_cols(const float* x, float* y, int64_t rows, int32_t k, int32_t k_padded, void* stream);
 /* nn.BatchNorm{1,2}d in train() mode over channels-last rows [rows, C]: batch statistics (biased variance for the
  * normalisation, unbiased for running_var, momentum as torch), saved mean / rstd for the backward. */
 int64_t eg_colreduce_workspace_floats(int32_t c);

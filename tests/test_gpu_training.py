@@ -69,10 +69,15 @@ def test_conv1x1_stride2_and_conv1d():
     from emotiongestures_amd.train import functional as F
     x, w = T("x", (2, 9, 12, 32)), T("w", (64, 32, 1, 1), -0.2, 0.2)
     _grad_check(lambda x, w: F.conv1x1(x, w, 2), lambda x, w: TF.conv2d(x.permute(0, 3, 1, 2), w, None, stride=2).permute(0, 2, 3, 1), [x, w])
-    for (Ci, Co, k, st, pad, L) in [(4, 30, 3, 1, 1, 126), (30, 30, 3, 1, 1, 126), (16, 8, 5, 2, 2, 64)]:
-        x, w, b = T("x", (3, L, Ci)), T("w", (Co, Ci, k), -0.3, 0.3), T("b", (Co,))
-        _grad_check(lambda x, w, b: F.conv1d_cl(x, w, b, st, pad, 1),
-                    lambda x, w, b: TF.conv1d(x.transpose(1, 2), w, b, stride=st, padding=pad).transpose(1, 2), [x, w, b])
+    # (.., B): B * Lout >= 512 takes the LDS-tiled weight gradient (partials + fold), below that the one-launch kernel; 70 channels: the untiled forms
+    for (Ci, Co, k, st, pad, L, dil, B) in [(4, 30, 3, 1, 1, 126, 1, 3), (30, 30, 3, 1, 1, 126, 1, 5), (16, 8, 5, 2, 2, 64, 1, 3), (34, 32, 3, 1, 1, 34, 1, 16),
+                                            (8, 4, 5, 1, 4, 40, 2, 3), (5, 7, 3, 3, 0, 31, 2, 3), (3, 2, 8, 1, 3, 9, 1, 2), (34, 32, 3, 1, 1, 512, 1, 2),
+                                            (32, 16, 3, 2, 1, 512, 1, 3), (16, 8, 5, 2, 2, 300, 1, 4), (6, 5, 4, 3, 2, 700, 2, 2), (70, 66, 3, 1, 1, 200, 1, 3)]:
+        x, w, b = T("x", (B, L, Ci)), T("w", (Co, Ci, k), -0.3, 0.3), T("b", (Co,))
+        _grad_check(lambda x, w, b: F.conv1d_cl(x, w, b, st, pad, dil),
+                    lambda x, w, b: TF.conv1d(x.transpose(1, 2), w, b, stride=st, padding=pad, dilation=dil).transpose(1, 2), [x, w, b])
+    x, w = T("x", (2, 20, 6)), T("w", (5, 6, 3), -0.3, 0.3)                                                     # no bias
+    _grad_check(lambda x, w: F.conv1d_cl(x, w, None, 1, 1, 1), lambda x, w: TF.conv1d(x.transpose(1, 2), w, None, padding=1).transpose(1, 2), [x, w])
 
 
 def test_batchnorm_layernorm_se_attention():
@@ -441,10 +446,11 @@ def test_emotion_net_train_step_and_adam():
 
 def test_conv_transpose1d_reparam_kld_ops():
     from emotiongestures_amd.train import functional as F
-    for (Ci, Co, L) in [(4, 8, 128), (8, 16, 256)]:
-        x, w, b = T("x", (3, L, Ci)), T("w", (Ci, Co, 3), -0.4, 0.4), T("b", (Co,))
-        _grad_check(lambda x, w, b: F.conv_transpose1d_cl(x, w, b, 2, 1, 1),
-                    lambda x, w, b: TF.conv_transpose1d(x.transpose(1, 2), w, b, stride=2, padding=1, output_padding=1).transpose(1, 2), [x, w, b])
+    for (Ci, Co, L, k, st, pad, op, B) in [(4, 8, 128, 3, 2, 1, 1, 3), (8, 16, 256, 3, 2, 1, 1, 3), (5, 3, 17, 3, 1, 1, 0, 3), (6, 4, 9, 4, 3, 0, 2, 3),
+                                           (2, 7, 5, 5, 2, 2, 0, 3), (4, 8, 128, 3, 2, 1, 1, 6), (8, 16, 256, 3, 2, 1, 1, 2)]:
+        x, w, b = T("x", (B, L, Ci)), T("w", (Ci, Co, k), -0.4, 0.4), T("b", (Co,))
+        _grad_check(lambda x, w, b: F.conv_transpose1d_cl(x, w, b, st, pad, op),
+                    lambda x, w, b: TF.conv_transpose1d(x.transpose(1, 2), w, b, stride=st, padding=pad, output_padding=op).transpose(1, 2), [x, w, b])
     mu, lv, eps = T("mu", (5, 32)), T("lv", (5, 32), -2, 1), T("eps", (5, 32), -2, 2)
     _grad_check(lambda mu, lv: F.reparameterize(mu, lv, eps.to(DEV)), lambda mu, lv: eps * torch.exp(0.5 * lv) + mu, [mu, lv])
     _grad_check(lambda mu, lv: F.kld_loss(mu, lv, 2.0),

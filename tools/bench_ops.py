@@ -31,7 +31,8 @@ def timeit(fn, iters=30, warm=5):
 def gemm(prec):
     pc = L.precision_code(prec)
     shapes = [(2048, 512, 512), (2048, 512, 2048), (2048, 2048, 512), (2048, 1536, 512), (2176, 512, 512), (2176, 1536, 512), (2176, 2048, 512), (2176, 512, 2048), (2176, 512, 992), (3840, 300, 300),
-              (8704, 512, 512), (2176, 128, 512), (69632, 512, 512), (69632, 2048, 512), (69632, 512, 2048)]
+              (8704, 512, 512), (2176, 128, 512), (69632, 512, 512), (69632, 2048, 512), (69632, 512, 2048),
+              (544, 512, 512), (544, 2048, 512), (544, 512, 2048), (4352, 512, 512), (4352, 1536, 512), (4352, 2048, 512), (4352, 512, 2048)]   # training rows: 16 / 128 clips x 34 frames
     pad = int(os.environ.get("LDA_PAD", "0"))
     for (M, N, K) in shapes:
         x = torch.randn(M, K + pad, device=dev)
