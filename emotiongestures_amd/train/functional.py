@@ -155,8 +155,16 @@ def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False):
         N = w.shape[1] if w_transposed else w.shape[0]
         wimg, ldw = _pack_linear(w, w_transposed)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        splits = 0
         if res is None and M <= 128 and K >= 4096:
             splits = min(64, K // 1024)
+        elif res is None and K >= 1024:
+            # few output tiles and a deep K (the FFN's second product and the first one's input gradient at 16 clips: 544 x 512 x 2048 = 72 tiles
+            # on 256 CUs, 64 serial K-steps, 29.7 us): split K until ~256 workgroups exist, fold with the bias / ReLU pass
+            tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            if tiles <= 96:
+                splits = min(K // 512, max(2, 256 // tiles))
+        if splits >= 2:
             part = _scratch(x.device, splits * M * N, "splitk")
             L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part), _PREC["gemm"],
                                          _stream(x.device)), "eg_linear_splitk")
