@@ -130,7 +130,8 @@ def _se_basic_block_unfused(blk, x):
 def resnetse_forward(enc, spec):
     """spec [B,H,W] -> NHWC feature map."""
     x = spec.unsqueeze(-1).contiguous()
-    x = F.batch_norm(F.conv3x3(x, enc.conv1.weight, enc.conv1.bias, 1, relu=True), enc.bn1)
+    # conv -> ReLU -> BatchNorm (ResNetSE34V2.py:64-66): the ReLU's backward mask rides on bn1's backward reduction / apply, as in the blocks
+    x = F.batch_norm(F.conv3x3(x, enc.conv1.weight, enc.conv1.bias, 1, relu=True, defer_mask=True), enc.bn1, relu_input=True)
     for layer in (enc.layer1, enc.layer2, enc.layer3, getattr(enc, "layer4", ())):
         for blk in layer:
             x = se_basic_block(blk, x)
