@@ -457,6 +457,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// float4 forms of the two passes above (C % 4 == 0, 16-byte aligned maps and vectors): same per-element operation order, a quarter of the
+// load / store instructions and of the channel-index arithmetic (the scalar forms ran at 3.9 / 5.3 TB/s on the tower's maps)
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const f4* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, f4* __restrict__ y, size_t n4,
+                                                        int C4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const f4 m = *reinterpret_cast<const f4*>(mean + c), r = *reinterpret_cast<const f4*>(rstd + c), g = *reinterpret_cast<const f4*>(gamma + c),
+                 b = *reinterpret_cast<const f4*>(beta + c);
+        y[i] = (x[i] - m) * r * g + b;
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const f4* __restrict__ x, const f4* __restrict__ dy, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, f4* __restrict__ dx,
+                                                            float* __restrict__ dgamma, size_t n4, int C4, float inv_rows, int relu_mask) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const f4 m = *reinterpret_cast<const f4*>(mean + c), r = *reinterpret_cast<const f4*>(rstd + c), g = *reinterpret_cast<const f4*>(gamma + c),
+                 sd = *reinterpret_cast<const f4*>(sum_dy + c), sx = *reinterpret_cast<const f4*>(sum_dyx + c);
+        const f4 xv = x[i], dv = dy[i];
+        const f4 xh = (xv - m) * r;
+        const f4 sdyxh = r * sx;
+        f4 d = g * r * (dv - sd * inv_rows - xh * sdyxh * inv_rows);
+        if (relu_mask) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = xv[q] > 0.f ? d[q] : 0.f;
+        }
+        dx[i] = d;
+        if (dgamma && i < (size_t)C4) *reinterpret_cast<f4*>(dgamma + 4 * i) = r * sx;
+    }
+}
+
 // ---- fused SE-block pieces of the training path (ResNetBlocks.py:21-37 under autograd) --------------------------------------------
 // The conv kernels already emit per-(clip, tile) channel sums of their output (the SE pooling partials of the inference path):
 // BatchNorm's mean and the per-clip sums come from those without reading the map again.  One wave per channel.
@@ -1253,6 +1286,19 @@ int col_sums(const float* a, const float* b, const float* mean, int64_t rows, in
 // workspace for the column reductions below: partials [<= COL_MAX_PART][2][C] + one scratch column
 extern "C" int64_t eg_colreduce_workspace_floats(int32_t c) { return (int64_t)(2 * COL_MAX_PART + 1) * c; }
 
+namespace {
+int launch_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y, int64_t rows, int c, hipStream_t st) {
+    if ((c & 3) == 0 && eg_aligned16(x) && eg_aligned16(y) && eg_aligned16(mean) && eg_aligned16(rstd) && eg_aligned16(gamma) && eg_aligned16(beta)) {
+        const size_t n4 = (size_t)rows * c / 4;
+        hipLaunchKernelGGL(bn_apply4_kernel, grid1(n4), dim3(256), 0, st, reinterpret_cast<const f4*>(x), mean, rstd, gamma, beta, reinterpret_cast<f4*>(y), n4,
+                           c / 4);
+        return eg_check_launch("bn_apply4");
+    }
+    hipLaunchKernelGGL(bn_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, st, x, mean, rstd, gamma, beta, y, (size_t)rows * c, c);
+    return eg_check_launch("bn_apply");
+}
+}  // namespace
+
 extern "C" int eg_bn_train_forward(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_rstd,
                                    float* running_mean, float* running_var, int64_t rows, int32_t c, float momentum, float eps, float* workspace,
                                    void* stream) {
@@ -1265,8 +1311,7 @@ extern "C" int eg_bn_train_forward(const float* x, const float* gamma, const flo
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
                        running_mean, running_var);
     if (int rc = eg_check_launch("bn_finalize")) return rc;
-    hipLaunchKernelGGL(bn_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, save_mean, save_rstd, gamma, beta, y, (size_t)rows * c, c);
-    return eg_check_launch("bn_apply");
+    return launch_bn_apply(x, save_mean, save_rstd, gamma, beta, y, rows, c, ST);
 }
 extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, const float* save_mean, const float* save_rstd, float* dx,
                                     float* dgamma, float* dbeta, int64_t rows, int32_t c, int32_t relu_mask, float* workspace, void* stream) {
@@ -1275,6 +1320,13 @@ extern "C" int eg_bn_train_backward(const float* x, const float* dy, const float
     float* sum_dyx = workspace + (size_t)2 * COL_MAX_PART * c;           // scratch column behind the partials
     // (sum dy, sum dy*(x - mean)): dbeta receives sum dy directly; sum dy*(x - mean) goes to the scratch column
     if (int rc = col_sums(dy, x, save_mean, rows, c, 2, workspace, dbeta, sum_dyx, 1.0f, ST)) return rc;
+    if ((c & 3) == 0 && eg_aligned16(x) && eg_aligned16(dy) && eg_aligned16(dx) && eg_aligned16(save_mean) && eg_aligned16(save_rstd) && eg_aligned16(gamma) &&
+        eg_aligned16(dbeta) && eg_aligned16(sum_dyx) && eg_aligned16(dgamma)) {
+        const size_t n4 = (size_t)rows * c / 4;
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, grid1(n4), dim3(256), 0, ST, reinterpret_cast<const f4*>(x), reinterpret_cast<const f4*>(dy), save_mean,
+                           save_rstd, gamma, dbeta, sum_dyx, reinterpret_cast<f4*>(dx), dgamma, n4, c / 4, 1.0f / (float)rows, relu_mask);
+        return eg_check_launch("bn_bwd_apply4");
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, dbeta, sum_dyx, dx, dgamma,
                        (size_t)rows * c, c, 1.0f / (float)rows, relu_mask);
     return eg_check_launch("bn_bwd_apply");
@@ -1299,8 +1351,7 @@ extern "C" int eg_bn_train_forward_gap(const float* x, const float* gap_partial,
                        running_mean, running_var);
     if (int rc = eg_check_launch("bn_finalize")) return rc;
     if (!y) return EG_OK;
-    hipLaunchKernelGGL(bn_apply_kernel, grid1((size_t)rows * c), dim3(256), 0, ST, x, save_mean, save_rstd, gamma, beta, y, (size_t)rows * c, c);
-    return eg_check_launch("bn_apply");
+    return launch_bn_apply(x, save_mean, save_rstd, gamma, beta, y, rows, c, ST);
 }
 
 #define SE_TAIL_SHAPE(who) EG_REQUIRE(batch > 0 && hw > 0 && c >= 8 && c <= 256 && c % 8 == 0, EG_ERR_UNSUPPORTED, who ": C=%d (multiple of 8, <= 256)", c)
