@@ -208,6 +208,55 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict_
         dx[i] = s;
     }
 }
+// float4 forms (C % 4 == 0, fewer than 2^31 channel quads: 32-bit index arithmetic): one thread = 4 channels of a pixel
+__global__ __launch_bounds__(256) void col2im3x3_v4_kernel(const f4* __restrict__ col, f4* __restrict__ dx, int B, int H, int W, int C4, int Ho, int Wo,
+                                                           int S) {
+    const unsigned total = (unsigned)B * H * W * C4;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned c = i % C4;
+        unsigned r = i / C4;
+        const int xx = (int)(r % W);
+        r /= W;
+        const int yy = (int)(r % H), b = (int)(r / H);
+        f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ty = yy + 1 - kh;
+            if (ty < 0 || ty % S) continue;
+            const int oy = ty / S;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tx = xx + 1 - kw;
+                if (tx < 0 || tx % S) continue;
+                const int ox = tx / S;
+                if (ox >= Wo) continue;
+                s += col[(((size_t)b * Ho + oy) * Wo + ox) * 9 * C4 + (kh * 3 + kw) * C4 + c];
+            }
+        }
+        dx[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void subsample_v4_kernel(const f4* __restrict__ x, f4* __restrict__ y, int B, int H, int W, int C4, int Ho, int Wo, int S,
+                                                           int backward) {
+    const unsigned total = backward ? (unsigned)B * H * W * C4 : (unsigned)B * Ho * Wo * C4;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned c = i % C4;
+        unsigned r = i / C4;
+        if (!backward) {
+            const int ox = (int)(r % Wo);
+            r /= Wo;
+            const int oy = (int)(r % Ho), b = (int)(r / Ho);
+            y[i] = x[(((size_t)b * H + oy * S) * W + ox * S) * C4 + c];
+        } else {
+            const int xx = (int)(r % W);
+            r /= W;
+            const int yy = (int)(r % H), b = (int)(r / H);
+            const bool hit = (yy % S == 0) && (xx % S == 0) && (yy / S < Ho) && (xx / S < Wo);
+            y[i] = hit ? x[(((size_t)b * Ho + yy / S) * Wo + xx / S) * C4 + c] : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
 // strided pixel subsample (1x1 stride-s conv input) and its transpose
 __global__ __launch_bounds__(256) void subsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int Ho,
                                                         int Wo, int S, int backward) {
@@ -1212,6 +1261,9 @@ extern "C" int eg_im2col3x3(const float* x, float* col, int32_t batch, int32_t h
     const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
     if (!backward)
         hipLaunchKernelGGL(im2col3x3_kernel, grid1((size_t)batch * ho * wo * 9 * c, 65536), dim3(256), 0, ST, x, col, batch, h, w, c, ho, wo, stride);
+    else if ((c & 3) == 0 && eg_aligned16(x) && eg_aligned16(col) && (size_t)batch * h * w * c / 4 < (1ull << 31))
+        hipLaunchKernelGGL(col2im3x3_v4_kernel, grid1((size_t)batch * h * w * c / 4, 65536), dim3(256), 0, ST, reinterpret_cast<const f4*>(x),
+                           reinterpret_cast<f4*>(col), batch, h, w, c / 4, ho, wo, stride);
     else        // x = dcol [B*Ho*Wo, 9C], col = dx [B,H,W,C]
         hipLaunchKernelGGL(col2im3x3_kernel, grid1((size_t)batch * h * w * c, 65536), dim3(256), 0, ST, x, col, batch, h, w, c, ho, wo, stride);
     return eg_check_launch("im2col3x3");
@@ -1220,7 +1272,11 @@ extern "C" int eg_subsample(const float* x, float* y, int32_t batch, int32_t h, 
     EG_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && c > 0 && stride >= 1, EG_ERR_BAD_ARG, "eg_subsample: bad argument");
     const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
     const size_t total = backward ? (size_t)batch * h * w * c : (size_t)batch * ho * wo * c;
-    hipLaunchKernelGGL(subsample_kernel, grid1(total, 65536), dim3(256), 0, ST, x, y, batch, h, w, c, ho, wo, stride, backward);
+    if ((c & 3) == 0 && eg_aligned16(x) && eg_aligned16(y) && (size_t)batch * h * w * c / 4 < (1ull << 31))
+        hipLaunchKernelGGL(subsample_v4_kernel, grid1(total / 4, 65536), dim3(256), 0, ST, reinterpret_cast<const f4*>(x), reinterpret_cast<f4*>(y), batch, h, w,
+                           c / 4, ho, wo, stride, backward);
+    else
+        hipLaunchKernelGGL(subsample_kernel, grid1(total, 65536), dim3(256), 0, ST, x, y, batch, h, w, c, ho, wo, stride, backward);
     return eg_check_launch("subsample");
 }
 extern "C" int eg_im2col1d(const float* x, float* col, int32_t batch, int32_t len, int32_t c, int32_t k, int32_t stride, int32_t pad_left,
