@@ -395,6 +395,45 @@ def test_generator_train_step_gradients_match_oracle():
     assert txt is not None and tuple(txt.shape) == (batch, 60, 512)
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16x3", 3e-3)])
+def test_beat_long_generator_train_step_matches_oracle(precision, tol):
+    """BASELINE configs[3] shapes in train() mode (10 s audio -> spec 128x312, 120 frames, 282-dim poses, 10 prior frames: the decoder's
+    cross-attention runs Lq = Lk = 120, beyond the LDS-resident backward of round 2): loss, pose and every parameter gradient of one step
+    against the oracle's autograd (the oracle's BEAT-long forward is pinned to the reference by beat_long_b2.npz)."""
+    from conftest import make_args, make_lang
+    from emotiongestures_amd.Full_model.Models_spatial_memory import Transformer
+    from emotiongestures_amd.train import functional as F
+    from oracle import emogest_oracle as O
+    Fr, D, P, T, B, seed = 120, 282, 10, 312, 2, 21
+    model = Transformer(make_args(10), make_lang(200), frames=Fr, pose_dim=D, prior_frames=P, d_word_vec=512, d_model=512, d_inner=2048,
+                        n_layers=3, n_head=8, d_k=64, d_v=64, n_position=Fr, spec_len=T, precision="f32")
+    load_synth_weights(model, seed)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    inp = synth_inputs(B, Fr, D, P, spec_len=T, seed=seed)
+    target = torch.from_numpy((hash_unit("train.target_pose", B * Fr * D, seed) - 0.5).astype(np.float32).reshape(B, Fr, D))
+    label = torch.from_numpy(inp["label"]).argmax(1)
+    loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(frames=Fr, pose_dim=D, prior_frames=P, chunk=10), torch.from_numpy(inp["spec"]),
+                                                          torch.from_numpy(inp["text"]), torch.from_numpy(inp["pre_pose"]), target, label)
+    loss_ref.backward()
+    model.to(DEV).train()
+    try:
+        F.set_precision(precision)
+        pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
+                                          torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+        loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
+        loss.backward()
+    finally:
+        F.set_precision("f32")
+    assert tuple(pose.shape) == (B, Fr, D)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach()) < tol
+    assert rel(pose.detach(), pose_ref.detach()) < tol
+    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 5 * tol, "audio_encoder.feat_extractor.", 2e-2 if precision == "f32" else 5e-2)
+    print(f"BEAT-long generator ({precision}): {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower {worst_tower:.2e}")
+
+
 def test_emotion_net_train_step_and_adam():
     """The one training loop the reference ships (train_audio_classifier_K_fold.py:155-175): EmotionNet in train() mode,
     100 x FocalLoss, Adam(lr, betas=(0.5, 0.999), weight_decay=1e-5) -- gradients and the updated parameters vs the oracle / torch."""
