@@ -24,6 +24,7 @@ namespace {
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* scale; const float* shift;
     float* y; float* gap;
+    float* gap2 = nullptr;              // training forward: per-(clip, tile) channel sums of v*v beside `gap` (BatchNorm's variance without a pass over y)
     int H, W, Ho, Wo, cout, relu, nchw, tiles_x, tiles;
     // fused SE tail (SEBasicBlock.forward, ResNetBlocks.py:28-36, identity shortcut): v = relu(v * gate[b, co] + res[pixel, co])
     // applied after the BatchNorm affine; gate comes from se_gate_pre_kernel (computed BEFORE this convolution runs)
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
 
     // epilogue: v = acc + bias; relu; v*scale + shift.  Pixel offsets are 32-bit and computed once per pixel tile; the
     // per-image base is a scalar.  NHWC: one 16-byte store per (pixel tile, channel tile); NCHW (final_conv1 only): 4 stores.
-    f4 gsum[NT];
+    f4 gsum[NT], gsq[NT];
     int pixo[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
+        gsq[n] = gsum[n];
         const int co = (wn * NT + n) * 16 + kq * 4;
         const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
         const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
@@ -446,11 +448,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
                         if (co + r < a.cout) yb[(co + r) * hw + pixo[t]] = v[r];
                 }
                 gsum[n] += v;
+                if (a.gap2) gsq[n] += v * v;
             }
         }
     }
     if (a.gap) {            // no LDS reads follow the last step's barrier: the LDS is free for the reduction
-        float* sred = reinterpret_cast<float*>(lds);        // [WM][COUTP]
+        float* sred = reinterpret_cast<float*>(lds);        // [WM][COUTP] sums, then [WM][COUTP] sums of squares
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -459,6 +462,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
                 s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
                 s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
                 if (li == 0) sred[wm * COUTP + (wn * NT + n) * 16 + kq * 4 + r] = s;
+                if (a.gap2) {
+                    float q = gsq[n][r];
+                    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+                    q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+                    if (li == 0) sred[(WM + wm) * COUTP + (wn * NT + n) * 16 + kq * 4 + r] = q;
+                }
             }
         }
         __syncthreads();
@@ -467,6 +476,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
 #pragma unroll
             for (int m = 0; m < WM; ++m) s += sred[m * COUTP + tid];
             a.gap[((size_t)b * a.tiles + tile_id) * a.cout + tid] = s;
+            if (a.gap2) {
+                float q = 0.f;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) q += sred[(WM + m) * COUTP + tid];
+                a.gap2[((size_t)b * a.tiles + tile_id) * a.cout + tid] = q;
+            }
         }
     }
 }
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
     extern __shared__ __attribute__((aligned(16))) bf8 lds[];      // tile | weights (hi [tap][octet][co], lo) | gap scratch
     bf8* tile = lds;
     bf8* wl = lds + TILE;
-    // gap scratch [4 waves][32 floats]: behind the weights (4-row tiles), or -- 8-row tiles: tile + weights fill exactly half a CU's LDS -- in the
+    // gap scratch [4 waves][32 floats] (+ the same again for the sums of squares): behind the weights (4-row tiles), or -- 8-row tiles: tile + weights fill exactly half a CU's LDS -- in the
     // padding slots NPIX .. PL-1 of the first four channel-octet planes, which no staging write and no fragment read touches
     float* sred_base = reinterpret_cast<float*>(lds + TILE + NIMG * WIMG);
     const int sred_pitch = (TH == 4) ? 32 : PL * 4;               // floats between two waves' scratch rows
@@ -695,10 +710,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
         }
         stamp(3);
         float* __restrict__ yb = a.y + (size_t)b * hw * 32;
-        f4 gsum[NT];
+        f4 gsum[NT], gsq[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
+            gsq[n] = gsum[n];
             const int co = n * 16 + kq * 4;
             const f4 gt = a.gate ? *reinterpret_cast<const f4*>(a.gate + (size_t)b * 32 + co) : (f4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
@@ -718,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
                 if (pixo[t] >= 0) {
                     *reinterpret_cast<f4*>(yb + pixo[t] * 32 + co) = v;
                     gsum[n] += v;
+                    if (a.gap2) gsq[n] += v * v;
                 }
             }
         }
@@ -730,6 +747,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
                     sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
                     sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
                     if (li == 0) sred[wave * sred_pitch + n * 16 + kq * 4 + r] = sm;
+                    if (a.gap2) {               // 4-row tiles only (launch check): the squares' scratch follows the sums'
+                        float q = gsq[n][r];
+                        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+                        q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+                        if (li == 0) sred[128 + wave * 32 + n * 16 + kq * 4 + r] = q;
+                    }
                 }
         }
         stamp(4);
@@ -740,6 +763,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
 #pragma unroll
             for (int m = 0; m < 4; ++m) sm += sred[m * sred_pitch + tid];
             a.gap[((size_t)b * a.tiles + tile_id) * 32 + tid] = sm;
+            if (a.gap2) a.gap2[((size_t)b * a.tiles + tile_id) * 32 + tid] = (sred[128 + tid] + sred[160 + tid]) + (sred[192 + tid] + sred[224 + tid]);
         }
     }
     if constexpr (STAMP) {
@@ -999,7 +1023,7 @@ template <int TERMS, int TH>
 int launch_conv32_persistent_t(const ConvArgs& a, int batch, const bf8* whi, const bf8* wlo, hipStream_t st) {
     using G = ConvGeom<1, TH>;
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + NIMG * 9 * 128) + (TH == 4 ? 4 * 32 * sizeof(float) : 0);
+    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + NIMG * 9 * 128) + (TH == 4 ? 2 * 4 * 32 * sizeof(float) : 0);   // + sums / squares scratch
     auto kern = conv3x3_c32_persistent_kernel<TERMS, TH>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (32 -> 32, persistent)")) return rc;
     const int total = a.tiles * batch;
@@ -1082,9 +1106,31 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
     return eg_conv3x3_se(x, w, bias, scale, shift, nullptr, nullptr, y, gap_partial, batch, h, wdt, cin, cout, stride, relu, nchw_out, precision, stream);
 }
 
+namespace {
+int conv3x3_dispatch(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate, const float* residual,
+                     float* y, float* gap_partial, float* gap_sq, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
+                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
+}
 extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate,
                              const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin,
                              int32_t cout, int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
+    return conv3x3_dispatch(x, w, bias, scale, shift, gate, residual, y, gap_partial, nullptr, batch, h, wdt, cin, cout, stride, relu, nchw_out, precision, stream);
+}
+// Training forward: y = [relu](conv(x) + bias), plus the per-(clip, tile) channel sums of y AND of y*y (both [batch][tiles][cout]): train-mode
+// BatchNorm takes its mean and variance from them (csrc/train.hip: eg_bn_train_forward_sq) without reading y again.  Split-bf16 modes only.
+extern "C" int eg_conv3x3_sq(const float* x, const float* w, const float* bias, float* y, float* gap_partial, float* gap_sq_partial, int32_t batch, int32_t h,
+                             int32_t wdt, int32_t cin, int32_t cout, int32_t stride, int32_t relu, int32_t precision, void* stream) {
+    EG_REQUIRE(gap_partial && gap_sq_partial, EG_ERR_BAD_ARG, "eg_conv3x3_sq: both partial buffers are required");
+    EG_REQUIRE(precision != EG_PREC_F32, EG_ERR_UNSUPPORTED, "eg_conv3x3_sq: split-bf16 modes only (the fp32 kernel emits sums only)");
+    EG_REQUIRE(!(cin == 32 && cout == 32 && stride == 1) || conv_tile_rows(cin, cout, stride) == 4, EG_ERR_UNSUPPORTED,
+               "eg_conv3x3_sq: the 8-row experiment tiles of the 32 -> 32 kernel have no room for the squares scratch");
+    return conv3x3_dispatch(x, w, bias, nullptr, nullptr, nullptr, nullptr, y, gap_partial, gap_sq_partial, batch, h, wdt, cin, cout, stride, relu, 0, precision,
+                            stream);
+}
+namespace {
+int conv3x3_dispatch(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate, const float* residual,
+                     float* y, float* gap_partial, float* gap_sq, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
+                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
     EG_REQUIRE(x && w && y && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3: null pointer or empty shape");
     // gate + residual: relu(v * gate + residual) (the fused SE tail); residual alone: v + residual, no ReLU (the training path's fused fan-in add:
     // an input gradient that lands on a tensor with a second consumer, train/functional.py conv3x3(passthrough=True))
@@ -1096,7 +1142,7 @@ extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, 
     EG_REQUIRE(precision >= 0 && precision <= 2, EG_ERR_BAD_ARG, "eg_conv3x3: precision %d", precision);
     EG_REQUIRE(nchw_out || (cout % 4 == 0), EG_ERR_UNSUPPORTED, "eg_conv3x3: NHWC output needs cout %% 4 == 0");
     ConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.gap = gap_partial;
+    a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.gap = gap_partial; a.gap2 = gap_sq;
     a.gate = gate; a.res = residual; a.relu2 = gate ? 1 : 0;
     a.H = h; a.W = wdt; a.Ho = (h + 2 - 3) / stride + 1; a.Wo = (wdt + 2 - 3) / stride + 1;
     a.cout = cout; a.relu = relu; a.nchw = nchw_out;
@@ -1127,6 +1173,7 @@ extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, 
     eg_set_error("eg_conv3x3: unsupported channels cin=%d cout=%d stride=%d", cin, cout, stride);
     return EG_ERR_UNSUPPORTED;
 }
+}  // namespace
 
 extern "C" int eg_stem_conv(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift,
                             float* y, int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream) {

@@ -564,6 +564,58 @@ __global__ __launch_bounds__(256) void bn_mean_from_clips_kernel(const float* __
     if (lane == 0) mean[c] = (float)(tot / (double)rows);
 }
 
+// Train-mode BatchNorm statistics from the producing convolution's per-tile sums AND sums of squares (eg_conv3x3_sq): no pass over the map.
+// The per-tile partials are fp32 sums over <= 256 pixels; everything across tiles and clips, and the E[x^2] - mean^2 subtraction, is double:
+// the relative error of the variance is ~1e-6 (1 + mean^2 / var), far inside the split-bf16 modes' own error (the fp32 configuration keeps
+// the centred pass over the map).
+__global__ __launch_bounds__(256) void clip_sums_sq_kernel(const float* __restrict__ gap, const float* __restrict__ gap_sq, int tiles, int C,
+                                                           float* __restrict__ clip_sum, double* __restrict__ clip_d) {
+    __shared__ float red[256];
+    __shared__ double redq[256], reds[256];
+    const int b = blockIdx.x, t = threadIdx.x, c = t % C, g = t / C, ng = 256 / C;          // C divides 256: ng tile groups
+    float s = 0.f;
+    double sd = 0.0, q = 0.0;
+    for (int k = g; k < tiles; k += ng) {
+        const float v = gap[((size_t)b * tiles + k) * C + c];
+        s += v;                                 // the fp32 clip sum the SE pooling uses (same order as clip_sum_from_gap_kernel)
+        sd += (double)v;
+        q += (double)gap_sq[((size_t)b * tiles + k) * C + c];
+    }
+    red[t] = s;
+    reds[t] = sd;
+    redq[t] = q;
+    __syncthreads();
+    if (t < C) {
+        float a = 0.f;
+        double ad = 0.0, aq = 0.0;
+        for (int k = 0; k < ng; ++k) { a += red[k * C + t]; ad += reds[k * C + t]; aq += redq[k * C + t]; }
+        if (clip_sum) clip_sum[(size_t)b * C + t] = a;
+        clip_d[((size_t)b * 2) * C + t] = ad;
+        clip_d[((size_t)b * 2 + 1) * C + t] = aq;
+    }
+}
+__global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __restrict__ clip_d, int B, int C, long rows, float eps, float momentum,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                             float* __restrict__ run_var) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < B; b += 64) { s += clip_d[((size_t)b * 2) * C + c]; q += clip_d[((size_t)b * 2 + 1) * C + c]; }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane != 0) return;
+    const double m = s / (double)rows;
+    double var = q / (double)rows - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
 // SE gate of one clip from the pooled BatchNorm output, pooled[c] = gamma (clip_sum/HW - mean) rstd + beta = mean_hw(bn2(c2)):
 // h = relu(W1 pooled + b1), gate = sigmoid(W2 h + b2) (ResNetBlocks.py:92-96).  One workgroup per clip, C <= 256.
 __global__ __launch_bounds__(256) void se_gate_train_kernel(const float* __restrict__ clip_sum, const float* __restrict__ mean,
@@ -1406,6 +1458,27 @@ extern "C" int eg_bn_train_forward_gap(const float* x, const float* gap_partial,
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, workspace, nblk, c, (long)rows, eps, momentum, save_mean, save_rstd,
                        running_mean, running_var);
     if (int rc = eg_check_launch("bn_finalize")) return rc;
+    if (!y) return EG_OK;
+    return launch_bn_apply(x, save_mean, save_rstd, gamma, beta, y, rows, c, ST);
+}
+
+// The same operator fed by eg_conv3x3_sq's two partial arrays: statistics in two small launches (per-clip folds, then the merge), no pass over x.
+// workspace >= eg_colreduce_workspace_floats(c) (holds the per-clip double sums: 4 * batch * c floats).
+extern "C" int eg_bn_train_forward_sq(const float* x, const float* gap_partial, const float* gap_sq_partial, int32_t tiles, int32_t batch,
+                                      const float* gamma, const float* beta, float* y, float* save_mean, float* save_rstd, float* clip_sum,
+                                      float* running_mean, float* running_var, int64_t rows, int32_t c, float momentum, float eps, float* workspace,
+                                      void* stream) {
+    EG_REQUIRE(gap_partial && gap_sq_partial && save_mean && save_rstd && workspace && rows > 0 && c > 0 && tiles > 0 && batch > 0 &&
+                   (!y || (x && gamma && beta)), EG_ERR_BAD_ARG, "eg_bn_train_forward_sq: bad argument");
+    EG_REQUIRE(c <= 256 && 256 % c == 0, EG_ERR_UNSUPPORTED, "eg_bn_train_forward_sq: C=%d must divide 256", c);
+    EG_REQUIRE((int64_t)4 * batch * c <= eg_colreduce_workspace_floats(c) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EG_ERR_WORKSPACE,
+               "eg_bn_train_forward_sq: batch %d does not fit the reduction workspace", batch);
+    double* clip_d = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(clip_sums_sq_kernel, dim3(batch), dim3(256), 0, ST, gap_partial, gap_sq_partial, tiles, c, clip_sum, clip_d);
+    if (int rc = eg_check_launch("clip_sums_sq")) return rc;
+    hipLaunchKernelGGL(bn_finalize_sq_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, clip_d, batch, c, (long)rows, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var);
+    if (int rc = eg_check_launch("bn_finalize_sq")) return rc;
     if (!y) return EG_OK;
     return launch_bn_apply(x, save_mean, save_rstd, gamma, beta, y, rows, c, ST);
 }

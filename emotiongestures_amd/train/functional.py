@@ -440,10 +440,18 @@ class _Conv3x3(torch.autograd.Function):
                 bp[:Co].copy_(_chk(b))
             if Co % 4 == 0:
                 y = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev)
-                if want_gap:            # per-(clip, tile) channel sums of y from the conv epilogue: BatchNorm's mean / the SE pooling for free
-                    gap = torch.empty(B, int(lib.eg_conv3x3_gap_tiles(H, W, Ci, Co, stride)), Co, dtype=torch.float32, device=dev)
-                L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), _ptr(gap), B, H, W, Ci, Co, stride, int(relu), 0, prec,
-                                       _stream(dev)), "eg_conv3x3")
+                tiles = int(lib.eg_conv3x3_gap_tiles(H, W, Ci, Co, stride)) if want_gap else 0
+                if want_gap and prec != F32 and 256 % Co == 0:
+                    # split-bf16 modes: the epilogue also emits the per-tile sums of squares -- gap is then [2, B, tiles, Co] (plane 0 = the sums every
+                    # consumer reads through the base pointer, plane 1 = the squares): train-mode BatchNorm needs no pass over y for its variance
+                    gap = torch.empty(2, B, tiles, Co, dtype=torch.float32, device=dev)
+                    L.check(lib.eg_conv3x3_sq(_ptr(xd), _ptr(wp), _ptr(bp), _ptr(y), _ptr(gap), _ptr(gap[1]), B, H, W, Ci, Co, stride, int(relu), prec,
+                                              _stream(dev)), "eg_conv3x3_sq")
+                else:
+                    if want_gap:        # per-(clip, tile) channel sums of y from the conv epilogue: BatchNorm's mean / the SE pooling for free
+                        gap = torch.empty(B, tiles, Co, dtype=torch.float32, device=dev)
+                    L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(y), _ptr(gap), B, H, W, Ci, Co, stride, int(relu), 0, prec,
+                                           _stream(dev)), "eg_conv3x3")
             else:           # ragged channel count (final_conv1: 128 -> frames): channel-major epilogue, then back to NHWC
                 yc = torch.empty(B, Co, Ho * Wo, dtype=torch.float32, device=dev)
                 L.check(lib.eg_conv3x3(_ptr(xd), _ptr(wp), _ptr(bp), None, None, _ptr(yc), None, B, H, W, Ci, Co, stride, int(relu), 1, prec,
@@ -599,7 +607,11 @@ class _BatchNorm(torch.autograd.Function):
         y = torch.empty_like(xd)
         mean, rstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
-        if gap is not None:         # mean from the producing convolution's pooling partials: one pass (centred squares) instead of two
+        if gap is not None and gap.dim() == 4:     # sums and sums of squares from the producing convolution: statistics without touching the map
+            L.check(lib.eg_bn_train_forward_sq(_ptr(xd), _ptr(gap), _ptr(gap[1]), gap.shape[2], gap.shape[1], _ptr(g), _ptr(b), _ptr(y), _ptr(mean),
+                                               _ptr(rstd), None, _ptr(run_mean), _ptr(run_var), rows, Cc, float(momentum), float(eps), _ptr(ws),
+                                               _stream(dev)), "eg_bn_train_forward_sq")
+        elif gap is not None:       # mean from the producing convolution's pooling partials: one pass (centred squares) instead of two
             L.check(lib.eg_bn_train_forward_gap(_ptr(xd), _ptr(gap), gap.shape[1], gap.shape[0], _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), None,
                                                 _ptr(run_mean), _ptr(run_var), rows, Cc, float(momentum), float(eps), _ptr(ws), _stream(dev)),
                     "eg_bn_train_forward_gap")
@@ -648,8 +660,12 @@ class _SEBlockTail(torch.autograd.Function):
         mean, rstd, clip = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(B, Cc, device=dev)
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
         st = _stream(dev)
-        L.check(lib.eg_bn_train_forward_gap(_ptr(x), _ptr(gap), gap.shape[1], B, None, None, None, _ptr(mean), _ptr(rstd), _ptr(clip), _ptr(run_mean),
-                                            _ptr(run_var), B * hw, Cc, float(momentum), float(eps), _ptr(ws), st), "eg_bn_train_forward_gap")
+        if gap.dim() == 4:          # conv2 emitted sums and sums of squares: bn2's statistics and the SE pooling without a pass over c2
+            L.check(lib.eg_bn_train_forward_sq(None, _ptr(gap), _ptr(gap[1]), gap.shape[2], B, None, None, None, _ptr(mean), _ptr(rstd), _ptr(clip),
+                                               _ptr(run_mean), _ptr(run_var), B * hw, Cc, float(momentum), float(eps), _ptr(ws), st), "eg_bn_train_forward_sq")
+        else:
+            L.check(lib.eg_bn_train_forward_gap(_ptr(x), _ptr(gap), gap.shape[1], B, None, None, None, _ptr(mean), _ptr(rstd), _ptr(clip), _ptr(run_mean),
+                                                _ptr(run_var), B * hw, Cc, float(momentum), float(eps), _ptr(ws), st), "eg_bn_train_forward_gap")
         pooled, h, gate = torch.empty(B, Cc, device=dev), torch.empty(B, Cc // 8, device=dev), torch.empty(B, Cc, device=dev)
         L.check(lib.eg_se_gate_train_forward(_ptr(clip), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(w1d), _ptr(b1d), _ptr(w2d), _ptr(b2d), _ptr(pooled),
                                              _ptr(h), _ptr(gate), B, hw, Cc, st), "eg_se_gate_train_forward")

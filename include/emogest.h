@@ -241,6 +241,11 @@ int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, 
 int eg_conv3x3_se(const float* x, const float* w_packed, const float* bias, const float* scale, const float* shift, const float* gate,
                   const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
                   int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
+/* Training forward of a tower convolution (nn.Conv2d -> optional ReLU, ResNetBlocks.py:24-27 under autograd) in the split-bf16 modes: y as
+ * eg_conv3x3 plus BOTH per-(clip, tile) channel partials, sums of y and of y*y ([batch][eg_conv3x3_gap_tiles][cout] each), so that the train-mode
+ * BatchNorm that follows takes mean and variance from them (eg_bn_train_forward_sq) without reading y again. */
+int eg_conv3x3_sq(const float* x, const float* w_packed, const float* bias, float* y, float* gap_partial, float* gap_sq_partial, int32_t batch,
+                  int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride, int32_t relu, int32_t precision, void* stream);
 /* First tower stage on producer-split activations ("P32": per clip two bf16 images, hi then lo, each [4 channel octets][h*w pixels][8 bf16]; the same
  * bytes as fp32 NHWC at 32 channels).  The producer's epilogue splits once; the 32 -> 32 convolution stages halo tiles by LDS-DMA without a split
  * pass (ResNetSE34V2.py:64-67, ResNetBlocks.py:21-37 at 32 channels).  Split-bf16 / bf16 arithmetic only (precision 1 or 2).
@@ -434,6 +439,12 @@ int eg_bn_train_backward(const float* x, const float* dy, const float* gamma, co
 int eg_bn_train_forward_gap(const float* x, const float* gap_partial, int32_t tiles, int32_t batch, const float* gamma, const float* beta,
                             float* y, float* save_mean, float* save_rstd, float* clip_sum, float* running_mean, float* running_var,
                             int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream);
+/* The same with the variance also from partials (eg_conv3x3_sq's sums of squares): two small launches, no pass over x; the per-tile partials are
+ * fp32, everything across tiles / clips and E[x^2] - mean^2 is double (relative error of the variance ~1e-6 (1 + mean^2 / var): used in the
+ * split-bf16 modes only).  x may be NULL when y is NULL. */
+int eg_bn_train_forward_sq(const float* x, const float* gap_partial, const float* gap_sq_partial, int32_t tiles, int32_t batch, const float* gamma,
+                           const float* beta, float* y, float* save_mean, float* save_rstd, float* clip_sum, float* running_mean, float* running_var,
+                           int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream);
 /* SEBasicBlock tail under autograd (ResNetBlocks.py:28-36,92-96), maps [batch, hw, c] channels-last, c % 8 == 0, c <= 256:
  *   forward:  pooled = mean_hw(bn2(c2)) from clip_sum; h = relu(W1 pooled + b1); gate = sigmoid(W2 h + b2)      (eg_se_gate_train_forward)
  *             out = relu(bn2(c2) * gate + res) in one pass, bn2's output never stored                            (eg_se_tail_forward)

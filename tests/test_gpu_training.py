@@ -80,6 +80,33 @@ def test_conv1x1_stride2_and_conv1d():
     _grad_check(lambda x, w: F.conv1d_cl(x, w, None, 1, 1, 1), lambda x, w: TF.conv1d(x.transpose(1, 2), w, None, padding=1).transpose(1, 2), [x, w])
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", [(3, 19, 45, 32, 32, 1), (2, 24, 40, 32, 64, 2), (2, 17, 33, 64, 64, 1), (2, 9, 31, 128, 128, 1), (16, 12, 20, 64, 128, 2)])
+def test_conv_epilogue_squares_give_batchnorm_statistics(B, H, W, Ci, Co, s):
+    """Split-bf16 training forward: the convolution's epilogue emits per-(clip, tile) sums of y and of y*y (eg_conv3x3_sq) and train-mode BatchNorm
+    takes mean / variance / running statistics from them (eg_bn_train_forward_sq) without a pass over y -- against torch's batch_norm on the same y
+    (ragged tiles, stride-2 entries, every channel count of the tower)."""
+    from types import SimpleNamespace as NS
+    from emotiongestures_amd.train import functional as F
+    x, w = T("x", (B, H, W, Ci), -1, 2).to(DEV), T("w", (Co, Ci, 3, 3), -0.1, 0.1).to(DEV)
+    g, b = T("g", (Co,), 0.5, 1.5).to(DEV), T("b", (Co,)).to(DEV)
+    try:
+        F.set_precision("bf16x3")
+        y, gap = F.conv3x3(x, w, None, s, relu=True, want_gap=True)
+        assert gap.dim() == 4 and gap.shape[0] == 2 and gap.shape[1] == B
+        yc = y.detach().double().cpu()
+        assert rel(gap[0].sum(1).cpu(), yc.sum((1, 2)).float()) < 1e-5                       # per-clip channel sums
+        assert rel(gap[1].sum(1).cpu(), (yc * yc).sum((1, 2)).float()) < 1e-5               # per-clip channel sums of squares
+        bn = NS(weight=g, bias=b, running_mean=T("rm", (Co,)).to(DEV), running_var=T("rv", (Co,), 0.5, 1.5).to(DEV), num_batches_tracked=torch.tensor(0))
+        rm, rv = bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()
+        out = F.batch_norm(y, bn, gap=gap, relu_input=True)
+        ref = TF.batch_norm(y.detach().cpu().permute(0, 3, 1, 2), rm, rv, g.cpu(), b.cpu(), True, 0.1, 1e-5).permute(0, 2, 3, 1)
+        assert rel(out.cpu(), ref) < 1e-5
+        assert rel(bn.running_mean.cpu(), rm) < 1e-5 and rel(bn.running_var.cpu(), rv) < 1e-5
+    finally:
+        F.set_precision("f32")
+        F.flush_batch_counters()
+
+
 def test_batchnorm_layernorm_se_attention():
     from emotiongestures_amd.train import functional as F
     from types import SimpleNamespace as NS
