@@ -351,7 +351,8 @@ extern "C" int eg_conv1d_cl_backward_input(const float* dy, const float* w, cons
     const int cpw = cpw_of(cin);
     const int rows_cap = (C1_TL - 1 + (k - 1) * dilation) / stride + 2;
     const size_t lds = sizeof(float) * ((size_t)((rows_cap * (cout + 1) + 3) & ~3) + (size_t)cout * k * 4 * cpw);
-    if (cpw && lds <= C1_LDS_CAP && batch <= 65535) {
+    // pad <= (k - 1) * dilation: the staged dy rows of a tile then fit rows_cap (any Conv1d / ConvTranspose1d of the path; else the untiled kernel)
+    if (cpw && lds <= C1_LDS_CAP && batch <= 65535 && pad <= (k - 1) * dilation) {
         const dim3 grid(eg_cdiv(len, C1_TL), batch);
         switch (cpw) {
             case 1: hipLaunchKernelGGL((conv1d_cl_bwd_input_tiled_kernel<1>), grid, dim3(256), lds, st, a); break;
