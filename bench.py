@@ -619,12 +619,17 @@ def main():
         torch.cuda.empty_cache()
         train = {}
         for tb in (16, 128):
-            rec = train_leg(dev, tb, "bf16x3", True, max(5, args.steps // 2), 3)
-            par = train_leg(dev, tb, "f32", False, 3, 1)
-            for k in ("trainable_parameters", "buckets", "allreduce_exposed_ms_per_step"):
-                rec.pop(k, None)
-            rec["f32_eager"] = {k: par[k] for k in ("value", "ms_per_step", "first_loss", "library_launches_per_step", "frac_of_mfma_peak")}
-            train[f"b{tb}"] = rec
+            try:
+                rec = train_leg(dev, tb, "bf16x3", True, max(5, args.steps // 2), 3)
+                par = train_leg(dev, tb, "f32", False, 3, 1)
+                for k in ("trainable_parameters", "buckets", "allreduce_exposed_ms_per_step"):
+                    rec.pop(k, None)
+                rec["f32_eager"] = {k: par[k] for k in ("value", "ms_per_step", "first_loss", "library_launches_per_step", "frac_of_mfma_peak")}
+                train[f"b{tb}"] = rec
+            except Exception as e:      # a failed leg must not take the (already measured) headline with it: it is reported in the line, loudly
+                print(f"bench.py: training leg at {tb} clips FAILED: {e!r}", file=sys.stderr)
+                train[f"b{tb}"] = {"error": repr(e)[:400]}
+                torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_g, sd_v, inp)
 
