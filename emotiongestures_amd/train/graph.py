@@ -39,7 +39,7 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):               # warm-up off the capture: lazily sized scratch buffers, kernel attributes, autograd state
             for _ in range(max(1, warmup)):
-                step_fn(inputs)
+                self.warmup_loss = step_fn(inputs)  # real steps on `inputs`: a loop that must not train a batch twice takes this as its iteration
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()

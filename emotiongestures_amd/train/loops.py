@@ -129,10 +129,13 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
                  betas=(0.5, 0.999), weight_decay: float = 1e-5, gamma: float = 2.0, val_every: int = 100, save_dir: Optional[str] = None,
                  test_dataset=None, seed: int = 0, precision: str = "f32", alpha_mode: str = "by_label", spec_len: Optional[int] = 128,
                  max_iters_per_fold: Optional[int] = None, folds: Optional[Sequence[int]] = None, model_factory: Optional[Callable] = None,
-                 log: Callable[[str], None] = print) -> List[Dict[str, object]]:
+                 use_graph: bool = False, log: Callable[[str], None] = print) -> List[Dict[str, object]]:
     """train_K_fold (train_audio_classifier_K_fold.py:109-200).  Returns one record per fold: losses, validation / test accuracies,
     checkpoint paths.  `precision`: "f32" (gradient-parity arithmetic) or "bf16x3" (split-bf16 MFMA) for the convolutions / Linear products.
-    Under torch.distributed (initialised by the caller) the loop is data parallel as described in the module docstring."""
+    Under torch.distributed (initialised by the caller) the loop is data parallel as described in the module docstring.
+    use_graph: replay the iteration (zero_grad, forward, loss, backward, gradient collection and -- on one rank -- Adam) from one captured
+    hipGraph per fold instead of issuing its ~600 launches through autograd (a batch of 8 is host-bound otherwise); with several ranks the
+    bucket all-reduces and Adam follow each replay.  Same kernels, same order: the losses equal the eager loop's."""
     import torch.distributed as dist
     from ..model.audio_emotion_classifer import EmotionNet
     from . import functional as F
@@ -165,21 +168,54 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
             rec = {"fold": fold, "loss": [], "val_acc": [], "test_acc": [], "checkpoints": [], "iterations": 0}
             global_iter = 0
             done = False
+            graphed, static = None, None            # use_graph: built at the first full batch of the fold
+
+            def eager_iteration(spec_d, label_d, alpha_d):
+                opt.zero_grad()
+                if gb is not None:
+                    gb.begin()
+                loss = F.focal_loss(model(spec_d), label_d, alpha_d, gamma, 100.0)          # criterion(output, label) * 100 (:168)
+                loss.backward()
+                if gb is not None:
+                    gb.finish()
+                opt.step(collected=gb is not None)
+                return loss
+
             for epoch in range(total_epoch):
                 w = class_weights(all_labels[train_index])                       # :146-150 (recomputed every epoch, as upstream)
                 for idx in epoch_batches(train_index, batch_size, seed * 100003 + fold * 1009 + epoch, rank, world):
                     spec, label = _collate(train_dataset, idx, spec_len)
                     alpha = torch.tensor(w if alpha_mode == "positional" else w[label.numpy()], dtype=torch.float32)
                     model.train()
-                    opt.zero_grad()
-                    if gb is not None:
-                        gb.begin()
                     global_iter += 1
-                    loss = F.focal_loss(model(spec.to(device)), label.to(device), alpha, gamma, 100.0)      # criterion(output, label) * 100 (:168)
-                    loss.backward()
-                    if gb is not None:
-                        gb.finish()
-                    opt.step(collected=gb is not None)
+                    batch = {"spec": spec.to(device), "label": label.to(device), "alpha": alpha.to(device)}
+                    if use_graph and len(idx) == batch_size:
+                        if graphed is None:
+                            from .graph import GraphedStep
+                            static = {k: v.clone() for k, v in batch.items()}
+                            if gb is None:
+                                graphed = GraphedStep(lambda _i: eager_iteration(static["spec"], static["label"], static["alpha"]), static, opt, warmup=1)
+                            else:       # data parallel: the graph holds forward + backward + collection; collectives and Adam follow the replay
+                                gb.deferred = True
+
+                                def fwd_bwd(_i):
+                                    opt.zero_grad()
+                                    gb.begin()
+                                    ls = F.focal_loss(model(static["spec"]), static["label"], static["alpha"], gamma, 100.0)
+                                    ls.backward()
+                                    gb.finish()
+                                    return ls
+                                graphed = GraphedStep(fwd_bwd, static, None, warmup=1, device=device)
+                            loss = graphed.warmup_loss          # the capture's one warm-up step WAS this batch's iteration (executed eagerly)
+                        else:
+                            loss = graphed.run(batch)
+                        if gb is not None:
+                            gb.reduce_deferred()
+                            opt.step(collected=True)
+                    else:
+                        if gb is not None:
+                            gb.deferred = False
+                        loss = eager_iteration(batch["spec"], batch["label"], batch["alpha"])
                     rec["loss"].append(float(loss.detach()))
                     if global_iter % val_every == 0:                             # :177
                         va = evaluate(model, train_dataset, val_index, batch_size, device, spec_len)

@@ -67,6 +67,30 @@ def test_k_fold_loop_trains_validates_saves_and_reloads(tmp_path):
     assert hist[0]["loss"] != hist[1]["loss"]
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_k_fold_loop_replayed_from_a_graph_equals_the_eager_loop(precision):
+    """use_graph=True: the iteration replayed from one captured hipGraph per fold (the capture's warm-up step is the fold's first iteration, so no
+    batch trains twice).  Same kernels in the same order: the losses of six iterations and the final parameters / BatchNorm statistics equal
+    the eager loop's bitwise, the validation inside the loop (eval mode between replays) sees the updated weights."""
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    from emotiongestures_amd.synth import load_synth_weights
+    from emotiongestures_amd.train import loops
+    ds = build_dataset()
+    runs = []
+    for use_graph in (False, True):
+        factory = lambda: load_synth_weights(EmotionNet(precision="f32"), 7)
+        hist = loops.train_k_fold(ds, device=DEV, n_splits=2, total_epoch=3, batch_size=4, lr=1e-4, val_every=3, seed=2, max_iters_per_fold=6, folds=[1],
+                                  precision=precision, model_factory=factory, use_graph=use_graph, log=lambda s: None)
+        h = hist[0]
+        assert h["iterations"] == 6
+        flat = torch.cat([p.detach().reshape(-1) for p in h["model"].parameters()] + [b.detach().reshape(-1).float() for b in h["model"].buffers()]).cpu()
+        runs.append((h["loss"], h["val_acc"], flat))
+    (l0, v0, p0), (l1, v1, p1) = runs
+    assert l0 == l1, (l0, l1)
+    assert v0 == v1
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+
+
 _WORKER = textwrap.dedent('''
     import os, sys
     sys.path.insert(0, os.environ["EG_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EG_ROOT"], "tests"))
