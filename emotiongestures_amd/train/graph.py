@@ -75,14 +75,18 @@ class SegmentedStep:
     the graphs (RCCL launches issued by torch.distributed on the side stream), so the same code runs over gloo in the tests.
 
     loss_fn() runs the train-mode forward and returns the loss tensor (no zero_grad / backward / optimiser calls inside).
-    use_graphs=False issues the same phases eagerly (the CPU test of the bucket ordering; also the fallback while debugging)."""
+    use_graphs=False issues the same phases eagerly (the CPU test of the bucket ordering; also the fallback while debugging).
+    stochastic=True: the model's dropout is on (`train_dropout`): the mask epoch moves to the device before the warm-up, so that every replay
+    of the segments draws fresh masks (forward and backward of one step share the epoch: it advances once per step, in segment 0)."""
 
-    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower",), warmup: int = 3, use_graphs: bool = True):
+    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower",), warmup: int = 3, use_graphs: bool = True, stochastic: bool = False):
         from . import nets
         self.loss_fn, self.gb, self.opt, self.nets = loss_fn, buckets, optimizer, nets
         self.ctx = nets.CutContext(cuts)
         self.use_graphs = bool(use_graphs)
         self.dev = torch.device(device) if device is not None else buckets.fp.grad.device
+        if stochastic and self.use_graphs and self.dev.type == "cuda":       # the model trains with dropout: device-resident mask epoch, as in GraphedStep
+            F.use_device_dropout_epoch(self.dev)
         self.gb.deferred = True                                   # hooks only collect and record completion order; this class issues the collectives
         self.side = torch.cuda.Stream(self.dev) if self.dev.type == "cuda" else None
         self.ready = []                                           # per phase: buckets completed by that phase (recorded at the first run)
