@@ -1047,7 +1047,7 @@ int launch_conv32_persistent(const ConvArgs& a, int batch, int precision, int th
         (void)hipMemsetAsync(dbg, 0, nwords * sizeof(unsigned int), st);
         ConvArgs b = a;
         b.dbg = dbg;
-        constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(2 * 4 * ConvGeom<1, 4>::PL + 2 * 9 * 128) + 4 * 32 * sizeof(float);
+        constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(2 * 4 * ConvGeom<1, 4>::PL + 2 * 9 * 128) + 2 * 4 * 32 * sizeof(float);   // sums + squares (a.gap2), as the production launch
         auto kern = conv3x3_c32_persistent_kernel<3, 4, true>;
         if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (stamps)")) return rc;
         const int total = a.tiles * batch;

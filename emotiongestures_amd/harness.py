@@ -170,6 +170,44 @@ class Motion_Discriminator(nn.Module):
         return _affine_chain(self._cache, h.reshape(B, -1).contiguous(), head, True, self.precision)
 
 
+class Pose_Discriminator(nn.Module):
+    """Full_model/Models_spatial_memory.py:671-704: encoder over a pose sequence -> per-frame Linear(282, 64) -> Dropout(0.2) -> Linear(64, 1)
+    -> sigmoid: one real / fake probability per frame, [B, T, 1].  The head is hard-coded to 282 inputs and consumes the d_model-wide encoder
+    output directly, and the encoder adds a d_word_vec-wide positional table to the raw poses: the forward is consistent only for
+    d_word_vec == d_model == pose_dim (282 upstream), which the upstream defaults (128) violate -- refused up front, as Motion_Discriminator.
+    `pose_dim` is a keyword of this build (upstream: the literal 282).  eval(): the inference kernels; train(): the differentiable operators
+    (train/nets.pose_discriminator_forward), the 0.2 Dropout active with `train_dropout`."""
+
+    def __init__(self, src_pad_idx=1, trg_pad_idx=1, d_word_vec=128, d_model=128, d_inner=1024, n_layers=3, n_head=8, d_k=64, d_v=64,
+                 dropout=0.2, n_position=60, *, pose_dim=282, precision="f32"):
+        super().__init__()
+        if not (pose_dim == d_word_vec == d_model):
+            raise ValueError(f"Pose_Discriminator: forward needs d_word_vec == d_model == {pose_dim} (got {d_word_vec}, {d_model}); "
+                             "the upstream defaults fail at the first tensor add")
+        self.d_model = d_model
+        self.encoder = Encoder(n_position=n_position, d_word_vec=d_word_vec, d_model=d_model, d_inner=d_inner, n_layers=n_layers,
+                               n_head=n_head, d_k=d_k, d_v=d_v, pad_idx=src_pad_idx, dropout=dropout)
+        self.fc = _seq(Linear(pose_dim, 64), None, Linear(64, 1))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.precision = precision
+        self._cache = _PackCache()
+
+    def forward(self, x):
+        B, T, D = x.shape
+        if D != self.d_model:
+            raise ValueError(f"Pose_Discriminator.forward: expected [B, T, {self.d_model}], got {tuple(x.shape)}")
+        if self.training:
+            from .train import nets
+            return nets.pose_discriminator_forward(self, x)
+        for layer in self.encoder.layer_stack:
+            layer.slf_attn.precision = layer.pos_ffn.precision = self.precision
+        enc, *_ = self.encoder(x.contiguous(), None)
+        logit = _affine_chain(self._cache, enc.reshape(B * T, D).contiguous(), [self.fc[0], self.fc[2]], False, self.precision)
+        return ops.sigmoid(logit).view(B, T, 1)
+
+
 class SoftmaxContrastiveLoss(nn.Module):
     """test_emotion_gesture_diversity_iterative.py:80-127 on the GPU (eg_contrastive_loss: one workgroup per row, fixed-order
     reductions).  forward -> scalar loss tensor (differentiable when an input requires a gradient: eg_contrastive_loss_backward);

@@ -335,6 +335,23 @@ def relu(x):
     return _Act.apply(x, 0.0)
 
 
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = raw_ew(EW_SIGMOID, _chk(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return raw_ew(EW_SIGMOID_BWD, _chk(dy), y)          # dy * y * (1 - y)
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)
+
+
 def leaky_relu(x, slope=0.2):
     return _Act.apply(x, float(slope))
 
@@ -343,8 +360,11 @@ _DROP = {"seed": 0, "offset": 0, "epoch": None}
 
 
 def manual_seed(seed: int) -> None:
-    """Seed of the dropout mask stream (counter-based; every dropout call advances the counter by its element count)."""
+    """Seed of the dropout mask stream (counter-based; every dropout call advances the counter by its element count).  Also rewinds the
+    device-resident epoch (if one is in use) to 0: the same seed then reproduces the same masks."""
     _DROP["seed"], _DROP["offset"] = int(seed) & 0xFFFFFFFF, 0
+    if _DROP.get("epoch") is not None:
+        _DROP["epoch"].zero_()
 
 
 def use_device_dropout_epoch(dev) -> torch.Tensor:
@@ -358,7 +378,12 @@ def use_device_dropout_epoch(dev) -> torch.Tensor:
 
 
 def begin_dropout_step() -> None:
-    """Start of a training step in device-epoch mode (no-op otherwise): offsets restart at 0, the device epoch advances by one."""
+    """Start of a training STEP in device-epoch mode (no-op otherwise): offsets restart at 0, the device epoch advances by one.
+    Called once per optimiser step by the step drivers (train/graph.GraphedStep and SegmentedStep wrap it around the step they capture) --
+    never by a network's forward: the dropout kernels read the epoch from device memory when they EXECUTE, so every forward and backward
+    of one step must see the same value.  Two dropout-active forwards before one backward (a generator and a Motion_Discriminator, or the
+    generator called twice) therefore share the step's epoch and draw distinct masks from growing offsets.  Without a driver (eager use of
+    the device epoch) the offsets simply keep growing, which is equally collision-free."""
     ep = _DROP.get("epoch")
     if ep is not None:
         _DROP["offset"] = 0

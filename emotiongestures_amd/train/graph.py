@@ -35,6 +35,12 @@ class GraphedStep:
         self.inputs, self.opt = inputs, optimizer
         if optimizer is not None:
             optimizer.use_device_step()
+        if stochastic:                              # one mask epoch per STEP (not per forward): every forward / backward of the step reads the same value
+            user_step = step_fn
+
+            def step_fn(i):
+                F.begin_dropout_step()
+                return user_step(i)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):               # warm-up off the capture: lazily sized scratch buffers, kernel attributes, autograd state
@@ -108,6 +114,7 @@ class SegmentedStep:
 
     # ---- the phases -------------------------------------------------------------------------------------------------
     def _phase0(self):
+        F.begin_dropout_step()                                    # device-epoch mode only: one mask epoch per step, advanced here and nowhere else
         self.opt.zero_grad()
         self.gb.begin()
         self.ctx.reset()

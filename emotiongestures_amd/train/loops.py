@@ -3,7 +3,7 @@
 
 What upstream's `train_K_fold` does, and where it lives here:
 
-* `KFold(n_splits)` over the training set (:301, sklearn, no shuffling)                      -> `kfold_indices`
+* `KFold(n_splits=10, shuffle=True)` over the training set (:301, sklearn)                   -> `kfold_indices(n, k, shuffle=True, seed)`
 * per fold a fresh EmotionNet, Adam(lr, betas, weight_decay=1e-5) (:128-132)                -> `FlatAdam` over `flatten_parameters`
 * `SubsetRandomSampler` loaders, batch_size, drop_last (:136-145)                            -> `epoch_batches` (seeded permutation, whole batches)
 * per epoch: class counts over the fold's training samples -> class weights
@@ -40,17 +40,24 @@ EMOTIONS = ("neutral", "happiness", "anger", "sadness", "contempt", "surprise", 
 
 
 # ---- host logic (no GPU needed: tests/test_loops.py) ------------------------------------------------------------------------
-def kfold_indices(n: int, n_splits: int) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
-    """sklearn.model_selection.KFold(n_splits) without shuffling (:301): contiguous validation blocks, the first n % k folds one longer."""
+def kfold_indices(n: int, n_splits: int, shuffle: bool = True, seed: Optional[int] = 0) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+    """sklearn.model_selection.KFold(n_splits, shuffle=shuffle, random_state=seed).split (:301 calls `KFold(n_splits=10, shuffle=True)`).
+    sklearn's algorithm: `indices = arange(n)`, shuffled in place by `RandomState(seed).shuffle` when `shuffle`; fold f's validation set is
+    the f-th contiguous block of that (shuffled) array (the first n % k blocks one longer); both index sets are returned in ascending order
+    (sklearn builds them from a boolean mask).  Upstream passes no random_state, i.e. numpy's global generator: `seed=None` does that.  The
+    dataset is ordered by speaker / recording, so the shuffle decides the fold composition and the per-fold class weights."""
     if n_splits < 2 or n_splits > n:
         raise ValueError(f"kfold_indices: n_splits={n_splits} for {n} samples")
     sizes = np.full(n_splits, n // n_splits, dtype=np.int64)
     sizes[: n % n_splits] += 1
-    idx = np.arange(n)
+    order = np.arange(n)
+    if shuffle:
+        (np.random.RandomState(seed) if seed is not None else np.random.mtrand._rand).shuffle(order)
     start = 0
     for s in sizes:
-        val = idx[start:start + s]
-        yield np.concatenate([idx[:start], idx[start + s:]]), val
+        mask = np.zeros(n, dtype=bool)
+        mask[order[start:start + s]] = True
+        yield np.flatnonzero(~mask), np.flatnonzero(mask)
         start += s
 
 
@@ -92,12 +99,16 @@ def _collate(dataset, idx: np.ndarray, spec_len: Optional[int]):
 
 
 # ---- evaluation (inference kernels) -------------------------------------------------------------------------------------------
-def evaluate(model, dataset, indices: Sequence[int], batch_size: int, device, spec_len: Optional[int] = 128) -> Dict[str, object]:
-    """Accuracy as upstream averages it -- the mean of per-batch compute_acc over whole batches (:181-190, :212-232) -- and the confusion
-    matrix [true, predicted] of test_model (:221).  eval() mode: running-statistics BatchNorm on the inference engine."""
+def evaluate(model, dataset, indices: Sequence[int], batch_size: int, device, spec_len: Optional[int] = 128,
+             train_mode_bn: bool = False) -> Dict[str, object]:
+    """Accuracy as upstream averages it -- the mean of per-batch compute_acc over whole batches (:181-190, :212-232) -- and test_model's
+    confusion matrix, filled as upstream's `confusion_matrix` fills it: `conf[predicted, true] += 1` (:55-59).
+    train_mode_bn=False: eval() mode, running-statistics BatchNorm on the inference engine -- upstream's `test_model` (:213).
+    train_mode_bn=True: upstream's *validation* pass (:177-190) runs under `torch.no_grad()` with the model still in train() mode, so BatchNorm
+    normalises with batch statistics and keeps updating its running buffers, and the checkpoint saved right after (:197) holds those buffers."""
     from ..harness import compute_acc
     was_training = model.training
-    model.eval()
+    model.train() if train_mode_bn else model.eval()
     conf = np.zeros((NUM_CLASSES, NUM_CLASSES), dtype=np.int64)
     accs = []
     idx = np.asarray(indices)
@@ -107,9 +118,8 @@ def evaluate(model, dataset, indices: Sequence[int], batch_size: int, device, sp
             out = model(spec.to(device))
             accs.append(float(compute_acc(label.to(device), out)))
             for t, p in zip(label.tolist(), out.argmax(1).cpu().tolist()):
-                conf[t, p] += 1
-    if was_training:
-        model.train()
+                conf[p, t] += 1
+    model.train() if was_training else model.eval()
     return {"accuracy": float(np.mean(accs)) if accs else float("nan"), "batches": len(accs), "confusion": conf}
 
 
@@ -129,13 +139,17 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
                  betas=(0.5, 0.999), weight_decay: float = 1e-5, gamma: float = 2.0, val_every: int = 100, save_dir: Optional[str] = None,
                  test_dataset=None, seed: int = 0, precision: str = "f32", alpha_mode: str = "by_label", spec_len: Optional[int] = 128,
                  max_iters_per_fold: Optional[int] = None, folds: Optional[Sequence[int]] = None, model_factory: Optional[Callable] = None,
-                 use_graph: bool = False, log: Callable[[str], None] = print) -> List[Dict[str, object]]:
+                 use_graph: bool = False, shuffle_folds: bool = True, keep_models: str = "last", log: Callable[[str], None] = print) -> List[Dict[str, object]]:
     """train_K_fold (train_audio_classifier_K_fold.py:109-200).  Returns one record per fold: losses, validation / test accuracies,
     checkpoint paths.  `precision`: "f32" (gradient-parity arithmetic) or "bf16x3" (split-bf16 MFMA) for the convolutions / Linear products.
     Under torch.distributed (initialised by the caller) the loop is data parallel as described in the module docstring.
     use_graph: replay the iteration (zero_grad, forward, loss, backward, gradient collection and -- on one rank -- Adam) from one captured
     hipGraph per fold instead of issuing its ~600 launches through autograd (a batch of 8 is host-bound otherwise); with several ranks the
-    bucket all-reduces and Adam follow each replay.  Same kernels, same order: the losses equal the eager loop's."""
+    bucket all-reduces and Adam follow each replay.  Same kernels, same order: the losses equal the eager loop's.
+    shuffle_folds / seed: the fold split is sklearn's KFold(n_splits, shuffle=True, random_state=seed) (:301).
+    keep_models: "last" keeps only the final fold's model on the device in its record (`rec["model"]`), "none" none, "all" every fold's;
+    every record carries the fold's final `state_dict` on the CPU (`rec["state_dict"]`).  Validation (:177-190) runs as upstream does, with
+    train()-mode BatchNorm under no_grad; the test pass (:205-255) in eval() mode."""
     import torch.distributed as dist
     from ..model.audio_emotion_classifer import EmotionNet
     from . import functional as F
@@ -152,7 +166,7 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
     history = []
     F.set_precision(precision)
     try:
-        for fold, (train_index, val_index) in enumerate(kfold_indices(n, n_splits), start=1):
+        for fold, (train_index, val_index) in enumerate(kfold_indices(n, n_splits, shuffle=shuffle_folds, seed=seed), start=1):
             if folds is not None and fold not in folds:
                 continue
             model = (model_factory() if model_factory is not None else EmotionNet(precision=precision)).to(device)
@@ -165,80 +179,86 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
                 fp.enable_weight_images()
             opt = FlatAdam(fp, lr=lr, betas=betas, weight_decay=weight_decay)
             gb = GradBuckets(fp).attach() if world > 1 else None
-            rec = {"fold": fold, "loss": [], "val_acc": [], "test_acc": [], "checkpoints": [], "iterations": 0}
-            global_iter = 0
-            done = False
-            graphed, static = None, None            # use_graph: built at the first full batch of the fold
+            try:
+                rec = {"fold": fold, "loss": [], "val_acc": [], "test_acc": [], "checkpoints": [], "iterations": 0}
+                global_iter = 0
+                done = False
+                graphed, static = None, None            # use_graph: built at the first full batch of the fold
 
-            def eager_iteration(spec_d, label_d, alpha_d):
-                opt.zero_grad()
-                if gb is not None:
-                    gb.begin()
-                loss = F.focal_loss(model(spec_d), label_d, alpha_d, gamma, 100.0)          # criterion(output, label) * 100 (:168)
-                loss.backward()
-                if gb is not None:
-                    gb.finish()
-                opt.step(collected=gb is not None)
-                return loss
+                def eager_iteration(spec_d, label_d, alpha_d):
+                    opt.zero_grad()
+                    if gb is not None:
+                        gb.begin()
+                    loss = F.focal_loss(model(spec_d), label_d, alpha_d, gamma, 100.0)          # criterion(output, label) * 100 (:168)
+                    loss.backward()
+                    if gb is not None:
+                        gb.finish()
+                    opt.step(collected=gb is not None)
+                    return loss
 
-            for epoch in range(total_epoch):
-                w = class_weights(all_labels[train_index])                       # :146-150 (recomputed every epoch, as upstream)
-                for idx in epoch_batches(train_index, batch_size, seed * 100003 + fold * 1009 + epoch, rank, world):
-                    spec, label = _collate(train_dataset, idx, spec_len)
-                    alpha = torch.tensor(w if alpha_mode == "positional" else w[label.numpy()], dtype=torch.float32)
-                    model.train()
-                    global_iter += 1
-                    batch = {"spec": spec.to(device), "label": label.to(device), "alpha": alpha.to(device)}
-                    if use_graph and len(idx) == batch_size:
-                        if graphed is None:
-                            from .graph import GraphedStep
-                            static = {k: v.clone() for k, v in batch.items()}
-                            if gb is None:
-                                graphed = GraphedStep(lambda _i: eager_iteration(static["spec"], static["label"], static["alpha"]), static, opt, warmup=1)
-                            else:       # data parallel: the graph holds forward + backward + collection; collectives and Adam follow the replay
-                                gb.deferred = True
+                for epoch in range(total_epoch):
+                    w = class_weights(all_labels[train_index])                       # :146-150 (recomputed every epoch, as upstream)
+                    for idx in epoch_batches(train_index, batch_size, seed * 100003 + fold * 1009 + epoch, rank, world):
+                        spec, label = _collate(train_dataset, idx, spec_len)
+                        alpha = torch.tensor(w if alpha_mode == "positional" else w[label.numpy()], dtype=torch.float32)
+                        model.train()
+                        global_iter += 1
+                        batch = {"spec": spec.to(device), "label": label.to(device), "alpha": alpha.to(device)}
+                        if use_graph and len(idx) == batch_size:
+                            if graphed is None:
+                                from .graph import GraphedStep
+                                static = {k: v.clone() for k, v in batch.items()}
+                                if gb is None:
+                                    graphed = GraphedStep(lambda _i: eager_iteration(static["spec"], static["label"], static["alpha"]), static, opt, warmup=1)
+                                else:       # data parallel: the graph holds forward + backward + collection; collectives and Adam follow the replay
+                                    gb.deferred = True
 
-                                def fwd_bwd(_i):
-                                    opt.zero_grad()
-                                    gb.begin()
-                                    ls = F.focal_loss(model(static["spec"]), static["label"], static["alpha"], gamma, 100.0)
-                                    ls.backward()
-                                    gb.finish()
-                                    return ls
-                                graphed = GraphedStep(fwd_bwd, static, None, warmup=1, device=device)
-                            loss = graphed.warmup_loss          # the capture's one warm-up step WAS this batch's iteration (executed eagerly)
+                                    def fwd_bwd(_i):
+                                        opt.zero_grad()
+                                        gb.begin()
+                                        ls = F.focal_loss(model(static["spec"]), static["label"], static["alpha"], gamma, 100.0)
+                                        ls.backward()
+                                        gb.finish()
+                                        return ls
+                                    graphed = GraphedStep(fwd_bwd, static, None, warmup=1, device=device)
+                                loss = graphed.warmup_loss          # the capture's one warm-up step WAS this batch's iteration (executed eagerly)
+                            else:
+                                loss = graphed.run(batch)
+                            if gb is not None:
+                                gb.reduce_deferred()
+                                opt.step(collected=True)
                         else:
-                            loss = graphed.run(batch)
-                        if gb is not None:
-                            gb.reduce_deferred()
-                            opt.step(collected=True)
-                    else:
-                        if gb is not None:
-                            gb.deferred = False
-                        loss = eager_iteration(batch["spec"], batch["label"], batch["alpha"])
-                    rec["loss"].append(float(loss.detach()))
-                    if global_iter % val_every == 0:                             # :177
-                        va = evaluate(model, train_dataset, val_index, batch_size, device, spec_len)
-                        rec["val_acc"].append((global_iter, va["accuracy"]))
-                        log("Fold {}, Epoch {}, Val Accuracy: {:.2f}%".format(fold, epoch, va["accuracy"]))
-                        if save_dir is not None and rank == 0:
-                            path = checkpoint_name(save_dir, fold, epoch, global_iter)
-                            save_checkpoint(model, path)
-                            rec["checkpoints"].append(path)
-                        if test_dataset is not None:
-                            ta = evaluate(model, test_dataset, range(len(test_dataset)), batch_size, device, spec_len)
-                            rec["test_acc"].append((global_iter, ta["accuracy"]))
-                            rec["confusion"] = ta["confusion"]
-                            log("Fold {}, Epoch {}/{}, Iteraction {}, Test Accuracy: {:.2f}%".format(fold, epoch, total_epoch, global_iter, ta["accuracy"]))
-                    if max_iters_per_fold is not None and global_iter >= max_iters_per_fold:
-                        done = True
+                            if gb is not None:
+                                gb.deferred = False
+                            loss = eager_iteration(batch["spec"], batch["label"], batch["alpha"])
+                        rec["loss"].append(float(loss.detach()))
+                        if global_iter % val_every == 0:                             # :177
+                            va = evaluate(model, train_dataset, val_index, batch_size, device, spec_len, train_mode_bn=True)
+                            rec["val_acc"].append((global_iter, va["accuracy"]))
+                            log("Fold {}, Epoch {}, Val Accuracy: {:.2f}%".format(fold, epoch, va["accuracy"]))
+                            if save_dir is not None and rank == 0:
+                                path = checkpoint_name(save_dir, fold, epoch, global_iter)
+                                save_checkpoint(model, path)
+                                rec["checkpoints"].append(path)
+                            if test_dataset is not None:
+                                ta = evaluate(model, test_dataset, range(len(test_dataset)), batch_size, device, spec_len)
+                                rec["test_acc"].append((global_iter, ta["accuracy"]))
+                                rec["confusion"] = ta["confusion"]
+                                log("Fold {}, Epoch {}/{}, Iteraction {}, Test Accuracy: {:.2f}%".format(fold, epoch, total_epoch, global_iter, ta["accuracy"]))
+                        if max_iters_per_fold is not None and global_iter >= max_iters_per_fold:
+                            done = True
+                            break
+                    if done:
                         break
-                if done:
-                    break
-            rec["iterations"] = global_iter
-            rec["model"] = model
-            history.append(rec)
-            F.unregister_weight_images(fp.images) if fp.images is not None else None
+                rec["iterations"] = global_iter
+                rec["state_dict"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+                if keep_models == "all" or (keep_models == "last" and (folds is None and fold == n_splits or folds is not None and fold == max(folds))):
+                    rec["model"] = model
+                history.append(rec)
+            finally:                            # also on an exception mid-fold: no stale weight images in the registry, no fold's graph / scratch kept alive
+                if fp.images is not None:
+                    F.unregister_weight_images(fp.images)
+                graphed = static = opt = gb = None
     finally:
         F.set_precision("f32")
     return history

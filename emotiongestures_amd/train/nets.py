@@ -30,11 +30,10 @@ def _dp(x, p):
 
 
 def _dropout_on(model) -> None:
-    """Entry of a network's train-mode forward: activate the Dropout placements when the model asks for them, and start a new mask epoch
-    (functional.begin_dropout_step: a no-op unless the device-resident epoch is in use, e.g. under train/graph.GraphedStep)."""
+    """Entry of a network's train-mode forward: activate the Dropout placements when the model asks for them.  The mask epoch is NOT advanced
+    here but once per optimiser step by the step driver (functional.begin_dropout_step): a forward's backward kernels re-read the epoch from
+    device memory when they run, so a second forward before that backward must not move it."""
     _P["on"] = bool(getattr(model, "train_dropout", False))
-    if _P["on"]:
-        F.begin_dropout_step()
 
 
 # Cut sites of a segmented training step (train/graph.SegmentedStep): at a named site the activation is detached and a fresh leaf carries the
@@ -199,6 +198,19 @@ def motion_discriminator_forward(md, x):
     for i in (0, 2, 4, 6, 8):
         h = F.linear(h, md.fc2[i].weight, md.fc2[i].bias, relu=True)
     return F.linear(h, md.fc2[10].weight, md.fc2[10].bias)
+
+
+def pose_discriminator_forward(pd, x):
+    """Pose_Discriminator.forward (Models_spatial_memory.py:698-702) in train() mode: encoder -> Linear -> Dropout(0.2) -> Linear -> sigmoid,
+    one probability per frame [B, T, 1].  x may require a gradient (the generator's adversarial term)."""
+    B, T, D = x.shape
+    _dropout_on(pd)
+    try:
+        enc = encoder_forward(pd.encoder, x)
+        h = _dp(F.linear(enc.reshape(B * T, D), pd.fc[0].weight, pd.fc[0].bias), 0.2)
+    finally:
+        _P["on"] = False
+    return F.sigmoid(F.linear(h, pd.fc[2].weight, pd.fc[2].bias)).reshape(B, T, 1)
 
 
 def decoder_forward(dec, trg, enc_out):

@@ -535,6 +535,13 @@ def motion_discriminator(sd: SD, x: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
     return _lin(sd, "fc2.10", h)
 
 
+def pose_discriminator(sd: SD, x: torch.Tensor, cfg: GenCfg) -> torch.Tensor:
+    """Pose_Discriminator.forward, Full_model/Models_spatial_memory.py:698-702: encoder -> Linear(282, 64) -> (Dropout) -> Linear(64, 1)
+    -> sigmoid; one probability per frame, [B, T, 1]."""
+    h = encoder(sd, "encoder", x, cfg)
+    return torch.sigmoid(_lin(sd, "fc.2", _lin(sd, "fc.0", h)))
+
+
 def softmax_contrastive(face: np.ndarray, audio: np.ndarray):
     """SoftmaxContrastiveLoss.forward / .evaluate, test_emotion_gesture_diversity_iterative.py:80-127, in float64 numpy:
     rows L2-normalised (F.normalize eps 1e-12), cross = clamp(1 / (pairwise L2 + 1e-8), min 1e-8),

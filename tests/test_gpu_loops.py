@@ -67,6 +67,36 @@ def test_k_fold_loop_trains_validates_saves_and_reloads(tmp_path):
     assert hist[0]["loss"] != hist[1]["loss"]
 
 
+def test_evaluate_validation_pass_is_train_mode_batchnorm_and_confusion_is_predicted_by_true():
+    """Upstream validates under no_grad with the model still in train() mode (train_audio_classifier_K_fold.py:177-190): BatchNorm uses batch
+    statistics and keeps updating the running buffers that the checkpoint saved right after holds; `test_model` runs in eval() (:213) and
+    fills `conf_matrix[predicted, true]` (:55-59)."""
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    from emotiongestures_amd.synth import load_synth_weights
+    from emotiongestures_amd.train import loops
+    ds = build_dataset()
+    model = load_synth_weights(EmotionNet(precision="f32"), 7).to(DEV).train()
+    bufs = lambda: torch.cat([b.detach().reshape(-1).float() for n, b in model.named_buffers() if "running" in n]).cpu()
+    before = bufs()
+    idx = np.arange(8)
+    ev = loops.evaluate(model, ds, idx, 4, DEV)                                  # eval mode: running statistics untouched, mode restored
+    assert model.training and torch.equal(bufs(), before)
+    va = loops.evaluate(model, ds, idx, 4, DEV, train_mode_bn=True)             # upstream's validation pass
+    assert model.training and not torch.equal(bufs(), before)
+    assert all(p.grad is None for p in model.parameters())                       # no_grad: nothing recorded
+    assert ev["batches"] == va["batches"] == 2
+    # orientation: rows = predicted class, columns = true label
+    labels = loops.labels_of(ds, idx)
+    model.eval()
+    with torch.no_grad():
+        pred = torch.cat([model(loops._collate(ds, idx[b * 4:(b + 1) * 4], 128)[0].to(DEV)).argmax(1).cpu() for b in range(2)]).numpy()
+    want = np.zeros((8, 8), dtype=np.int64)
+    for p_, t_ in zip(pred, labels):
+        want[p_, t_] += 1
+    np.testing.assert_array_equal(ev["confusion"], want)
+    np.testing.assert_array_equal(ev["confusion"].sum(axis=0), np.bincount(labels, minlength=8))     # column sums = per-class sample counts
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_k_fold_loop_replayed_from_a_graph_equals_the_eager_loop(precision):
     """use_graph=True: the iteration replayed from one captured hipGraph per fold (the capture's warm-up step is the fold's first iteration, so no

@@ -787,6 +787,54 @@ def test_dropout_inside_a_captured_graph_needs_and_uses_the_device_epoch():
         F.manual_seed(0)
 
 
+def test_two_dropout_forwards_before_one_backward_share_the_steps_mask_epoch():
+    """The dropout kernels read the mask epoch from device memory when they execute.  The epoch therefore advances once per STEP (the step
+    driver), not per forward: with two dropout-active forwards before the backward (a generator plus a Motion_Discriminator, or the
+    generator called twice) the first forward's backward must still rebuild the mask its forward applied, and the two forwards must draw
+    different masks.  manual_seed rewinds the device epoch, so a seed reproduces its masks."""
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.graph import GraphedStep
+    from emotiongestures_amd.train import nets
+
+    class M:            # the forward entry of a network with its Dropout placements on
+        train_dropout = True
+    x = torch.ones(1 << 16, device=DEV)
+    out = {}
+    try:
+        F.manual_seed(9)
+
+        def step(_i):
+            a = x.detach().requires_grad_(True)
+            b = x.detach().requires_grad_(True)
+            nets._dropout_on(M)                         # first forward
+            ya = F.dropout(a, 0.3)
+            nets._dropout_on(M)                         # second forward before any backward
+            yb = F.dropout(b, 0.3)
+            (ya.sum() + yb.sum()).backward()
+            out.update(ya=ya.detach(), yb=yb.detach(), da=a.grad, db=b.grad)
+            return ya.detach().sum()
+        gs = GraphedStep(step, {}, None, warmup=1, device=DEV, stochastic=True)
+        seen = []
+        for _ in range(3):
+            gs.run()
+            torch.cuda.synchronize()
+            assert torch.equal(out["ya"], out["da"]) and torch.equal(out["yb"], out["db"])     # dy = 1: dx is the forward's own scaled mask
+            assert not torch.equal(out["ya"], out["yb"])                                       # distinct offsets within the step
+            seen.append(out["ya"].clone())
+        assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])         # fresh masks per replay
+        assert int(F._DROP["epoch"]) == 1 + 3
+        F.manual_seed(9)
+        assert int(F._DROP["epoch"]) == 0                                                       # the seed rewinds the device epoch too
+        gs.run(); torch.cuda.synchronize()
+        first_after_reseed = out["ya"].clone()
+        F.manual_seed(9)
+        gs.run(); torch.cuda.synchronize()
+        assert torch.equal(out["ya"], first_after_reseed)
+    finally:
+        F._DROP["epoch"] = None
+        F.manual_seed(0)
+
+
 def test_graphed_step_keeps_its_scratch_buffers_alive():
     """The captured kernels hold raw pointers into functional._WS; a later, larger eager request replaces the registry entry.  The graph
     keeps the buffers it was captured with, so a replay after that still writes into memory it owns (same result as before)."""

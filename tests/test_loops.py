@@ -1,5 +1,5 @@
 """Host logic of the EmotionNet K-fold loop (emotiongestures_amd/train/loops.py; train_audio_classifier_K_fold.py:109-200): the fold split
-against sklearn's KFold (what upstream calls), class weights, the seeded / sharded batch schedule, checkpoint naming.  No GPU."""
+against sklearn's KFold(shuffle=True) (what upstream calls, :301), class weights, the seeded / sharded batch schedule, checkpoint naming.  No GPU."""
 import numpy as np
 import pytest
 
@@ -7,16 +7,40 @@ from emotiongestures_amd.train import loops
 
 
 @pytest.mark.parametrize("n,k", [(10, 10), (23, 10), (100, 7), (5, 2)])
-def test_kfold_indices_match_sklearn(n, k):
+@pytest.mark.parametrize("seed", [0, 1234])
+def test_kfold_indices_match_sklearn_shuffled(n, k, seed):
+    """Upstream: `KFold(n_splits=10, shuffle=True)` (train_audio_classifier_K_fold.py:301)."""
     from sklearn.model_selection import KFold
-    ours = list(loops.kfold_indices(n, k))
-    ref = list(KFold(n_splits=k).split(np.zeros(n)))
+    ours = list(loops.kfold_indices(n, k, shuffle=True, seed=seed))
+    ref = list(KFold(n_splits=k, shuffle=True, random_state=seed).split(np.zeros(n)))
     assert len(ours) == len(ref) == k
     for (tr, va), (rtr, rva) in zip(ours, ref):
         np.testing.assert_array_equal(tr, rtr)
         np.testing.assert_array_equal(va, rva)
+    # every sample is validated exactly once, and with n > k the folds are not the contiguous blocks of an unshuffled split
+    assert sorted(np.concatenate([va for _, va in ours]).tolist()) == list(range(n))
+    if n > 20:
+        assert any(np.any(np.diff(va) != 1) for _, va in ours)
     with pytest.raises(ValueError):
         list(loops.kfold_indices(3, 4))
+
+
+def test_kfold_indices_unseeded_draws_from_numpys_global_generator_like_sklearn():
+    from sklearn.model_selection import KFold
+    np.random.seed(77)
+    ref = list(KFold(n_splits=5, shuffle=True).split(np.zeros(31)))          # random_state=None -> np.random's global RandomState
+    np.random.seed(77)
+    ours = list(loops.kfold_indices(31, 5, shuffle=True, seed=None))
+    for (tr, va), (rtr, rva) in zip(ours, ref):
+        np.testing.assert_array_equal(tr, rtr)
+        np.testing.assert_array_equal(va, rva)
+
+
+def test_kfold_indices_unshuffled_option_matches_sklearn_default():
+    from sklearn.model_selection import KFold
+    for (tr, va), (rtr, rva) in zip(loops.kfold_indices(23, 10, shuffle=False), KFold(n_splits=10).split(np.zeros(23))):
+        np.testing.assert_array_equal(tr, rtr)
+        np.testing.assert_array_equal(va, rva)
 
 
 def test_class_weights_follow_upstream_formula():

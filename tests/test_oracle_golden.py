@@ -120,6 +120,39 @@ def test_mel_oracle_properties():
     assert np.all(silent == 0.0)          # all-amin input: db == ref everywhere
 
 
+def test_mel_oracle_stft_cross_checked_against_torch_stft():
+    """librosa is absent (mel parity is unpinned upstream-side), but the STFT half of the restatement can be pinned by an independent
+    implementation in the image: torch.stft(center=True, pad_mode="constant", periodic Hann 1024, hop 512, onesided) is librosa.stft's
+    documented default configuration.  It checks framing, padding, window and frame count independently of the oracle's np.fft indexing;
+    the rest of the chain (Slaney basis, power_to_db(ref=max, top_db=80), fp16) is applied to both spectra and must agree on the fp16 grid."""
+    from emotiongestures_amd.synth import synth_audio
+    a = synth_audio(2, 64000, seed=3)
+    a[1, :5000] = 0.0                                        # a silent head: the zero padding of the first centred frames must not matter
+    spec = torch.stft(torch.from_numpy(a).double(), n_fft=1024, hop_length=512, win_length=1024,
+                      window=torch.hann_window(1024, periodic=True, dtype=torch.float64), center=True, pad_mode="constant",
+                      normalized=False, onesided=True, return_complex=True)                  # [B, 513, frames]
+    assert spec.shape == (2, 513, 1 + 64000 // 512)
+    power_t = (spec.abs() ** 2).numpy().transpose(0, 2, 1)                                   # [B, frames, 513]
+    # the oracle's own framing, recomputed here the way melspectrogram() does it
+    x = np.pad(a.astype(np.float64), ((0, 0), (512, 512)))
+    idx = np.arange(1024)[None, :] + 512 * np.arange(126)[:, None]
+    power_o = np.abs(np.fft.rfft(x[:, idx] * O.hann_periodic(1024).astype(np.float64), axis=-1)) ** 2
+    # the oracle keeps the window in fp32 (as scipy's get_window result is cast by librosa): 1e-7 relative
+    np.testing.assert_allclose(power_o, power_t, rtol=2e-6, atol=1e-9 * power_t.max())
+    fb = O.mel_filterbank().astype(np.float64)
+
+    def to_db(power):
+        mel = np.einsum("mk,bfk->bmf", fb, power)
+        db = 10.0 * np.log10(np.maximum(1e-10, mel))
+        db -= 10.0 * np.log10(np.maximum(1e-10, mel.reshape(2, -1).max(axis=1)))[:, None, None]
+        return np.maximum(db, db.reshape(2, -1).max(axis=1)[:, None, None] - 80.0).astype(np.float16).astype(np.float32)
+    ours = O.melspectrogram(a)
+    via_torch = to_db(power_t)
+    assert ours.shape == via_torch.shape == (2, 128, 126)
+    diff = np.abs(ours - via_torch)
+    assert diff.max() <= 0.0625 and (diff > 0).mean() < 1e-3          # at most one fp16 step (dB in [-80, 0]: ulp <= 1/16) on a handful of bins
+
+
 def test_beat_long_oracle_matches_reference_golden():
     """BASELINE configs[3] (120 frames, 128x312 spectrogram, 120-channel CVAE): the oracle against the reference's classes with
     their hard-coded sizes replaced after construction (tests/golden/make_golden_beat_long.py)."""
