@@ -78,12 +78,6 @@ SIGNATURES = {
     "eg_conv3x3_se": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_se_gate_pre": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eg_conv3x3_gap_tiles": (_I, [_I, _I, _I, _I, _I]),
-    "eg_conv3x3_c32_planar_gap_tiles": (_I, [_I, _I]),
-    "eg_stem_conv_planar": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "eg_conv3x3_c32_planar": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "eg_se_gate_pre_planar": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "eg_planar32_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _P]),
-    "eg_nhwc_to_planar32": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "eg_stem_conv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eg_se_gate": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "eg_se_residual_relu": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

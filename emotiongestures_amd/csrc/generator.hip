@@ -431,38 +431,11 @@ int run_audio_tower(const EgGenerator* g, const float* arena, const float* spec,
     float* bufs[3] = {P(ws, w.act[0]), P(ws, w.act[1]), P(ws, w.act[2])};
     float *gap = P(ws, w.gap), *gate = P(ws, w.gate);
     int xi = 0, h = g->H1, wd = g->W1, bi = 0;
-    // First stage on producer-split activations (conv_planar.hip): the stem and the 32-channel identity blocks exchange bf16 (hi, lo) planes,
-    // the convolutions stage their halos by LDS-DMA with no split pass; the stage's last tail writes fp32 NHWC again for layer2.
-    // Measured SLOWER than the fp32-NHWC persistent kernel on the same box (93.5 vs 87.3 us per convolution at 64 clips, step 2.58 vs
-    // 2.53 ms; profiles/r03l_planar_stage1.md), so it is opt-in (EG_CONV32_PLANAR=1) and kept for its unit test and as the starting
-    // point of a later attempt; keep_taps (fp32 taps of the intermediate maps) and the f32 mode always use the fp32 kernels.
-    static const bool planar_on = [] { const char* e = getenv("EG_CONV32_PLANAR"); return e && e[0] == '1'; }();
-    bool planar = planar_on && prec != EG_PREC_F32 && g->fuse_se && !g->keep_taps && g->stages[0] > 0;
-    for (int j = 0; planar && j < g->stages[0]; ++j) planar = !g->blocks[j].ds && g->blocks[j].cin == 32 && g->blocks[j].cout == 32;
-    int first_stage = 0;
-    if (planar) {
-        EG_TRY(eg_stem_conv_planar(spec, arena + g->stem_w, arena + g->stem_b, arena + g->stem_scale, arena + g->stem_shift, bufs[0], B, h, wd, st));
-        const int tiles1 = eg_conv3x3_c32_planar_gap_tiles(h, wd);
-        for (int j = 0; j < g->stages[0]; ++j, ++bi) {
-            const BlockW& bw = g->blocks[bi];
-            const int t1 = (xi + 1) % 3, t2 = (xi + 2) % 3;
-            const bool last = j + 1 == g->stages[0];
-            EG_TRY(eg_conv3x3_c32_planar(bufs[xi], arena + bw.c1.w, nullptr, arena + bw.c1.scale, arena + bw.c1.shift, nullptr, nullptr, bufs[t1], nullptr,
-                                         gap, B, h, wd, 1, prec, st));
-            EG_TRY(eg_se_gate_pre_planar(bufs[t1], gap, tiles1, arena + bw.c2.w, arena + bw.c2.scale, arena + bw.c2.shift, arena + bw.se_w1,
-                                         arena + bw.se_b1, arena + bw.se_w2, arena + bw.se_b2, gate, B, h, wd, st));
-            EG_TRY(eg_conv3x3_c32_planar(bufs[t1], arena + bw.c2.w, nullptr, arena + bw.c2.scale, arena + bw.c2.shift, gate, bufs[xi], last ? nullptr : bufs[t2],
-                                         last ? bufs[t2] : nullptr, nullptr, B, h, wd, 0, prec, st));
-            xi = t2;
-        }
-        first_stage = 1;
-    } else {
-        EG_TRY(eg_stem_conv(spec, arena + g->stem_w, arena + g->stem_b, arena + g->stem_scale, arena + g->stem_shift, bufs[0], B, g->H1,
-                            g->W1, 32, st));
-        if (g->keep_taps)
-            EG_HIP_TRY(hipMemcpyAsync(P(ws, w.tap_stem), bufs[0], sizeof(float) * (size_t)B * g->H1 * g->W1 * 32, hipMemcpyDeviceToDevice, st), "tap copy");
-    }
-    for (int s = first_stage; s < 3; ++s) {
+    EG_TRY(eg_stem_conv(spec, arena + g->stem_w, arena + g->stem_b, arena + g->stem_scale, arena + g->stem_shift, bufs[0], B, g->H1,
+                        g->W1, 32, st));
+    if (g->keep_taps)
+        EG_HIP_TRY(hipMemcpyAsync(P(ws, w.tap_stem), bufs[0], sizeof(float) * (size_t)B * g->H1 * g->W1 * 32, hipMemcpyDeviceToDevice, st), "tap copy");
+    for (int s = 0; s < 3; ++s) {
         for (int j = 0; j < g->stages[s]; ++j, ++bi) {
             const BlockW& bw = g->blocks[bi];
             const int t1 = (xi + 1) % 3, t2 = (xi + 2) % 3;

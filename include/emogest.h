@@ -246,26 +246,6 @@ int eg_conv3x3_se(const float* x, const float* w_packed, const float* bias, cons
  * BatchNorm that follows takes mean and variance from them (eg_bn_train_forward_sq) without reading y again. */
 int eg_conv3x3_sq(const float* x, const float* w_packed, const float* bias, float* y, float* gap_partial, float* gap_sq_partial, int32_t batch,
                   int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride, int32_t relu, int32_t precision, void* stream);
-/* First tower stage on producer-split activations ("P32": per clip two bf16 images, hi then lo, each [4 channel octets][h*w pixels][8 bf16]; the same
- * bytes as fp32 NHWC at 32 channels).  The producer's epilogue splits once; the 32 -> 32 convolution stages halo tiles by LDS-DMA without a split
- * pass (ResNetSE34V2.py:64-67, ResNetBlocks.py:21-37 at 32 channels).  Split-bf16 / bf16 arithmetic only (precision 1 or 2).
- *   eg_stem_conv_planar:     eg_stem_conv (C = 32) writing P32.
- *   eg_conv3x3_c32_planar:   y = epilogue(conv3x3(x)) with eg_conv3x3_se's epilogue (bias, ReLU, BN affine, optional gate + residual + ReLU, the
- *                            residual read from the block input's P32 planes as hi + lo), output either P32 (y_planes) or fp32 NHWC (y_nhwc):
- *                            exactly one of the two; gap_partial as eg_conv3x3 with eg_conv3x3_c32_planar_gap_tiles(h, wdt) tiles per clip.
- *   eg_se_gate_pre_planar:   eg_se_gate_pre with conv1's output held as P32.
- *   eg_planar32_to_nhwc / eg_nhwc_to_planar32: layout conversion (tests, taps). */
-int32_t eg_conv3x3_c32_planar_gap_tiles(int32_t h, int32_t wdt);
-int eg_stem_conv_planar(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift, void* y_planes, int32_t batch,
-                        int32_t h, int32_t wdt, void* stream);
-int eg_conv3x3_c32_planar(const void* x_planes, const float* w_packed, const float* bias, const float* scale, const float* shift, const float* gate,
-                          const void* residual_planes, void* y_planes, float* y_nhwc, float* gap_partial, int32_t batch, int32_t h, int32_t wdt,
-                          int32_t relu, int32_t precision, void* stream);
-int eg_se_gate_pre_planar(const void* t1_planes, const float* gap_partial, int32_t tiles, const float* conv2_w, const float* scale2, const float* shift2,
-                          const float* w1, const float* b1, const float* w2, const float* b2, float* gate, int32_t batch, int32_t h, int32_t wdt,
-                          void* stream);
-int eg_planar32_to_nhwc(const void* planes, float* y, int32_t batch, int32_t h, int32_t wdt, void* stream);
-int eg_nhwc_to_planar32(const float* x, void* planes, int32_t batch, int32_t h, int32_t wdt, void* stream);
 /* SELayer gate of a block computed BEFORE its conv2 runs: the spatial mean of BN2(conv2(t1)) is linear in window sums of t1
  * (total from conv1's gap partials, border lines / corners read from t1), so gate = sigmoid(W2 relu(W1 mean + b1) + b2) needs
  * only t1 and conv2's fp32 weight image (the head of its EG_PACK_CONV3X3 entry).  t1 NHWC [B,H,W,C], conv2: C -> C, stride 1. */
