@@ -123,8 +123,20 @@ def measured_traffic(tag, precision):
         return None
     hits = [v for k, v in kern.items() if k.startswith(prefix)]
     if not hits and tag >= 1000 and tag // 1000000 == 32 and (tag // 1000) % 1000 == 32:      # the 32 -> 32 stage runs on the persistent kernel
-        hits = [v for k, v in kern.items() if k.startswith("conv3x3_c32_persistent_kernel<3>")]
+        hits = [v for k, v in kern.items() if k.startswith("conv3x3_c32_persistent_kernel<3")]       # <TERMS, TH, STAMP>: any tile height, production build
     return hits[0]["bytes"] if hits else None
+
+
+def train_hbm_gb_per_step(batch):
+    """Memory-side GB moved by one training step at `batch` clips, from the newest committed PMC summary profiles/*_train_traffic_b{batch}.json
+    (tools/train_traffic_json.py over `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of `bench.py --train --train-batch {batch}`); None when
+    no such profile is committed.  A lookup: counters cannot be read inside the timed process."""
+    pdir = os.path.join(ROOT, "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith(f"_train_traffic_b{batch}.json")) if os.path.isdir(pdir) else []
+    if not cands:
+        return None
+    d = json.load(open(os.path.join(pdir, cands[-1])))
+    return {"gb_per_step": d["gb_per_step"], "source": "profiles/" + cands[-1]}
 
 
 def parse_args():
@@ -227,13 +239,129 @@ def dry_worker(args, rank, world):
     return 0
 
 
+# ---- informational legs of the default line: the other BASELINE.json configurations on one GPU -------------------------------------------
+def gpu_b1_latency(gen, vae, mel, inp, sd_g, sd_v, dev, reps=50):
+    """BASELINE configs[0] on the GPU: ONE clip (4 s of audio -> mel -> CVAE sample -> generator -> pose), one lane, the step replayed from its
+    hipGraph and synchronised every time; median of `reps` wall-clock latencies, pose checked against the CPU oracle for that clip."""
+    from emotiongestures_amd.builders import clip_rel_l2
+    from emotiongestures_amd.pipeline import ClipPipeline
+    from oracle import emogest_oracle as O
+    g1 = {k: torch.from_numpy(v[:1]).to(dev) for k, v in inp.items()}
+    pipe = ClipPipeline((gen, vae, mel), g1, dev, lanes=1)
+    for _ in range(5):
+        pipe.wait(pipe.launch_next())
+    lat = []
+    for _ in range(reps):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pipe.wait(pipe.launch_next())
+        lat.append((time.perf_counter() - t0) * 1e3)
+    pose = pipe.outputs(0)[0].cpu().numpy()
+    with torch.no_grad():
+        t1 = {k: torch.from_numpy(v[:1]) for k, v in inp.items() if k != "audio"}
+        spec = torch.from_numpy(O.melspectrogram(inp["audio"][:1], out_frames=124))
+        ref = O.generator_forward(sd_g, O.GenCfg(), spec, t1["text"], t1["pre_pose"], O.cvae_sample(sd_v, t1["label"], t1["z"]))[0]
+    return {"latency_ms_median": round(float(np.median(lat)), 4), "latency_ms_min": round(float(np.min(lat)), 4), "reps": reps,
+            "clips_per_step": 1, "launch": "hipGraph replay, 1 lane, synchronised per clip",
+            "pose_rel_l2_vs_cpu_oracle": clip_rel_l2(pose, ref.numpy())}
+
+
+def beat_long_leg(precision, dev, steps, B=16, lanes=4):
+    """BASELINE configs[3] on one GPU: BEAT-dataset-shaped long clips -- 10 s of 16 kHz audio -> mel [128, 312] -> CVAE sample (120 channels) ->
+    generator (120 frames x 282, 10 prior frames), B clips per step, `lanes` steps in flight; pose of every clip against the CPU oracle."""
+    from emotiongestures_amd.builders import clip_rel_l2, make_args, make_lang
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.engine import MelFrontEnd
+    from emotiongestures_amd.Full_model.Models_spatial_memory import Transformer
+    from emotiongestures_amd.pipeline import ClipPipeline
+    from emotiongestures_amd.synth import load_synth_weights, synth_audio, synth_inputs
+    from oracle import emogest_oracle as O
+    Fr, D, P, T = 120, 282, 10, 312
+    model = Transformer(make_args(10), make_lang(200), frames=Fr, pose_dim=D, prior_frames=P, d_word_vec=512, d_model=512, d_inner=2048,
+                        n_layers=3, n_head=8, d_k=64, d_v=64, n_position=Fr, spec_len=T, precision=precision)
+    load_synth_weights(model, 21).eval()
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=Fr), 21).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sdv = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    model.to(dev); vae.to(dev)
+    inp = synth_inputs(B, Fr, D, P, spec_len=T, seed=21)
+    inp["audio"] = synth_audio(B, 160000, seed=21)
+    g = {k: torch.from_numpy(inp[k]).to(dev) for k in ("audio", "text", "pre_pose", "label", "z")}
+    pipe = ClipPipeline((model, vae, MelFrontEnd(dev)), g, dev, lanes=lanes)
+    for _ in range(2 * lanes):
+        pipe.launch_next()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.launch_next()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    pose = pipe.outputs(0)[0].cpu().numpy()
+    n_chk = 4                                   # oracle cost: ~0.1 s per long clip on the host
+    with torch.no_grad():
+        t = {k: torch.from_numpy(inp[k][:n_chk]) for k in ("text", "pre_pose", "label", "z")}
+        spec = torch.from_numpy(O.melspectrogram(inp["audio"][:n_chk], out_frames=T))
+        ref = O.generator_forward(sd, O.GenCfg(frames=Fr, pose_dim=D, prior_frames=P, chunk=10), spec, t["text"], t["pre_pose"],
+                                  O.cvae_sample(sdv, t["label"], t["z"]))[0]
+    return {"value": round(B * steps / el, 2), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 4), "dtype": precision,
+            "config": f"BEAT-long: 10 s audio -> mel(128x{T}) -> CVAE({Fr} ch) -> generator -> {Fr}x{D} pose; {B} clips per step, {lanes} steps in flight",
+            "audio_seconds_per_second": round(B * steps / el * 10.0, 1),
+            "pose_rel_l2_vs_cpu_oracle": clip_rel_l2(pose[:n_chk], ref.numpy()), "parity_clips_checked": n_chk}
+
+
+def diversity_leg(precision, dev, steps, B=64, R=32):
+    """BASELINE configs[4] on one GPU, in the headline's arithmetic (bf16x3; fp8 is reported separately when built): 32 CVAE latent draws per clip,
+    audio tower once per clip, fusion -> encoder -> decoder -> post_projector per draw (M = B*R*34 rows).  A subset of (clip, draw) pairs against
+    the CPU oracle."""
+    from emotiongestures_amd.builders import build_mirror, clip_rel_l2
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.synth import hash_unit, load_synth_weights, synth_inputs
+    from oracle import emogest_oracle as O
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=9, precision=precision)
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 9).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sdv = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    model.to(dev); vae.to(dev)
+    inp = synth_inputs(B, seed=9)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    z = (hash_unit("bench.draws.z", B * R * 32, 9).reshape(B, R, 32) * 2 - 1).astype(np.float32) * 1.7
+    lab = g["label"][:, None, :].expand(B, R, 8).reshape(B * R, 8).contiguous()
+    zd = torch.from_numpy(z).reshape(B * R, 32).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model.forward_draws(g["spec"], g["pre_pose"], vae.sample(lab, z=zd).view(B, R, 34, 512))
+    for _ in range(2):
+        poses = step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        poses = step()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    clips, draws = [0, 31, 63], [0, 15, 31]
+    err = 0.0
+    t = {k: torch.from_numpy(v[clips]) for k, v in inp.items()}
+    for r in draws:
+        with torch.no_grad():
+            ref = O.generator_forward(sd, O.GenCfg(), t["spec"], t["text"], t["pre_pose"], O.cvae_sample(sdv, t["label"], torch.from_numpy(z[clips, r])))[0]
+        err = max(err, clip_rel_l2(poses[clips, r].cpu().numpy(), ref.numpy()))
+    return {"value": round(B * R * steps / el, 1), "unit": "pose sequences/s", "clips_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+            "dtype": precision, "config": f"{B} clips x {R} CVAE draws per step (audio tower once per clip, transformer per draw), eager launch, 1 step in flight",
+            "pose_rel_l2_vs_cpu_oracle": err, "parity_pairs_checked": len(clips) * len(draws)}
+
+
 TRAIN_FLOP_PER_CLIP = 3.0 * FLOP_PER_CLIP      # forward + input gradients + weight gradients of the generator (DESIGN.md §7); CVAE and losses not counted
 
 
-def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=None, backend="nccl", segments=0):
+def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=None, backend="nccl", segments=0, dropout=False):
     """One timed configuration of the training step (generator + emotion CVAE: forward + 100*smooth_l1 + CE + backward + bucketed gradient
     all-reduce + fused Adam on B clips per GPU).  precision: arithmetic of the convolutions / Linear products ("f32" = the gradient-parity
-    configuration); graph: replay the step from captured hipGraph(s) instead of issuing every kernel through autograd."""
+    configuration); graph: replay the step from captured hipGraph(s) instead of issuing every kernel through autograd.
+    dropout=True: the graph the REFERENCE trains -- every nn.Dropout of its train() mode active (encoder input, MHA / FFN outputs, the 0.2 layers
+    of the projection MLPs and of the CVAE, the attention probabilities; SubLayers.py:54,79, Modules.py:21) on the library's counter-based mask
+    stream (`train_dropout`; under a graph the mask epoch lives on the device: GraphedStep / SegmentedStep(stochastic=True)).  dropout=False is the
+    gradient-parity configuration (p = 0)."""
     from emotiongestures_amd import _lib
     from emotiongestures_amd.builders import build_mirror
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
@@ -254,8 +382,26 @@ def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=Non
         torch.cuda.synchronize(dev)
 
     F.set_precision(precision)
+    try:
+        return _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier)
+    finally:                    # also when a leg raises: the process-wide precision / image registry / mask epoch never leak into the next leg
+        F.set_precision("f32")
+        F.register_weight_images(None)
+        F._DROP["epoch"] = None
+        F.manual_seed(0)
+        torch.cuda.empty_cache()
+
+
+def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier):
+    from emotiongestures_amd.builders import build_mirror
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.synth import load_synth_weights
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
     model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
     vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
+    model.train_dropout = vae.train_dropout = bool(dropout)
+    F.manual_seed(1234 + rank)
     both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
     fp = flatten_parameters(both)
     fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
@@ -302,14 +448,14 @@ def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=Non
     if graph:
         from emotiongestures_amd.train.graph import GraphedStep, SegmentedStep
         if world == 1:
-            gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, warmup))
+            gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, warmup), stochastic=bool(dropout))
             run = gs.run
             mode = "one captured hipGraph per step"
         else:
             # data parallel: the step is cut into per-bucket graph segments (forward + the backward up to bucket 0 complete, then one segment per
             # further bucket); bucket k's all-reduce runs on the side stream while segment k+1 replays, Adam follows the last reduction
             gb.payload = os.environ.get("EG_GRAD_PAYLOAD", "f32")          # "bf16": buckets travel as bfloat16 (half the xGMI bytes)
-            ss = SegmentedStep(forward_loss, gb, opt, device=dev, warmup=max(1, warmup))
+            ss = SegmentedStep(forward_loss, gb, opt, device=dev, warmup=max(1, warmup), stochastic=bool(dropout))
             run = lambda: ss.run(exposed=ar_ms)
             mode = f"{ss.n_segments} hipGraph segments per step, bucket all-reduces between them on a side stream ({gb.payload} payload)"
 
@@ -330,14 +476,12 @@ def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=Non
     value = B * world * steps / el
     tf = value * TRAIN_FLOP_PER_CLIP / 1e12 / world
     out = {"value": round(value, 2), "ms_per_step": round(el / steps * 1e3, 3), "dtype": precision, "clips_per_gpu_per_step": B,
+           "dropout": "reference placements active (train_dropout)" if dropout else "p = 0 (gradient-parity configuration)",
            "launch": mode, "library_launches_per_step": launches, "first_loss": first_loss, "final_loss": float(loss.detach()),
            "algorithmic_tflops_per_gpu": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_TFLOPS["bf16x3" if precision != "f32" else "f32"], 4),
            "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
            "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
-    F.set_precision("f32")
-    F.register_weight_images(None)
     del model, vae, both, fp, opt, gb
-    torch.cuda.empty_cache()
     return out
 
 
@@ -557,6 +701,16 @@ def main():
             extra["fold_affine"] = leg(args.precision, True, B, lanes)          # same arithmetic mode, fewer products than the reference graph
         if B == 64:
             extra["b256"] = leg(args.precision, False, 256, 2)                  # informational: the same path at 4x the batch (NOT the headline config)
+        if rank == 0 and world == 1:
+            for name, fn in (("gpu_b1", lambda: gpu_b1_latency(gen, vae, mel, inp, sd_g, sd_v, dev)),
+                             ("beat_long", lambda: beat_long_leg(args.precision, dev, args.steps)),
+                             ("diversity_32", lambda: diversity_leg(args.precision, dev, max(4, args.steps // 4)))):
+                try:
+                    extra[name] = fn()
+                except Exception as e:          # informational legs: reported, never fatal to the headline
+                    print(f"bench.py: extra leg {name} FAILED: {e!r}", file=sys.stderr)
+                    extra[name] = {"error": repr(e)[:400]}
+                torch.cuda.empty_cache()
 
     # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
     if rank == 0 and not args.no_roofline:
@@ -620,11 +774,16 @@ def main():
         train = {}
         for tb in (16, 128):
             try:
-                rec = train_leg(dev, tb, "bf16x3", True, max(5, args.steps // 2), 3)
+                # headline of the leg: the graph the reference trains (every Dropout active); `parity_p0` = the same step with p = 0 (the
+                # configuration the gradient tests pin against the reference's autograd); `f32_eager` = fp32 operators issued through autograd
+                rec = train_leg(dev, tb, "bf16x3", True, max(5, args.steps // 2), 3, dropout=True)
+                p0 = train_leg(dev, tb, "bf16x3", True, max(5, args.steps // 2), 3, dropout=False)
                 par = train_leg(dev, tb, "f32", False, 3, 1)
                 for k in ("trainable_parameters", "buckets", "allreduce_exposed_ms_per_step"):
                     rec.pop(k, None)
+                rec["parity_p0"] = {k: p0[k] for k in ("value", "ms_per_step", "first_loss", "final_loss", "library_launches_per_step", "frac_of_mfma_peak")}
                 rec["f32_eager"] = {k: par[k] for k in ("value", "ms_per_step", "first_loss", "library_launches_per_step", "frac_of_mfma_peak")}
+                rec["hbm"] = train_hbm_gb_per_step(tb)
                 train[f"b{tb}"] = rec
             except Exception as e:      # a failed leg must not take the (already measured) headline with it: it is reported in the line, loudly
                 print(f"bench.py: training leg at {tb} clips FAILED: {e!r}", file=sys.stderr)

@@ -9,6 +9,7 @@
 // ds_read_b128 of 16 consecutive rows is bank-conflict free.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -432,42 +433,56 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 // ahead, fragments of step s+1 read from LDS while the MFMAs of step s run (register double buffer), one counted vmcnt and
 // one raw barrier per 32-deep step.
 
-// BK = K elements per barrier interval, RING = LDS slots; shipped as <32, 4> (see the launcher for the variants that lost).
-template <int TERMS, int BK, int RING>
-__global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
+// BK = K elements per barrier interval, RING = LDS slots, WM = MFMA tiles of a wave along M: 2 -> 64 (M) x 64 (N) workgroup tile,
+// 4 -> 128 x 64 (two 64-row X image tiles; the wave grid stays 2 x 2, a wave owns 64 x 32).  The 64 x 64 tile streams 16 KB of operands
+// from L2 into LDS per 48 MFMAs; the 128 x 64 tile 24 KB per 96 (3/4 of the operand stream per MFMA, 6 instead of 4 LDS-DMA pieces and
+// 12 instead of 8 ds_read_b128 per wave for twice the MFMAs), at half the workgroups.
+template <int TERMS, int BK, int RING, int WM = 2>
+__global__ __launch_bounds__(256, (WM == 2 || RING <= 3) ? 2 : 1) void gemm_presplit_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr int KG = BK / 32;                                           // MFMA k-groups per step
-    constexpr int OP = NIMG * KG * 4 * 64, SLOT = 2 * OP;                 // bf8 slots: [X hi|lo][W hi|lo], KG*4 octets x 64 rows each
-    constexpr int G = 2 * NIMG * KG;                                      // LDS-DMA instructions per wave per step
+    constexpr int TM = WM / 2;                                            // 64-row X image tiles per workgroup
+    constexpr int IMG = KG * 256;                                         // bf8 slots of one (tile, image): KG*4 octets x 64 rows
+    constexpr int XO = TM * NIMG * IMG, SLOT = XO + NIMG * IMG;           // slot: X [tile][hi|lo] then W [hi|lo]
+    constexpr int G = (TM + 1) * NIMG * KG;                               // LDS-DMA instructions per wave per step
+    static_assert(WM == 2 || (WM == 4 && BK == 32), "wave tile: 32 x 32 or 64 x 32");
     extern __shared__ __attribute__((aligned(16))) bf8 lds[];             // RING * SLOT
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     xcd_tile(bx, by);
-    const int m0 = bx * 64, n0 = by * 64;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int m0 = bx * 64 * TM, n0 = by * 64;
+    const int wmt = wave >> 1;                                            // WM == 2: 32-row half of the tile; WM == 4: which 64-row tile
+    const int wm = (TM == 1) ? wmt * 32 : 0, wn = (wave & 1) * 32;
+    const int xfrag0 = (TM == 1) ? 0 : wmt * NIMG * IMG;                  // this wave's X fragments start here inside a slot
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
     const int KO = a.ldw >> 3;
+    const int mt_last = ((a.M + 63) >> 6) - 1;
+    // X image tile t of this workgroup (a 128-row workgroup past an odd tile count re-reads the last tile: those rows are never stored)
+    const int xt0 = bx * TM, xt1 = min(bx * TM + TM - 1, mt_last);
     auto issue = [&](int step, int slot) {
         const int ko = (kbeg + step * BK) >> 3;
         bf8* S = lds + slot * SLOT;
 #pragma unroll
         for (int p = 0; p < KG; ++p) {                                    // piece = octet (p*4 + wave) of this step
-            const size_t gx = ((size_t)bx * xKO + a.xoct0 + ko + p * 4 + wave) * 64 + lane;
-            const size_t gw = ((size_t)by * KO + ko + p * 4 + wave) * 64 + lane;
             const int d = (p * 4 + wave) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx),
-                                             (__attribute__((address_space(3))) void*)(S + d), 16, 0, 0);
-            if (TERMS == 3)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xlo + gx),
-                                                 (__attribute__((address_space(3))) void*)(S + KG * 256 + d), 16, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const size_t gx = ((size_t)(t ? xt1 : xt0) * xKO + a.xoct0 + ko + p * 4 + wave) * 64 + lane;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xhi + gx),
+                                                 (__attribute__((address_space(3))) void*)(S + t * NIMG * IMG + d), 16, 0, 0);
+                if (TERMS == 3)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xlo + gx),
+                                                     (__attribute__((address_space(3))) void*)(S + t * NIMG * IMG + IMG + d), 16, 0, 0);
+            }
+            const size_t gw = ((size_t)by * KO + ko + p * 4 + wave) * 64 + lane;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gw),
-                                             (__attribute__((address_space(3))) void*)(S + OP + d), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(S + XO + d), 16, 0, 0);
             if (TERMS == 3)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gw),
-                                                 (__attribute__((address_space(3))) void*)(S + OP + KG * 256 + d), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(S + XO + IMG + d), 16, 0, 0);
         }
     };
     auto wait_groups = [&](int n) {                 // all but the youngest n step groups of this wave have landed
@@ -480,35 +495,35 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
             default: wait_vmcnt_imm<5 * G>(); break;
         }
     };
-    static_assert(RING <= 8 && 5 * G <= 63, "wait_groups covers RING - 3 <= 5 groups in flight");
-    struct Frags { bf8 xh[KG][2], xl[KG][2], wh[KG][2], wl[KG][2]; };
+    static_assert(RING <= 8 && (RING - 3) * G <= 63, "wait_groups covers RING - 3 groups in flight");
+    struct Frags { bf8 xh[KG][WM], xl[KG][WM], wh[KG][2], wl[KG][2]; };
     auto read_frags = [&](Frags& f, int slot) {
         const bf8* S = lds + slot * SLOT + li;
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             const int o = (g * 4 + kq) * 64;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f.xh[g][t] = S[o + wm + t * 16];
-                if (TERMS == 3) f.xl[g][t] = S[KG * 256 + o + wm + t * 16];
+            for (int t = 0; t < WM; ++t) {
+                f.xh[g][t] = S[xfrag0 + o + wm + t * 16];
+                if (TERMS == 3) f.xl[g][t] = S[xfrag0 + IMG + o + wm + t * 16];
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                f.wh[g][n] = S[OP + o + wn + n * 16];
-                if (TERMS == 3) f.wl[g][n] = S[OP + KG * 256 + o + wn + n * 16];
+                f.wh[g][n] = S[XO + o + wn + n * 16];
+                if (TERMS == 3) f.wl[g][n] = S[XO + IMG + o + wn + n * 16];
             }
         }
     };
-    f4 acc[2][2];
+    f4 acc[WM][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < WM; ++t)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
     auto mfma_step = [&](const Frags& f) {
 #pragma unroll
         for (int g = 0; g < KG; ++g)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < WM; ++t)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     if (TERMS == 3) {
@@ -541,21 +556,30 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
     int s0 = 0;
     if constexpr (BK == 32) {
         // Steady state, RING steps per iteration: every step issues a copy (group s+RING-1), so there are no conditionals, the
-        // ring slots are compile-time constants and the source addresses are four running pointers (one 64-bit add each per
+        // ring slots are compile-time constants and the source addresses are running pointers (one 64-bit add each per
         // step).  A copy has RING-2 steps to land.
         constexpr int AHEAD = (RING - 1) * 4;                           // octets between this step and the group it issues
-        const bf8* px = xhi + ((size_t)bx * xKO + a.xoct0 + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
-        const bf8* pxl = xlo + ((size_t)bx * xKO + a.xoct0 + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
+        const size_t xoff = (size_t)(a.xoct0 + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
+        const bf8* px = xhi + (size_t)xt0 * xKO * 64 + xoff;
+        const bf8* pxl = xlo + (size_t)xt0 * xKO * 64 + xoff;
+        const bf8* px1 = xhi + (size_t)xt1 * xKO * 64 + xoff;          // second X tile (WM == 4 only)
+        const bf8* pxl1 = xlo + (size_t)xt1 * xKO * 64 + xoff;
         const bf8* pw = reinterpret_cast<const bf8*>(a.whi) + ((size_t)by * KO + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
         const bf8* pwl = reinterpret_cast<const bf8*>(a.wlo) + ((size_t)by * KO + (kbeg >> 3) + AHEAD + wave) * 64 + lane;
         auto fast = [&](const int j, Frags& cur, Frags& nxt) {     // j = step index mod RING (static)
             bf8* S = lds + ((j + RING - 1) % RING) * SLOT + wave * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px, (__attribute__((address_space(3))) void*)S, 16, 0, 0);
             if (TERMS == 3)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pxl, (__attribute__((address_space(3))) void*)(S + 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw, (__attribute__((address_space(3))) void*)(S + OP), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pxl, (__attribute__((address_space(3))) void*)(S + IMG), 16, 0, 0);
+            if (TM == 2) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px1, (__attribute__((address_space(3))) void*)(S + NIMG * IMG), 16, 0, 0);
+                if (TERMS == 3)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pxl1, (__attribute__((address_space(3))) void*)(S + NIMG * IMG + IMG), 16, 0, 0);
+                px1 += 256; pxl1 += 256;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw, (__attribute__((address_space(3))) void*)(S + XO), 16, 0, 0);
             if (TERMS == 3)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pwl, (__attribute__((address_space(3))) void*)(S + OP + 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pwl, (__attribute__((address_space(3))) void*)(S + XO + IMG), 16, 0, 0);
             px += 256; pxl += 256; pw += 256; pwl += 256;
             read_frags(nxt, (j + 1) % RING);
             mfma_step(cur);
@@ -578,15 +602,16 @@ __global__ __launch_bounds__(256, 2) void gemm_presplit_kernel(GemmArgs a, const
         step(s, fa, fb);
         if (s + 1 < nsteps) step(s + 1, fb, fa);
     }
-    gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+    gemm_epilogue<WM, 2>(a, acc, m0 + ((TM == 1) ? wm : wmt * 64) + li, n0 + wn + kq * 4);
 }
 
-template <int TERMS, int BK, int RING>
+template <int TERMS, int BK, int RING, int WM = 2>
 int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, dim3 grid, hipStream_t st) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr size_t LDS_BYTES = (size_t)RING * 2 * NIMG * (BK / 32) * 4 * 64 * 16;
-    auto kern = gemm_presplit_kernel<TERMS, BK, RING>;
+    constexpr size_t LDS_BYTES = (size_t)RING * (WM / 2 + 1) * NIMG * (BK / 32) * 4 * 64 * 16;
+    auto kern = gemm_presplit_kernel<TERMS, BK, RING, WM>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_presplit")) return rc;
+    if (WM == 4) grid.x = (grid.x + 1) / 2;          // grid.x arrives as the number of 64-row tiles
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, xhi, xlo, xko);
     return eg_check_launch("gemm_presplit");
 }
@@ -598,12 +623,12 @@ int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, 
 // workgroup tile 128 x 128 = two 64-row image tiles of X and of W, 32 KB per 32-deep step, 3-slot ring (96 KB: one workgroup
 // = two waves per SIMD).  Schedule as in the convolution: one barrier per step between the two MFMA halves, counted vmcnt
 // (the copy of step s+2 stays in flight), fragments of step s+1 read after the barrier under the second half.
-template <int TERMS>
+template <int TERMS, int RING = 3>
 __global__ __launch_bounds__(512, 1) void gemm_presplit128_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO,
                                                                   int m_tiles, int n_tiles) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr int OPI = 8 * 64;                         // bf8 slots of one image of one operand: [tile(2)][octet(4)][64 rows]
-    constexpr int OP = NIMG * OPI, SLOT = 2 * OP, RING = 3;
+    constexpr int OP = NIMG * OPI, SLOT = 2 * OP;
     constexpr int G = 2 * NIMG;                         // LDS-DMA instructions per wave per step (one 1-KiB piece each)
     extern __shared__ __attribute__((aligned(16))) bf8 lds[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
@@ -663,18 +688,23 @@ __global__ __launch_bounds__(512, 1) void gemm_presplit128_kernel(GemmArgs a, co
                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
             }
     };
-    issue(0, 0);
-    if (nsteps > 1) issue(1, 1);
-    wait_vmcnt_imm<0>();
+    static_assert(RING == 3 || RING == 4, "ring depth");
+    auto wait_younger = [&](int n) {                // all but the youngest n groups of this wave have landed
+        if (n <= 0) wait_vmcnt_imm<0>();
+        else if (n == 1) wait_vmcnt_imm<G>();
+        else wait_vmcnt_imm<2 * G>();
+    };
+    const int pre = min(nsteps, RING - 1);
+    for (int s = 0; s < pre; ++s) issue(s, s);
+    wait_younger(pre - 1);                          // group 0 landed
     wg_barrier();
     Frags fa, fb;
     read_frags(fa, 0);
     auto step = [&](int s, Frags& cur, Frags& nxt) {
-        const bool ahead = s + 2 < nsteps;
-        if (ahead) issue(s + 2, (s + 2) % RING);        // slot of step s-1: its fragments were read before the barrier of step s-1
+        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) % RING);      // slot of step s-1: its fragments were read before the barrier of step s-1
         mfma_half(cur, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (ahead) wait_vmcnt_imm<G>(); else wait_vmcnt_imm<0>();       // group s+1 landed
+        wait_younger(min(s + RING - 1, nsteps - 1) - (s + 1));                      // group s+1 landed; younger copies stay in flight
         wait_lgkmcnt0();
         wg_barrier();
         if (s + 1 < nsteps) read_frags(nxt, (s + 1) % RING);
@@ -688,15 +718,58 @@ __global__ __launch_bounds__(512, 1) void gemm_presplit128_kernel(GemmArgs a, co
     gemm_epilogue<4, 2>(a, acc, m0 + wm * 64 + li, n0 + wn * 32 + kq * 4);
 }
 
-template <int TERMS>
+template <int TERMS, int RING = 3>
 int launch_presplit128(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int m_tiles, int n_tiles, hipStream_t st) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr size_t LDS_BYTES = (size_t)3 * 2 * NIMG * 8 * 64 * 16;
-    auto kern = gemm_presplit128_kernel<TERMS>;
+    constexpr size_t LDS_BYTES = (size_t)RING * 2 * NIMG * 8 * 64 * 16;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    auto kern = gemm_presplit128_kernel<TERMS, RING>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_presplit128")) return rc;
     dim3 grid(eg_cdiv(m_tiles, 2), eg_cdiv(n_tiles, 2), 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, st, a, xhi, xlo, xko, m_tiles, n_tiles);
     return eg_check_launch("gemm_presplit128");
+}
+
+// Tile choice of the pre-split product.  Default policy (measured on the 4-lane headline and on tools/bench_ops.py):
+//   >= 1024 workgroups of 128 x 128  -> 128 x 128, 8 waves (diversity sampling, M = 69 632)
+//   otherwise the policy of `presplit_tile_default` below.
+// EG_GEMM_TILE overrides it for A/B runs: "64" | "128x64" (4-slot ring, one workgroup per CU) | "128x64r3" (3-slot ring, two per CU) | "128".
+enum PresplitTile { TILE_64 = 0, TILE_128x64 = 1, TILE_128x64_R3 = 2, TILE_128 = 3, TILE_64_R8 = 4, TILE_128x64_R6 = 5, TILE_128_R4 = 6, TILE_AUTO = -1 };
+int presplit_tile_override() {          // read per call (a tool / test switches it between launches; a captured graph keeps what it was captured with)
+    const char* e = getenv("EG_GEMM_TILE");
+    if (!e || !e[0]) return TILE_AUTO;
+    if (!strcmp(e, "64")) return TILE_64;
+    if (!strcmp(e, "128x64")) return TILE_128x64;
+    if (!strcmp(e, "128x64r3")) return TILE_128x64_R3;
+    if (!strcmp(e, "128")) return TILE_128;
+    if (!strcmp(e, "64r8")) return TILE_64_R8;            // deeper rings: more operand bytes in flight per CU (one workgroup per CU)
+    if (!strcmp(e, "128x64r6")) return TILE_128x64_R6;
+    if (!strcmp(e, "128r4")) return TILE_128_R4;
+    return TILE_AUTO;
+}
+int presplit_tile_default(int m, int n) {
+    if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 1024) return TILE_128;       // >= 4 workgroups per CU
+    return TILE_64;
+}
+int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int precision, hipStream_t st) {
+    const int mt = eg_cdiv(a.M, 64), nt = eg_cdiv(a.N, 64);
+    int tile = presplit_tile_override();
+    if (tile == TILE_AUTO) tile = presplit_tile_default(a.M, a.N);
+    const bool x3 = precision == EG_PREC_BF16X3;
+    dim3 grid(mt, nt, 1);
+    switch (tile) {
+        case TILE_128: return x3 ? launch_presplit128<3>(a, xhi, xlo, xko, mt, nt, st) : launch_presplit128<1>(a, xhi, xlo, xko, mt, nt, st);
+        case TILE_128x64: return x3 ? launch_presplit<3, 32, 4, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4, 4>(a, xhi, xlo, xko, grid, st);
+        case TILE_128_R4: return x3 ? launch_presplit128<3, 4>(a, xhi, xlo, xko, mt, nt, st) : launch_presplit128<1, 4>(a, xhi, xlo, xko, mt, nt, st);
+        case TILE_64_R8: return x3 ? launch_presplit<3, 32, 8>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 8>(a, xhi, xlo, xko, grid, st);
+        case TILE_128x64_R6: return x3 ? launch_presplit<3, 32, 6, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 6, 4>(a, xhi, xlo, xko, grid, st);
+        case TILE_128x64_R3: return x3 ? launch_presplit<3, 32, 3, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 3, 4>(a, xhi, xlo, xko, grid, st);
+        default: break;
+    }
+    // 64 x 64: 32-deep steps, 4 slots (64 KB: two workgroups per CU).  Measured and dropped in round 1 (2176-row products, bf16x3):
+    // 64-deep steps with 4 slots (16 % slower), 5 slots (no change), 8 slots (one workgroup per CU: the 272-tile grids
+    // then need two passes, 50 % slower), register-staged copies instead of LDS-DMA (30 % slower).
+    return x3 ? launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
 }
 
 // fp32 [M, K] (row stride lda) -> bf16 (hi, lo) tile-planar images [ceil(M/64)][Kpad/8][64][8]; rows >= M and k >= K are zero.
@@ -790,16 +863,7 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
-        dim3 grid(mt, eg_cdiv(p.n, 64), 1);
-        // 32-deep steps, 4 slots (64 KB: two workgroups per CU).  Measured and dropped in round 1 (2176-row products, bf16x3):
-        // 64-deep steps with 4 slots (16 % slower), 5 slots (no change), 8 slots (one workgroup per CU: the 272-tile grids
-        // then need two passes, 50 % slower), register-staged copies instead of LDS-DMA (30 % slower).
-        if ((long)eg_cdiv(p.m, 128) * eg_cdiv(p.n, 128) >= 1024 && !getenv("EG_GEMM_NO128")) {   // >= 4 workgroups per CU, else the 64 x 64 kernel wins (8704 x 512: 23.7 vs 28.7 us)
-            if (p.precision == EG_PREC_BF16X3) return launch_presplit128<3>(a, xhi, xlo, xko, mt, eg_cdiv(p.n, 64), st);
-            return launch_presplit128<1>(a, xhi, xlo, xko, mt, eg_cdiv(p.n, 64), st);
-        }
-        if (p.precision == EG_PREC_BF16X3) return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st);
-        return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
+        return dispatch_presplit(a, xhi, xlo, xko, p.precision, st);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
     return launch_gemm(a, 1, p.precision, st);
@@ -866,18 +930,6 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
     const int xko = (int)eg_round_up(k_x, 64) / 8, mt = eg_cdiv(m, 64);
     const bf8* xhi = reinterpret_cast<const bf8*>(x_images);
     const bf8* xlo = xhi + (size_t)mt * xko * 64;
-    dim3 grid(mt, eg_cdiv(n, 64), 1);
     EgProfScope prof(3, 2.0 * m * (double)n * k, (hipStream_t)stream);
-    if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 1024 && !getenv("EG_GEMM_NO128")) {
-        if (precision == EG_PREC_BF16X3) return launch_presplit128<3>(a, xhi, xlo, xko, mt, eg_cdiv(n, 64), (hipStream_t)stream);
-        return launch_presplit128<1>(a, xhi, xlo, xko, mt, eg_cdiv(n, 64), (hipStream_t)stream);
-    }
-    if (precision == EG_PREC_BF16X3) {
-        if (const char* r = getenv("EG_GEMM_RING")) {           // experiment hook (tools/bench_ops.py): ring depth of the 64x64 kernel
-            if (r[0] == '8') return launch_presplit<3, 32, 8>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
-            if (r[0] == '6') return launch_presplit<3, 32, 6>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
-        }
-        return launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
-    }
-    return launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, (hipStream_t)stream);
+    return dispatch_presplit(a, xhi, xlo, xko, precision, (hipStream_t)stream);
 }

@@ -55,6 +55,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// any D (rows not 16-byte aligned, e.g. the 282-wide encoder of Pose_Discriminator, Models_spatial_memory.py:671-704): scalar accesses, same two-pass order
+__global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                            float* __restrict__ y, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    for (int i = lane; i < D; i += 64) y[(size_t)row * D + i] = (xr[i] - mean) * rstd * g[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void add_rows_any_kernel(const float* __restrict__ a, const float* __restrict__ table, float* __restrict__ out,
+                                                           size_t n, int d, int period) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / d;
+        const size_t trow = period > 0 ? row % period : row;
+        out[i] = a[i] + table[trow * d + (i - row * d)];
+    }
+}
+
 // ---- elementwise helpers -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
                                                         float* __restrict__ out, int rows, int dim, int ld, int n_words) {
@@ -402,10 +426,14 @@ inline int grid_for(size_t n, int cap = 4096) {
 
 int egi_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* img, int rows, int d, float eps, hipStream_t st) {
     EG_REQUIRE(x && gamma && beta && y && rows > 0, EG_ERR_BAD_ARG, "eg_layernorm: null pointer");
-    EG_REQUIRE((d & 3) == 0 && d <= 2048, EG_ERR_UNSUPPORTED, "eg_layernorm: D=%d", d);
+    EG_REQUIRE(d > 0 && d <= 2048, EG_ERR_UNSUPPORTED, "eg_layernorm: D=%d", d);
     EG_REQUIRE(!img || (d & 63) == 0, EG_ERR_ALIGN, "layernorm image output needs D %% 64 == 0");
     unsigned short* im = reinterpret_cast<unsigned short*>(img);
     dim3 grid(eg_cdiv(rows, 4)), block(256);
+    if (d & 3) {
+        hipLaunchKernelGGL(layernorm_any_kernel, grid, block, 0, st, x, gamma, beta, y, rows, d, eps);
+        return eg_check_launch("layernorm");
+    }
     if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
     else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
     else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
@@ -426,7 +454,11 @@ extern "C" int eg_reparameterize(const float* mu, const float* logvar, const flo
 
 extern "C" int eg_add_rows(const float* a, const float* table, float* out, int64_t rows, int32_t d, int32_t period, void* stream) {
     EG_REQUIRE(a && table && out && rows > 0 && d > 0, EG_ERR_BAD_ARG, "eg_add_rows: null pointer or empty shape");
-    EG_REQUIRE((d & 3) == 0, EG_ERR_ALIGN, "eg_add_rows: d %% 4 != 0");
+    if (d & 3) {
+        const size_t n = (size_t)rows * d;
+        hipLaunchKernelGGL(add_rows_any_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, table, out, n, d, period);
+        return eg_check_launch("add_rows");
+    }
     const size_t n4 = (size_t)rows * (d / 4);
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f4*>(a),
                        reinterpret_cast<const f4*>(table), reinterpret_cast<f4*>(out), n4, d / 4, period);

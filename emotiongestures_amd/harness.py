@@ -192,20 +192,24 @@ class Pose_Discriminator(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
         self.precision = precision
-        self._cache = _PackCache()
 
     def forward(self, x):
         B, T, D = x.shape
         if D != self.d_model:
             raise ValueError(f"Pose_Discriminator.forward: expected [B, T, {self.d_model}], got {tuple(x.shape)}")
+        from .train import functional as TF
+        from .train import nets
         if self.training:
-            from .train import nets
             return nets.pose_discriminator_forward(self, x)
-        for layer in self.encoder.layer_stack:
-            layer.slf_attn.precision = layer.pos_ffn.precision = self.precision
-        enc, *_ = self.encoder(x.contiguous(), None)
-        logit = _affine_chain(self._cache, enc.reshape(B * T, D).contiguous(), [self.fc[0], self.fc[2]], False, self.precision)
-        return ops.sigmoid(logit).view(B, T, 1)
+        # eval(): the same HIP operators without a tape and with every Dropout off.  (The fused inference blocks -- eg_multi_head_attention,
+        # eg_positionwise_ffn -- stream 16-byte-aligned rows; a 282-wide model is not, so the encoder runs operator by operator here.)
+        prev = TF.get_precision()
+        TF.set_precision(self.precision if self.precision in ("f32", "bf16x3") else "f32")
+        try:
+            with torch.no_grad():
+                return nets.pose_discriminator_forward(self, x, dropout=False)
+        finally:
+            TF.set_precision(prev)
 
 
 class SoftmaxContrastiveLoss(nn.Module):

@@ -200,11 +200,13 @@ def motion_discriminator_forward(md, x):
     return F.linear(h, md.fc2[10].weight, md.fc2[10].bias)
 
 
-def pose_discriminator_forward(pd, x):
-    """Pose_Discriminator.forward (Models_spatial_memory.py:698-702) in train() mode: encoder -> Linear -> Dropout(0.2) -> Linear -> sigmoid,
-    one probability per frame [B, T, 1].  x may require a gradient (the generator's adversarial term)."""
+def pose_discriminator_forward(pd, x, dropout=True):
+    """Pose_Discriminator.forward (Models_spatial_memory.py:698-702): encoder -> Linear -> Dropout(0.2) -> Linear -> sigmoid, one probability
+    per frame [B, T, 1].  x may require a gradient (the generator's adversarial term).  dropout=False: the eval() forward (same operators)."""
     B, T, D = x.shape
     _dropout_on(pd)
+    if not dropout:
+        _P["on"] = False
     try:
         enc = encoder_forward(pd.encoder, x)
         h = _dp(F.linear(enc.reshape(B * T, D), pd.fc[0].weight, pd.fc[0].bias), 0.2)
@@ -324,22 +326,26 @@ def cvae_forward(vae, Input, y, eps):
     Conv1d / ConvTranspose1d run channels-last ([n, L, C]); LeakyReLU(0.2) precedes BatchNorm1d as upstream (:318-332,355-369);
     `eps` replaces torch.randn_like(std) of reparameterize (:398)."""
     E, D = vae.Encoder, vae.Decoder
-    h = _cl(Input)                                                     # [n, L = d_model, C = frames]
-    for ci, bi, st, pd in ((0, 2, 1, 1), (3, 5, 1, 1), (6, 8, 2, 2), (9, 11, 2, 2)):
-        h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, E[ci].weight, E[ci].bias, st, pd, 1), 0.2), E[bi])
-    n = h.shape[0]
-    latent = h.transpose(1, 2).reshape(n, -1)                          # NCL flatten (:409)
-    la, lb = F.fork(latent)
-    mu = F.linear(F.linear(la, vae.fc_mu[0].weight, vae.fc_mu[0].bias), vae.fc_mu[2].weight, vae.fc_mu[2].bias)
-    logvar = F.linear(F.linear(lb, vae.fc_var[0].weight, vae.fc_var[0].bias), vae.fc_var[2].weight, vae.fc_var[2].bias)
-    mu_z, mu_out = F.fork(mu)
-    lv_z, lv_out = F.fork(logvar)
-    z = F.reparameterize(mu_z, lv_z, eps)
-    py = vae.Posterior_Y_embedding
-    post_y = F.linear(F.linear(y, py[0].weight, py[0].bias), py[2].weight, py[2].bias)
-    zc = torch.cat((z, post_y), 1)
-    fz = vae.fusion_z_posterior
-    zc = F.linear(F.linear(zc, fz[0].weight, fz[0].bias), fz[2].weight, fz[2].bias)
+    _dropout_on(vae)            # the Dropout(0.2) inside the four Linear pairs (:336,345,350,380), active with `vae.train_dropout = True`
+    try:
+        h = _cl(Input)                                                     # [n, L = d_model, C = frames]
+        for ci, bi, st, pd in ((0, 2, 1, 1), (3, 5, 1, 1), (6, 8, 2, 2), (9, 11, 2, 2)):
+            h = F.batch_norm(F.leaky_relu(F.conv1d_cl(h, E[ci].weight, E[ci].bias, st, pd, 1), 0.2), E[bi])
+        n = h.shape[0]
+        latent = h.transpose(1, 2).reshape(n, -1)                          # NCL flatten (:409)
+        la, lb = F.fork(latent)
+        mu = F.linear(_dp(F.linear(la, vae.fc_mu[0].weight, vae.fc_mu[0].bias), 0.2), vae.fc_mu[2].weight, vae.fc_mu[2].bias)
+        logvar = F.linear(_dp(F.linear(lb, vae.fc_var[0].weight, vae.fc_var[0].bias), 0.2), vae.fc_var[2].weight, vae.fc_var[2].bias)
+        mu_z, mu_out = F.fork(mu)
+        lv_z, lv_out = F.fork(logvar)
+        z = F.reparameterize(mu_z, lv_z, eps)
+        py = vae.Posterior_Y_embedding
+        post_y = F.linear(_dp(F.linear(y, py[0].weight, py[0].bias), 0.2), py[2].weight, py[2].bias)
+        zc = torch.cat((z, post_y), 1)
+        fz = vae.fusion_z_posterior
+        zc = F.linear(_dp(F.linear(zc, fz[0].weight, fz[0].bias), 0.2), fz[2].weight, fz[2].bias)
+    finally:
+        _P["on"] = False
     h = _cl(zc.reshape(n, 4, -1))                                      # [n, L = d_model/4, C = 4]
     h = F.batch_norm(F.leaky_relu(F.conv_transpose1d_cl(h, D[0].weight, D[0].bias), 0.2), D[2])
     h = F.batch_norm(F.leaky_relu(F.conv_transpose1d_cl(h, D[3].weight, D[3].bias), 0.2), D[5])

@@ -245,6 +245,40 @@ def test_linear_presplit_matches_fp64(prec, M, N, K):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(2176, 512, 512), (2176, 2048, 512), (2176, 512, 2048),     # the headline's transformer products
+                                   (200, 192, 96), (8390, 320, 1024), (64, 64, 32)])          # odd tile counts, a short K, a single tile
+def test_linear_presplit_tile_variants_are_bitwise_equal(prec, M, N, K, monkeypatch):
+    """The workgroup tile of the pre-split product is a scheduling choice: every variant (64 x 64, 128 x 64 with a 4- or 3-slot ring,
+    128 x 128; forced through EG_GEMM_TILE, which the library reads per call) accumulates each output element over K in the same order with
+    the same three split terms, so the results are bitwise identical -- to each other and to eg_linear's in-kernel split."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd import ops
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    x, w = T("tx", (M, K)), T("tw", (N, K), -0.1, 0.1)
+    bias, res = T("tb", (N,)), T("tr", (M, N))
+    xd, rd = x.to(dev()), res.to(dev())
+    wp, npad, kpad = ops.pack_linear_weight(w, dev())
+    bp = torch.zeros(npad, device=dev()); bp[:N] = bias.to(dev())
+    kp, mt = (K + 63) // 64 * 64, (M + 63) // 64
+    img = torch.empty(2 * mt * 64 * kp, dtype=torch.int16, device=dev())
+    L.check(lib.eg_split_tiles(_ptr(xd), K, M, K, _ptr(img), _stream(dev())), "eg_split_tiles")
+    outs = {}
+    for tile in ("64", "128x64", "128x64r3", "128"):
+        monkeypatch.setenv("EG_GEMM_TILE", tile)
+        y = torch.full((M, N), float("nan"), device=dev())
+        L.check(lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, _ptr(bp), _ptr(rd), None, N, _ptr(y), N, M, N, K, 1,
+                                       L.precision_code(prec), _stream(dev())), "eg_linear_presplit " + tile)
+        torch.cuda.synchronize()
+        outs[tile] = y
+    monkeypatch.delenv("EG_GEMM_TILE")
+    ref = torch.relu(x.double() @ w.double().T + bias.double() + res.double())
+    assert rel_l2(outs["64"].cpu().numpy(), ref.numpy()) < TOL[prec]
+    for tile in ("128x64", "128x64r3", "128"):
+        assert torch.equal(outs[tile], outs["64"]), tile
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 def test_linear_random_shapes(prec):
     """eg_linear over 24 seeded shapes (ragged M / N, K not a multiple of the 32-deep step) vs float64, all epilogue options."""

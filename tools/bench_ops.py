@@ -49,10 +49,16 @@ def gemm(prec):
             xc = x.contiguous()
             us_s = timeit(lambda: lib.eg_split_tiles(_ptr(xc), K, M, K, _ptr(img), st))
             y2 = torch.empty(M, N, device=dev)
-            us_p = timeit(lambda: lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, None, None, None, 0, _ptr(y2), N, M, N, K, 0, pc, st))
             f(); torch.cuda.synchronize()
-            err = float((y2 - y).abs().max() / y.abs().max())
-            print(f"     presplit: split {us_s:6.1f} us  gemm {us_p:6.1f} us  {2.0 * M * N * K / us_p / 1e6:8.1f} TFLOP/s  max rel diff vs eg_linear {err:.1e}")
+            line = f"     presplit: split {us_s:6.1f} us |"
+            for tile in (os.environ.get("TILES", "64,128x64,128x64r3,128").split(",")):
+                os.environ["EG_GEMM_TILE"] = tile
+                us_p = timeit(lambda: lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, None, None, None, 0, _ptr(y2), N, M, N, K, 0, pc, st))
+                torch.cuda.synchronize()
+                ok = "" if torch.equal(y2, y) else " MISMATCH"
+                line += f" {tile}: {us_p:6.1f} us {2.0 * M * N * K / us_p / 1e6:6.1f} TF{ok} |"
+            os.environ.pop("EG_GEMM_TILE", None)
+            print(line)
 
 
 def conv(prec):
