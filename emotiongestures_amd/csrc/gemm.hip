@@ -748,7 +748,12 @@ int presplit_tile_override() {          // read per call (a tool / test switches
     return TILE_AUTO;
 }
 int presplit_tile_default(int m, int n) {
-    if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 1024) return TILE_128;       // >= 4 workgroups per CU
+    // 128 x 128 (8 waves, 32 KB of operands per 192 MFMAs) from 64 workgroups up.  At the headline's 2176-row products it is SLOWER alone
+    // (13.3 vs 9.3 us at N = 512: 68 workgroups leave 188 CUs idle) but FASTER in the step as it is run, four batches in flight: it occupies a
+    // quarter of the CUs for half the operand traffic, and the other lanes' convolutions take the rest -- same-box A/B of the default bench
+    // line, twice each: 25 537 / 25 605 clips/s against 25 311 / 25 288 with the 64 x 64 tile (profiles/r04c_gemm_tile_ab.txt).  Below that
+    // (16-clip training steps, M = 544) the 64 x 64 tile's 4 x more workgroups win.
+    if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 64) return TILE_128;
     return TILE_64;
 }
 int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int precision, hipStream_t st) {

@@ -265,7 +265,7 @@ def test_linear_presplit_tile_variants_are_bitwise_equal(prec, M, N, K, monkeypa
     img = torch.empty(2 * mt * 64 * kp, dtype=torch.int16, device=dev())
     L.check(lib.eg_split_tiles(_ptr(xd), K, M, K, _ptr(img), _stream(dev())), "eg_split_tiles")
     outs = {}
-    for tile in ("64", "128x64", "128x64r3", "128"):
+    for tile in ("64", "64r8", "128x64", "128x64r3", "128x64r6", "128", "128r4"):
         monkeypatch.setenv("EG_GEMM_TILE", tile)
         y = torch.full((M, N), float("nan"), device=dev())
         L.check(lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, _ptr(bp), _ptr(rd), None, N, _ptr(y), N, M, N, K, 1,
@@ -275,7 +275,7 @@ def test_linear_presplit_tile_variants_are_bitwise_equal(prec, M, N, K, monkeypa
     monkeypatch.delenv("EG_GEMM_TILE")
     ref = torch.relu(x.double() @ w.double().T + bias.double() + res.double())
     assert rel_l2(outs["64"].cpu().numpy(), ref.numpy()) < TOL[prec]
-    for tile in ("128x64", "128x64r3", "128"):
+    for tile in ("64r8", "128x64", "128x64r3", "128x64r6", "128", "128r4"):
         assert torch.equal(outs[tile], outs["64"]), tile
 
 

@@ -1319,3 +1319,42 @@ def test_resident_weight_images_match_per_use_packing():
         F.set_precision("f32")
         F.register_weight_images(None)
     assert torch.equal(finals[0], finals[1])
+
+
+def test_linear_on_many_rows_takes_the_presplit_product_and_equals_the_in_kernel_split():
+    """From 2048 rows up (128-clip steps) the training Linear splits its input once (eg_split_tiles, shared by consecutive products on the same
+    rows) and runs the pre-split product; below it the consumer splits in-kernel.  Same three bf16 terms in the same order: forward, input
+    gradient and weight gradient are bitwise those of the two half-size calls."""
+    from emotiongestures_amd.train import functional as F
+    torch.manual_seed(3)
+    M, K, N = 2176, 512, 384
+    x = torch.randn(M, K, device=DEV)
+    w1, w2 = (torch.randn(N, K, device=DEV) * 0.05).requires_grad_(True), (torch.randn(N, K, device=DEV) * 0.05).requires_grad_(True)
+    b = torch.randn(N, device=DEV).requires_grad_(True)
+    dy = torch.randn(M, N, device=DEV)
+    F.set_precision("bf16x3")
+    try:
+        assert M >= F.PRESPLIT_MIN_ROWS
+        F.clear_split_cache()
+        n0 = int(F._lib().eg_launch_count())
+        xa = x.clone().requires_grad_(True)
+        ya = F.linear(xa, w1, b, relu=True)
+        yb = F.linear(xa, w2)                                # same rows again: the images are reused (no second split launch)
+        launches = int(F._lib().eg_launch_count()) - n0
+        assert launches == 3, launches                       # one split + two products
+        (ya * dy).sum().backward()
+        ga, gw, gb = xa.grad.clone(), w1.grad.clone(), b.grad.clone()
+        w1.grad = None; b.grad = None
+        F.clear_split_cache()
+        outs, gxs = [], []
+        for lo, hi in ((0, 1088), (1088, M)):               # 1088 rows: the in-kernel-split product
+            xh = x[lo:hi].clone().requires_grad_(True)
+            yh = F.linear(xh, w1, b, relu=True)
+            (yh * dy[lo:hi]).sum().backward()
+            outs.append(yh.detach()); gxs.append(xh.grad)
+        assert torch.equal(ya.detach(), torch.cat(outs)) and torch.equal(ga, torch.cat(gxs))
+        assert rel(gw, w1.grad) < 1e-6 and rel(gb, b.grad) < 1e-6      # the row split changes the summation order of dW / db only
+        assert bool(torch.isfinite(yb).all())
+    finally:
+        F.set_precision("f32")
+        F.clear_split_cache()

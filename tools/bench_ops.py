@@ -51,7 +51,7 @@ def gemm(prec):
             y2 = torch.empty(M, N, device=dev)
             f(); torch.cuda.synchronize()
             line = f"     presplit: split {us_s:6.1f} us |"
-            for tile in (os.environ.get("TILES", "64,128x64,128x64r3,128").split(",")):
+            for tile in (os.environ.get("TILES", "64,64r8,128x64,128x64r3,128x64r6,128,128r4").split(",")):
                 os.environ["EG_GEMM_TILE"] = tile
                 us_p = timeit(lambda: lib.eg_linear_presplit(_ptr(img), K, _ptr(wp), kpad, None, None, None, 0, _ptr(y2), N, M, N, K, 0, pc, st))
                 torch.cuda.synchronize()
