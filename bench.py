@@ -397,7 +397,7 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.synth import load_synth_weights
     from emotiongestures_amd.train import functional as F
-    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
+    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters, stage_splits
     model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(dev).train()
     vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 0).to(dev).train()
     model.train_dropout = vae.train_dropout = bool(dropout)
@@ -406,8 +406,9 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     fp = flatten_parameters(both)
     fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
     opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
-    gb = GradBuckets(fp, bucket_mb=25.0).attach()
+    gb = GradBuckets(fp, bucket_mb=25.0, split_at=stage_splits(model, fp) if world > 1 else ()).attach()     # buckets end at the segmented backward's phase boundaries
     ar_ms = []
+    seg = [None]
 
     def forward_loss():
         pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
@@ -457,7 +458,8 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
             gb.payload = os.environ.get("EG_GRAD_PAYLOAD", "f32")          # "bf16": buckets travel as bfloat16 (half the xGMI bytes)
             ss = SegmentedStep(forward_loss, gb, opt, device=dev, warmup=max(1, warmup), stochastic=bool(dropout))
             run = lambda: ss.run(exposed=ar_ms)
-            mode = f"{ss.n_segments} hipGraph segments per step, bucket all-reduces between them on a side stream ({gb.payload} payload)"
+            seg[0] = ss
+            mode = f"{ss.n_segments} hipGraph segments per step (backward cut at the tower output and per tower stage), bucket all-reduces between them on a side stream ({gb.payload} payload)"
 
     for _ in range(max(1, warmup)):
         loss = run()
@@ -480,6 +482,7 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
            "launch": mode, "library_launches_per_step": launches, "first_loss": first_loss, "final_loss": float(loss.detach()),
            "algorithmic_tflops_per_gpu": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_TFLOPS["bf16x3" if precision != "f32" else "f32"], 4),
            "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
+           "allreduce_exposed_bytes_per_step": None if seg[0] is None else seg[0].exposed_bytes(),
            "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
     del model, vae, both, fp, opt, gb
     return out
@@ -508,7 +511,8 @@ def train_worker(args, rank, world, dev, dist, backend):
             "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
                        "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": nb},
-            "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"], "launch": main_leg["launch"],
+            "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"],
+            "allreduce_exposed_bytes_per_step": main_leg["allreduce_exposed_bytes_per_step"], "launch": main_leg["launch"],
             "library_launches_per_step": main_leg["library_launches_per_step"], "algorithmic_tflops_per_gpu": main_leg["algorithmic_tflops_per_gpu"],
             "frac_of_mfma_peak": main_leg["frac_of_mfma_peak"]}
         if parity is not None:

@@ -74,10 +74,13 @@ class SegmentedStep:
     """A data-parallel training step as a few captured hipGraph segments with the bucket all-reduces BETWEEN them.
 
     With more than one rank a single graph of forward + backward leaves the whole gradient reduction exposed behind the replay.  Here the
-    backward is cut at the tower output (train/nets.CutContext): segment 0 = forward + the backward of everything behind the audio tower
-    (post-projector, decoder, encoder, heads, projections: ~94 % of the gradient bytes, ~40 % of the backward time); segment 1 = the tower's
-    backward.  After segment 0 replays, the buckets it completed are all-reduced on a side stream WHILE segment 1 replays on the main stream;
-    the buckets of segment 1 follow, then the tail graph (1/world scaling, fused Adam, weight-image refresh).  The collectives stay outside
+    backward is cut at the tower output and at the inputs of the tower's stages (train/nets.CutContext; `cuts`): segment 0 = forward + the
+    backward of everything behind the audio tower (post-projector, decoder, encoder, heads, projections: ~94 % of the gradient bytes, ~40 % of
+    the backward time); segment 1 = final_conv1 + layer3's backward, segment 2 = layer2's, segment 3 = layer1's and the stem's.  After a segment
+    replays, the buckets it completed are all-reduced on a side stream WHILE the next segment replays on the main stream; only what the LAST
+    segment completes (layer1 + stem: 0.2 MB) is reduced with nothing left to hide it.  For that the buckets must end at the phase boundaries:
+    build them with `GradBuckets(fp, split_at=optim.stage_splits(model, fp))`.  Then the tail graph (1/world scaling, fused Adam, weight-image
+    refresh).  The collectives stay outside
     the graphs (RCCL launches issued by torch.distributed on the side stream), so the same code runs over gloo in the tests.
 
     loss_fn() runs the train-mode forward and returns the loss tensor (no zero_grad / backward / optimiser calls inside).
@@ -85,7 +88,7 @@ class SegmentedStep:
     stochastic=True: the model's dropout is on (`train_dropout`): the mask epoch moves to the device before the warm-up, so that every replay
     of the segments draws fresh masks (forward and backward of one step share the epoch: it advances once per step, in segment 0)."""
 
-    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower",), warmup: int = 3, use_graphs: bool = True, stochastic: bool = False):
+    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower", "layer3", "layer2"), warmup: int = 3, use_graphs: bool = True, stochastic: bool = False):
         from . import nets
         self.loss_fn, self.gb, self.opt, self.nets = loss_fn, buckets, optimizer, nets
         self.ctx = nets.CutContext(cuts)
@@ -180,6 +183,12 @@ class SegmentedStep:
         if ev is not None:
             ev[1].record()
             exposed.append(ev)
+
+    def exposed_bytes(self) -> int:
+        """Gradient bytes whose all-reduce has no later segment to hide behind: the buckets completed by the last phase."""
+        if not self.ready:
+            return 0
+        return int(sum(4 * (self.gb.buckets[b][1] - self.gb.buckets[b][0]) for b in self.ready[-1]))
 
     # ---- capture / replay -------------------------------------------------------------------------------------------
     def _capture(self):

@@ -40,7 +40,8 @@ def _dropout_on(model) -> None:
 # forward on, so the backward runs in phases -- loss.backward() stops at the leaves, then each cut continues with x.backward(leaf.grad) --
 # and the gradient buckets completed by one phase are all-reduced while the next phase computes.  No arithmetic: a detach and a .grad hand-over.
 # A site is only valid where every parameter's gradient and the leaf's gradient are completed within ONE phase: the tower output is (everything
-# upstream of it is the tower alone); the encoder output is not (the emotion head reaches emotion_proj / fc1 / fc2 past it in another phase).
+# upstream of it is the tower alone), and so are the inputs of the tower's stages ("layer2", "layer3": a chain, the stage's first block is the only
+# consumer); the encoder output is not (the emotion head reaches emotion_proj / fc1 / fc2 past it in another phase).
 _CUTS = {"ctx": None}
 
 
@@ -131,7 +132,9 @@ def resnetse_forward(enc, spec):
     x = spec.unsqueeze(-1).contiguous()
     # conv -> ReLU -> BatchNorm (ResNetSE34V2.py:64-66): the ReLU's backward mask rides on bn1's backward reduction / apply, as in the blocks
     x = F.batch_norm(F.conv3x3(x, enc.conv1.weight, enc.conv1.bias, 1, relu=True, defer_mask=True), enc.bn1, relu_input=True)
-    for layer in (enc.layer1, enc.layer2, enc.layer3, getattr(enc, "layer4", ())):
+    for name, layer in (("layer1", enc.layer1), ("layer2", enc.layer2), ("layer3", enc.layer3), ("layer4", getattr(enc, "layer4", ()))):
+        if name != "layer1" and len(layer):
+            x = _cut(name, x)           # stage inputs are valid cut sites: one consumer chain, every upstream gradient belongs to the later phase
         for blk in layer:
             x = se_basic_block(blk, x)
     return x

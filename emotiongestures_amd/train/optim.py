@@ -228,20 +228,55 @@ class FlatAdam:
         self.fp.zero_grad()
 
 
+def stage_splits(model, fp: FlatParams):
+    """Flat offsets at which the gradient buckets of a generator should be cut for a backward segmented per tower stage (nets.CutContext names
+    "tower", "layer3", "layer2"): the first parameter of layer2, of layer3, of what follows layer3 inside the audio encoder (final_conv1 ...), and of
+    the first module after the audio encoder.  Parameters are flattened in registration order, the tower first, so these are the phase boundaries
+    of the backward read from the end of the buffer."""
+    ae = getattr(model, "audio_encoder", None)
+    if ae is None:
+        for m in model.modules():
+            if hasattr(m, "audio_encoder"):
+                ae = m.audio_encoder
+                break
+    if ae is None:
+        return []
+    fe = ae.feat_extractor
+    firsts = []
+    for mod in (fe.layer2, fe.layer3):
+        ps = [p for p in mod.parameters() if id(p) in fp.index]
+        if ps:
+            firsts.append(min(fp.offsets[fp.index[id(p)]] for p in ps))
+    tower = [fp.offsets[fp.index[id(p)]] for p in fe.parameters() if id(p) in fp.index]
+    enc = [fp.offsets[fp.index[id(p)]] for p in ae.parameters() if id(p) in fp.index]
+    for group in (tower, enc):          # first parameter behind the tower / behind the whole audio encoder
+        later = [o for o in fp.offsets if group and o > max(group)]
+        if later:
+            firsts.append(min(later))
+    return sorted(set(o for o in firsts if o > 0))
+
+
 class GradBuckets:
     """Bucketed gradient all-reduce over the flat gradient buffer (sum across ranks, then scale by 1/world)."""
 
-    def __init__(self, fp: FlatParams, bucket_mb: float = 25.0, group=None):
+    def __init__(self, fp: FlatParams, bucket_mb: float = 25.0, group=None, split_at=()):
+        """split_at: flat offsets (parameter starts) at which a bucket must end even when it is short of `bucket_mb` -- the phase boundaries of a
+        segmented backward (train/graph.SegmentedStep with several cuts: a bucket that spanned two phases would only be complete, and reduced,
+        after the later one).  `stage_splits(model, fp)` returns the audio tower's."""
         import torch.distributed as dist
         self.fp, self.group = fp, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         n = fp.grad.numel()
+        forced = set(int(o) for o in split_at)
+        unknown = forced - set(fp.offsets)
+        if unknown:
+            raise ValueError(f"GradBuckets: split_at offsets {sorted(unknown)} are not parameter starts")
         # bucket boundaries on parameter boundaries, walking from the LAST parameter (whose gradient is ready first) backwards
         self.buckets = []
         end = n
         for o in reversed(fp.offsets):
-            if end - o >= per:
+            if end - o >= per or (o in forced and end > o):
                 self.buckets.append((o, end))
                 end = o
         if end > 0:

@@ -193,6 +193,35 @@ _WORKER = textwrap.dedent('''
         for p, want in zip(fp.params[:6], acc):
             assert torch.allclose(p.grad, want / world, rtol=tol, atol=tol * float(want.abs().max()) / world), (payload, float((p.grad - want / world).abs().max()))
     gb.payload, gb.deferred = "f32", False
+    # several cuts + buckets forced to end at the phase boundaries (GradBuckets(split_at=...)): every bucket is complete at the end of ONE phase,
+    # each phase's buckets are reduced while the next phase runs, and only the first layer's bucket is left for the join (exposed_bytes)
+    gb3 = GradBuckets(fp, bucket_mb=64.0, split_at=[fp.offsets[2], fp.offsets[4], fp.offsets[6]])        # one bucket per Linear (+ the unused one)
+    assert [lo for lo, _ in gb3.buckets] == [fp.offsets[6], fp.offsets[4], fp.offsets[2], 0], gb3.buckets
+    for p_ in fp.params:
+        p_._post_accumulate_grad_hooks.clear() if getattr(p_, "_post_accumulate_grad_hooks", None) else None
+    gb3.attach()
+    l0, l1, l2 = model[0], model[2], model[4]
+    def loss3():
+        h = nets._cut("layer2", torch.relu(l0(x)))
+        h = nets._cut("layer3", torch.relu(l1(h)))
+        return l2(h).sum()
+    ss3 = SegmentedStep(loss3, gb3, _Opt(fp), cuts=("layer3", "layer2"), use_graphs=False)
+    for it in range(2):
+        ss3.run()
+    assert len(ss3.ready) == 3, ss3.ready
+    b_of = lambda i: gb3.param_bucket[i]
+    assert b_of(4) in ss3.ready[0] and b_of(2) in ss3.ready[1] and b_of(0) in ss3.ready[2], (ss3.ready, gb3.param_bucket)
+    assert sorted(sum(ss3.ready, [])) == list(range(len(gb3.buckets)))
+    nbytes = lambda b: 4 * (gb3.buckets[b][1] - gb3.buckets[b][0])
+    assert ss3.exposed_bytes() == nbytes(b_of(0)) + nbytes(b_of(6)), ss3.exposed_bytes()       # the first Linear's bucket (+ the gradient-less layer's 30 zeros, completed by finish)
+    assert ss3.exposed_bytes() < 0.35 * 4 * fp.grad.numel()              # the other 70 % were reduced under a later segment
+    for p, want in zip(fp.params[:6], acc):
+        assert torch.allclose(p.grad, want / world, rtol=1e-5, atol=1e-6)
+    try:
+        GradBuckets(fp, split_at=[3])
+        raise SystemExit("split_at inside a parameter must be refused")
+    except ValueError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""What OCP e4m3 (per-tensor scale) GEMM operands would cost in accuracy on BASELINE configs[4]'s per-draw part
-(fusion_proj -> encoder -> decoder -> post_projector), measured on the CPU oracle by quantising both operands of every nn.Linear
-of that part (and, separately, to bf16) -- the numbers behind DESIGN.md's decision not to ship an fp8 mode.  CPU only.
+"""What fp8 GEMM operands would cost in accuracy on BASELINE configs[4]'s per-draw part (fusion_proj -> encoder -> decoder -> post_projector),
+measured on the CPU oracle by quantising both operands of every nn.Linear of that part -- the numbers behind DESIGN.md's decision not to ship
+an fp8 mode.  Three operand formats:
+  bf16    plain bfloat16 (the library's fast mode, for scale)
+  e4m3    OCP e4m3 with one scale per TENSOR (round 2's study)
+  mxfp8   the gfx950-native block-scaled form (v_mfma_scale_f32_16x16x128_f8f6f4): OCP MX, e4m3 elements with one shared power-of-two (e8m0)
+          scale per 32 consecutive K elements of each row, scale = 2^(floor(log2(max |v|)) - 8), elements saturated to +-448
+CPU only.
 
     python tools/fp8_error_study.py [clips=16]"""
 import os
@@ -29,6 +34,15 @@ def quant(x):
     if MODE["q"] == "e4m3":
         s = x.abs().max().clamp_min(1e-30) / 448.0
         return (x / s).to(torch.float8_e4m3fn).float() * s
+    if MODE["q"] == "mxfp8":
+        shp = x.shape
+        k = shp[-1]
+        pad = (-k) % 32
+        v = torch.nn.functional.pad(x, (0, pad)).reshape(-1, (k + pad) // 32, 32)
+        amax = v.abs().amax(-1, keepdim=True).clamp_min(2.0 ** -126)
+        scale = torch.exp2(torch.floor(torch.log2(amax)) - 8.0)                  # e8m0: a power of two per 32-element block (OCP MX v1.0 6.3)
+        q = (v / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+        return q.reshape(*shp[:-1], k + pad)[..., :k]
     if MODE["q"] == "bf16":
         return x.bfloat16().float()
     return x
@@ -46,7 +60,7 @@ def lin_q(sd_, p, x):
 O._lin = lin_q
 res = {}
 with torch.no_grad():
-    for mode in (None, "bf16", "e4m3"):
+    for mode in (None, "bf16", "e4m3", "mxfp8"):
         MODE["q"] = mode
         res[mode] = O.generator_forward(sd, O.GenCfg(), t["spec"], t["text"], t["pre_pose"], t["sampled"])[0].numpy()
 O._lin = orig_lin
@@ -55,7 +69,7 @@ from emotiongestures_amd.harness import MLP_Reconstruct
 ae_sd = {k: v.detach() for k, v in load_synth_weights(MLP_Reconstruct(pose_dim=126), 5).state_dict().items()}
 feat = lambda p: O.fgd_autoencoder(ae_sd, torch.from_numpy(p))[1].reshape(-1, 512).numpy().astype(np.float64)
 f0 = feat(res[None])
-for mode in ("bf16", "e4m3"):
+for mode in ("bf16", "e4m3", "mxfp8"):
     f1 = feat(res[mode])
     fgd = float(np.real(calculate_frechet_distance(f0.mean(0), np.cov(f0, rowvar=False), f1.mean(0), np.cov(f1, rowvar=False))))
     e = np.linalg.norm((res[mode] - res[None]).reshape(n, -1), axis=1) / np.linalg.norm(res[None].reshape(n, -1), axis=1)
