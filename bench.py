@@ -385,10 +385,7 @@ def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=Non
     try:
         return _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier)
     finally:                    # also when a leg raises: the process-wide precision / image registry / mask epoch never leak into the next leg
-        F.set_precision("f32")
-        F.register_weight_images(None)
-        F._DROP["epoch"] = None
-        F.manual_seed(0)
+        F.reset_state()
         torch.cuda.empty_cache()
 
 

@@ -203,13 +203,8 @@ class Pose_Discriminator(nn.Module):
             return nets.pose_discriminator_forward(self, x)
         # eval(): the same HIP operators without a tape and with every Dropout off.  (The fused inference blocks -- eg_multi_head_attention,
         # eg_positionwise_ffn -- stream 16-byte-aligned rows; a 282-wide model is not, so the encoder runs operator by operator here.)
-        prev = TF.get_precision()
-        TF.set_precision(self.precision if self.precision in ("f32", "bf16x3") else "f32")
-        try:
-            with torch.no_grad():
-                return nets.pose_discriminator_forward(self, x, dropout=False)
-        finally:
-            TF.set_precision(prev)
+        with TF.precision(self.precision if self.precision in ("f32", "bf16x3") else "f32"), torch.no_grad():
+            return nets.pose_discriminator_forward(self, x, dropout=False)
 
 
 class SoftmaxContrastiveLoss(nn.Module):

@@ -35,6 +35,38 @@ def get_precision() -> str:
     return "f32" if _PREC["conv"] == F32 else "bf16x3"
 
 
+class precision:
+    """`with functional.precision("bf16x3"): ...` -- the arithmetic of the training operators for a block, restored on exit also when the block
+    raises.  The training layer keeps its configuration (precision, scratch buffers, registered weight images, the dropout stream, the cut
+    context of a segmented step) per PROCESS: one trainer per process, as the one-process-per-GPU design has it.  It cannot be per thread:
+    autograd runs the backward operators on its own device thread, which must see the forward's configuration.  (The C ABI underneath is
+    stateless and re-entrant; this note is about the Python layer above it.)"""
+
+    def __init__(self, name: str):
+        self.name, self.prev = name, None
+
+    def __enter__(self):
+        self.prev = get_precision()
+        set_precision(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+        return False
+
+
+def reset_state() -> None:
+    """Drop every piece of per-process state of the training layer: fp32 precision, no registered weight images, no scratch buffers,
+    host-side dropout stream at seed 0 (device epoch off), no pending BatchNorm counters.  For `finally:` blocks of drivers that train
+    several models in one process (bench.py's legs, the K-fold loop)."""
+    set_precision("f32")
+    register_weight_images(None)
+    _WS.clear()
+    _DROP["epoch"] = None
+    manual_seed(0)
+    _PENDING_COUNTERS.clear()
+
+
 def _lib():
     return L.load()
 
@@ -145,29 +177,6 @@ def _pack_linear(w, transpose=False):
     return img, (k + 63) // 64 * 64
 
 
-PRESPLIT_MIN_ROWS = 2048        # below this the extra split launch costs more than the pre-split product saves (16-clip steps: M = 544)
-_SPLIT = {"key": None, "src": None, "img": None}
-
-
-def _split_images(x: torch.Tensor) -> torch.Tensor:
-    """bf16 (hi, lo) tile-planar images of the row-major fp32 matrix x (eg_split_tiles), remembered for the LAST tensor split: consecutive
-    products on the same rows (same storage, shape and version) reuse them.  The entry keeps its source tensor alive, so the address cannot be
-    handed to another tensor while the entry could still match."""
-    key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device))
-    if _SPLIT["key"] == key:
-        return _SPLIT["img"]
-    M, K = x.shape
-    kp, mt = (K + 63) // 64 * 64, (M + 63) // 64
-    img = torch.empty(2 * mt * 64 * kp, dtype=torch.int16, device=x.device)
-    L.check(_lib().eg_split_tiles(_ptr(x), K, M, K, _ptr(img), _stream(x.device)), "eg_split_tiles")
-    _SPLIT.update(key=key, src=x, img=img)
-    return img
-
-
-def clear_split_cache() -> None:
-    _SPLIT.update(key=None, src=None, img=None)
-
-
 def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False):
     """y[M,N] = x[M,K] w[N,K]^T (+bias) (+res) (relu) on the MFMA GEMM (eg_linear): fp32, or split-bf16 under set_precision("bf16x3").
     w_transposed: w is [K,N] and the product is x w (the input gradient of a Linear)."""
@@ -191,14 +200,6 @@ def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False):
             part = _scratch(x.device, splits * M * N, "splitk")
             L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part), _PREC["gemm"],
                                          _stream(x.device)), "eg_linear_splitk")
-            return y
-        if M >= PRESPLIT_MIN_ROWS and ldw % 64 == 0:
-            # many rows (128-clip steps: M = 4352): split X to bf16 (hi, lo) tile images ONCE (one pass; shared by every product that consumes
-            # this tensor next -- Q, K and V of a self-attention read the same rows) and run the pre-split product (no split work in the
-            # N/64 consuming workgroups, larger tiles), as the inference path does
-            img = _split_images(x)
-            L.check(lib.eg_linear_presplit(_ptr(img), K, _ptr(wimg), ldw, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), _PREC["gemm"],
-                                           _stream(x.device)), "eg_linear_presplit")
             return y
         L.check(lib.eg_linear(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), 0, 0, _PREC["gemm"],
                               _stream(x.device)), "eg_linear")

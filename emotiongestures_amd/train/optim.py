@@ -37,11 +37,9 @@ class FlatParams:
     def zero_grad(self):
         """Gradients start from None: autograd then hands each parameter a fresh gradient tensor (no torch add into an old one);
         `collect` / the bucket hooks copy it into the flat buffer."""
-        from . import functional as F
         for p in self.params:
             p.grad = None
         self.written.clear()
-        F.clear_split_cache()           # the last step's split images (and the activation they were made from) are not kept across steps
 
     def enable_weight_images(self):
         """Keep the split-bf16 weight images of all Linear / conv3x3 parameters resident and refresh them once per optimiser step."""

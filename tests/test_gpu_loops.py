@@ -81,15 +81,16 @@ def test_evaluate_validation_pass_is_train_mode_batchnorm_and_confusion_is_predi
     idx = np.arange(8)
     ev = loops.evaluate(model, ds, idx, 4, DEV)                                  # eval mode: running statistics untouched, mode restored
     assert model.training and torch.equal(bufs(), before)
+    labels = loops.labels_of(ds, idx)
+    model.eval()
+    with torch.no_grad():                                                        # the same eval-mode predictions, before validation moves the running statistics
+        pred = torch.cat([model(loops._collate(ds, idx[b * 4:(b + 1) * 4], 128)[0].to(DEV)).argmax(1).cpu() for b in range(2)]).numpy()
+    model.train()
     va = loops.evaluate(model, ds, idx, 4, DEV, train_mode_bn=True)             # upstream's validation pass
     assert model.training and not torch.equal(bufs(), before)
     assert all(p.grad is None for p in model.parameters())                       # no_grad: nothing recorded
     assert ev["batches"] == va["batches"] == 2
     # orientation: rows = predicted class, columns = true label
-    labels = loops.labels_of(ds, idx)
-    model.eval()
-    with torch.no_grad():
-        pred = torch.cat([model(loops._collate(ds, idx[b * 4:(b + 1) * 4], 128)[0].to(DEV)).argmax(1).cpu() for b in range(2)]).numpy()
     want = np.zeros((8, 8), dtype=np.int64)
     for p_, t_ in zip(pred, labels):
         want[p_, t_] += 1

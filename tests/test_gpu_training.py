@@ -863,12 +863,13 @@ def test_graphed_step_keeps_its_scratch_buffers_alive():
 
 
 def test_segmented_step_equals_the_single_graph_step():
-    """train/graph.SegmentedStep (forward + backward cut at the tower output into two hipGraph segments + a tail graph, the bucket reductions
-    between them) against GraphedStep (one graph) on one rank: same losses, parameters and moments after the same number of steps; both
-    phases complete buckets, the tower's parameters belong to the second."""
+    """train/graph.SegmentedStep (forward + backward cut at the tower output and at the inputs of the tower's stages: four hipGraph segments + a
+    tail graph, the bucket reductions between them) against GraphedStep (one graph) on one rank: same losses, parameters and moments after the
+    same number of steps; with the buckets cut at the phase boundaries (optim.stage_splits) every phase completes its own buckets and only
+    layer1 + the stem are left for the join."""
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train.graph import GraphedStep, SegmentedStep
-    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters
+    from emotiongestures_amd.train.optim import FlatAdam, GradBuckets, flatten_parameters, stage_splits
     inp = synth_inputs(2, 34, 126, 4, seed=21)
     g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
     label = torch.tensor([2, 6], device=DEV)
@@ -877,7 +878,7 @@ def test_segmented_step_equals_the_single_graph_step():
         model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32").to(DEV).train()
         fp = flatten_parameters(model)
         opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
-        gb = GradBuckets(fp, bucket_mb=25.0).attach()
+        gb = GradBuckets(fp, bucket_mb=25.0, split_at=stage_splits(model, fp) if segmented else ()).attach()
 
         def loss_fn():
             pose, _e, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
@@ -894,9 +895,14 @@ def test_segmented_step_equals_the_single_graph_step():
 
         if segmented:
             ss = SegmentedStep(loss_fn, gb, opt, device=DEV, warmup=2)
-            assert ss.n_segments == 2 and all(ss.ready), ss.ready
-            tower_bucket = gb.param_bucket[fp.index[id(model.audio_encoder.feat_extractor.layer1[0].conv1.weight)]]
-            assert tower_bucket in ss.ready[1] and 0 in ss.ready[0], ss.ready
+            assert ss.n_segments == 4 and all(ss.ready), ss.ready
+            fe = model.audio_encoder.feat_extractor
+            bucket = lambda p: gb.param_bucket[fp.index[id(p)]]
+            assert 0 in ss.ready[0], ss.ready                                                   # the last parameters' bucket: behind the tower
+            assert bucket(fe.layer3[0].conv1.weight) in ss.ready[1] and bucket(model.audio_encoder.fc1.weight) in ss.ready[0], ss.ready
+            assert bucket(fe.layer2[0].conv1.weight) in ss.ready[2] and bucket(fe.layer1[0].conv1.weight) in ss.ready[3], ss.ready
+            assert len({bucket(fe.layer1[0].conv1.weight), bucket(fe.layer2[0].conv1.weight), bucket(fe.layer3[0].conv1.weight)}) == 3
+            assert ss.exposed_bytes() < 0.01 * 4 * fp.grad.numel(), ss.exposed_bytes()         # layer1 + stem: < 1 % of the gradient bytes
             losses = [float(ss.run()) for _ in range(3)]
         else:
             gs = GraphedStep(step, g, opt, warmup=2)
@@ -1319,42 +1325,3 @@ def test_resident_weight_images_match_per_use_packing():
         F.set_precision("f32")
         F.register_weight_images(None)
     assert torch.equal(finals[0], finals[1])
-
-
-def test_linear_on_many_rows_takes_the_presplit_product_and_equals_the_in_kernel_split():
-    """From 2048 rows up (128-clip steps) the training Linear splits its input once (eg_split_tiles, shared by consecutive products on the same
-    rows) and runs the pre-split product; below it the consumer splits in-kernel.  Same three bf16 terms in the same order: forward, input
-    gradient and weight gradient are bitwise those of the two half-size calls."""
-    from emotiongestures_amd.train import functional as F
-    torch.manual_seed(3)
-    M, K, N = 2176, 512, 384
-    x = torch.randn(M, K, device=DEV)
-    w1, w2 = (torch.randn(N, K, device=DEV) * 0.05).requires_grad_(True), (torch.randn(N, K, device=DEV) * 0.05).requires_grad_(True)
-    b = torch.randn(N, device=DEV).requires_grad_(True)
-    dy = torch.randn(M, N, device=DEV)
-    F.set_precision("bf16x3")
-    try:
-        assert M >= F.PRESPLIT_MIN_ROWS
-        F.clear_split_cache()
-        n0 = int(F._lib().eg_launch_count())
-        xa = x.clone().requires_grad_(True)
-        ya = F.linear(xa, w1, b, relu=True)
-        yb = F.linear(xa, w2)                                # same rows again: the images are reused (no second split launch)
-        launches = int(F._lib().eg_launch_count()) - n0
-        assert launches == 3, launches                       # one split + two products
-        (ya * dy).sum().backward()
-        ga, gw, gb = xa.grad.clone(), w1.grad.clone(), b.grad.clone()
-        w1.grad = None; b.grad = None
-        F.clear_split_cache()
-        outs, gxs = [], []
-        for lo, hi in ((0, 1088), (1088, M)):               # 1088 rows: the in-kernel-split product
-            xh = x[lo:hi].clone().requires_grad_(True)
-            yh = F.linear(xh, w1, b, relu=True)
-            (yh * dy[lo:hi]).sum().backward()
-            outs.append(yh.detach()); gxs.append(xh.grad)
-        assert torch.equal(ya.detach(), torch.cat(outs)) and torch.equal(ga, torch.cat(gxs))
-        assert rel(gw, w1.grad) < 1e-6 and rel(gb, b.grad) < 1e-6      # the row split changes the summation order of dW / db only
-        assert bool(torch.isfinite(yb).all())
-    finally:
-        F.set_precision("f32")
-        F.clear_split_cache()
