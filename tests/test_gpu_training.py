@@ -1246,6 +1246,10 @@ def test_bench_train_two_ranks_share_one_gpu_over_gloo(graph):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and np.isfinite(line["final_loss"])
     assert ("hipGraph" in line["launch"]) == graph
+    if graph:       # backward cut at the tower output and per tower stage; only layer1 + the stem are left for the join
+        assert line["launch"].startswith("4 hipGraph segments"), line["launch"]
+        assert 0 < line["allreduce_exposed_bytes_per_step"] < 0.01 * line["config"]["gradient_bytes_per_step"], line
+        assert line["allreduce_exposed_ms_per_step"] is not None
 
 
 def test_eval_after_training_sees_the_updated_weights_and_statistics():
