@@ -124,7 +124,7 @@ def measured_traffic(tag, precision):
     hits = [v for k, v in kern.items() if k.startswith(prefix)]
     if not hits and tag >= 1000 and tag // 1000000 == 32 and (tag // 1000) % 1000 == 32:      # the 32 -> 32 stage runs on the persistent kernel
         hits = [v for k, v in kern.items() if k.startswith("conv3x3_c32_persistent_kernel<3")]       # <TERMS, TH, STAMP>: any tile height, production build
-    return hits[0]["bytes"] if hits else None
+    return max(hits, key=lambda v: v.get("launches_per_step", 0))["bytes"] if hits else None      # several instantiations: the one the step launches most
 
 
 def train_hbm_gb_per_step(batch):
@@ -726,11 +726,15 @@ def main():
             eager_step()                    # per-launch event timing runs eagerly (events are not part of the graph)
         torch.cuda.synchronize(dev)
         lib.eg_profile_disable()
-        tags = np.zeros(cap, np.int64); fl = np.zeros(cap, np.float64); ms = np.zeros(cap, np.float32)
+        tags = np.zeros(cap, np.int64); fl = np.zeros(cap, np.float64); ms = np.zeros(cap, np.float32); wgs = np.zeros(cap, np.int32)
+        lib.eg_profile_read_workgroups(wgs.ctypes.data_as(C.c_void_p), cap)         # before eg_profile_read, which resets the record list
         n = lib.eg_profile_read(tags.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), cap)
         if n < 0:
             _lib.check(n, "eg_profile_read")
-        tags, fl, ms = tags[:n], fl[:n], ms[:n]
+        tags, fl, ms, wgs = tags[:n], fl[:n], ms[:n], wgs[:n]
+        # share of the chip a launch occupies: a product on 68 workgroups (128 x 128 tiles at N = 512) holds a quarter of the 256 CUs for its
+        # duration and the other lanes' convolutions run on the rest; 0 = not recorded (convolutions: grids of >= 512 workgroups)
+        share = np.where(wgs > 0, np.minimum(1.0, wgs / 256.0), 1.0)
         groups = {}
         for tg in np.unique(tags):
             sel = tags == tg
@@ -741,9 +745,16 @@ def main():
         achieved = flop / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         traffic = measured_traffic(dom, args.precision)
+        seld = tags == dom
+        cu_ms = float((ms[seld] * share[seld]).sum())
         roof = {"bound": "mfma", "kernel": kernel_name(dom), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                 "launches_per_step": cnt // max(args.steps, 1), "kernel_ms_per_step_isolated": round(tot_ms / args.steps, 4),
+                # the same launches weighted with the share of the 256 CUs each occupies (workgroups / 256, capped at 1): what the family costs
+                # the step as it is run -- four batches in flight, the rest of the chip busy with other lanes' kernels -- and its rate per occupied CU share
+                "kernel_cu_ms_per_step": round(cu_ms / args.steps, 4), "mean_workgroups_per_launch": round(float(wgs[seld].mean()), 1),
+                "achieved_per_occupied_share": round(float(fl[seld].sum()) / (cu_ms * 1e-3) / 1e12, 2) if cu_ms > 0 else None,
+                "tile_policy": os.environ.get("EG_GEMM_TILE", "auto (128 x 128 from 64 workgroups up, else 64 x 64)"),
                 "flop_per_launch": flop,
                 "by_kernel_ms_per_step": {kernel_name(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())},
                 "by_kernel_tflops": {kernel_name(k): round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in sorted(contraction.items())}}

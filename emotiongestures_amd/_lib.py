@@ -97,6 +97,7 @@ SIGNATURES = {
     "eg_profile_enable": (C.c_int, [_I]),
     "eg_profile_disable": (C.c_int, []),
     "eg_profile_read": (_I, [_P, _P, _P, _I]),
+    "eg_profile_read_workgroups": (_I, [_P, _I]),
     "eg_reparameterize": (C.c_int, [_P, _P, _P, _P, _L, _P]),
     "eg_conv1d": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_contrastive_workspace_bytes": (C.c_int64, [_I]),

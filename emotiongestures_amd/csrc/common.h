@@ -155,6 +155,7 @@ struct EgProfScope {
     int slot;
     hipStream_t st;
     EgProfScope(int64_t tag, double flops, hipStream_t s);
+    void workgroups(int n);          // workgroups of the launch (0 = not recorded: a grid that covers the chip)
     ~EgProfScope();
 };
 

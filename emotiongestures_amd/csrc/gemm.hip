@@ -756,10 +756,14 @@ int presplit_tile_default(int m, int n) {
     if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 64) return TILE_128;
     return TILE_64;
 }
-int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int precision, hipStream_t st) {
+int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int precision, hipStream_t st, EgProfScope* prof = nullptr) {
     const int mt = eg_cdiv(a.M, 64), nt = eg_cdiv(a.N, 64);
     int tile = presplit_tile_override();
     if (tile == TILE_AUTO) tile = presplit_tile_default(a.M, a.N);
+    if (prof) {
+        const int tm = (tile == TILE_64 || tile == TILE_64_R8) ? 1 : 2, tn = (tile == TILE_128 || tile == TILE_128_R4) ? 2 : 1;
+        prof->workgroups(eg_cdiv(mt, tm) * eg_cdiv(nt, tn));
+    }
     const bool x3 = precision == EG_PREC_BF16X3;
     dim3 grid(mt, nt, 1);
     switch (tile) {
@@ -868,9 +872,10 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
-        return dispatch_presplit(a, xhi, xlo, xko, p.precision, st);
+        return dispatch_presplit(a, xhi, xlo, xko, p.precision, st, &prof);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
+    prof.workgroups(eg_cdiv(p.m, 64) * eg_cdiv(p.n, 64));
     return launch_gemm(a, 1, p.precision, st);
 }
 int egi_split_tiles(const float* x, int lda, int m, int k, void* images, hipStream_t st) { return eg_split_tiles(x, lda, m, k, images, st); }
@@ -936,5 +941,5 @@ extern "C" int eg_linear_presplit(const void* x_images, int32_t k_x, const float
     const bf8* xhi = reinterpret_cast<const bf8*>(x_images);
     const bf8* xlo = xhi + (size_t)mt * xko * 64;
     EgProfScope prof(3, 2.0 * m * (double)n * k, (hipStream_t)stream);
-    return dispatch_presplit(a, xhi, xlo, xko, precision, (hipStream_t)stream);
+    return dispatch_presplit(a, xhi, xlo, xko, precision, (hipStream_t)stream, &prof);
 }

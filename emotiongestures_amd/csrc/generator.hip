@@ -53,7 +53,7 @@ int eg_ensure_dynamic_lds(const void* kernel, size_t bytes, const char* who) {
 
 // ---- launch profiler ---------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; int64_t tag; double flops; bool ok; };
+struct ProfRec { hipEvent_t a, b; int64_t tag; double flops; bool ok; int wgs; };
 std::vector<ProfRec> g_prof;
 int g_prof_n = 0;
 bool g_prof_on = false;
@@ -63,7 +63,11 @@ EgProfScope::EgProfScope(int64_t tag, double flops, hipStream_t s) : slot(-1), s
     slot = g_prof_n++;
     g_prof[slot].tag = tag;
     g_prof[slot].flops = flops;
+    g_prof[slot].wgs = 0;
     g_prof[slot].ok = hipEventRecord(g_prof[slot].a, st) == hipSuccess;
+}
+void EgProfScope::workgroups(int n) {
+    if (slot >= 0) g_prof[slot].wgs = n;
 }
 EgProfScope::~EgProfScope() {
     if (slot >= 0 && hipEventRecord(g_prof[slot].b, st) != hipSuccess) g_prof[slot].ok = false;
@@ -73,7 +77,7 @@ extern "C" int eg_profile_enable(int32_t max_records) {
     while ((int)g_prof.size() < max_records) {
         ProfRec r;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { eg_set_error("hipEventCreate failed"); return EG_ERR_HIP; }
-        r.tag = 0; r.flops = 0; r.ok = false;
+        r.tag = 0; r.flops = 0; r.ok = false; r.wgs = 0;
         g_prof.push_back(r);
     }
     g_prof_n = 0;
@@ -81,6 +85,11 @@ extern "C" int eg_profile_enable(int32_t max_records) {
     return EG_OK;
 }
 extern "C" int eg_profile_disable(void) { g_prof_on = false; return EG_OK; }
+extern "C" int32_t eg_profile_read_workgroups(int32_t* workgroups, int32_t capacity) {
+    const int n = g_prof_n < capacity ? g_prof_n : capacity;
+    for (int i = 0; i < n; ++i) workgroups[i] = g_prof[i].wgs;
+    return n;
+}
 extern "C" int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacity) {
     int n = g_prof_n < capacity ? g_prof_n : capacity;
     for (int i = 0; i < n; ++i) {

@@ -67,6 +67,10 @@ int64_t eg_launch_count(void);
 int eg_profile_enable(int32_t max_records);
 int eg_profile_disable(void);
 int32_t eg_profile_read(int64_t* tags, double* flops, float* ms, int32_t capacity);
+/* Workgroups of each recorded launch (0: not recorded -- a grid that covers the chip), in record order; call BEFORE eg_profile_read (which
+ * resets the record list).  A product on 68 workgroups occupies a quarter of the 256 CUs for its duration: bench.py weighs a launch's
+ * duration with min(1, workgroups / 256) when it reports the CU time of a kernel family beside its stand-alone duration. */
+int32_t eg_profile_read_workgroups(int32_t* workgroups, int32_t capacity);
 
 /* ------------------------------------------------------------------------------------------
  * Weight arena.  A model's parameters live in ONE caller-owned fp32 device buffer ("arena")
