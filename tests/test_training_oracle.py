@@ -264,3 +264,29 @@ def test_cvae_gradients_oracle_vs_reference_golden():
     assert abs(loss.item() - float(z["cvae/loss"])) / float(z["cvae/loss"]) < 1e-5
     assert np.abs(mu.detach().numpy() - z["cvae/mu"]).max() < 1e-4
     _check_fingerprints(z, "cvae", sd, 2e-4)
+
+
+def test_stage_splits_cut_the_generators_buckets_at_the_tower_stage_boundaries():
+    """optim.stage_splits on the real TED generator (CPU, no kernels): four parameter starts -- layer2, layer3, what follows layer3 inside the
+    audio encoder, the first module behind the audio encoder -- and GradBuckets(split_at=...) ends a bucket at each, so that the stem + layer1,
+    layer2, layer3 and the encoder's Linear head land in four different buckets (the phases of train/graph.SegmentedStep's default cuts)."""
+    from emotiongestures_amd.builders import build_mirror
+    from emotiongestures_amd.train.optim import GradBuckets, flatten_parameters, stage_splits
+    model = build_mirror("spatial", 34, 126, 4, 4, seed=0, precision="f32")
+    fp = flatten_parameters(model)
+    splits = stage_splits(model, fp)
+    assert len(splits) == 4 and splits == sorted(splits) and all(o in fp.offsets for o in splits)
+    fe = model.audio_encoder.feat_extractor
+    off = lambda p: fp.offsets[fp.index[id(p)]]
+    assert splits[0] == off(fe.layer2[0].conv1.weight) and splits[1] == off(fe.layer3[0].conv1.weight)
+    assert splits[2] == off(model.audio_encoder.final_conv1.weight)
+    gb = GradBuckets(fp, bucket_mb=25.0, split_at=splits)
+    starts = {lo for lo, _ in gb.buckets}
+    assert set(splits) <= starts
+    bucket = lambda p: gb.param_bucket[fp.index[id(p)]]
+    tower = [bucket(fe.conv1.weight), bucket(fe.layer1[0].conv1.weight), bucket(fe.layer2[0].conv1.weight), bucket(fe.layer3[0].conv1.weight),
+             bucket(model.audio_encoder.fc1.weight)]
+    assert tower[0] == tower[1] and len(set(tower[1:])) == 4, tower
+    plain = GradBuckets(fp, bucket_mb=25.0)
+    assert len(gb.buckets) > len(plain.buckets)                     # the unforced layout puts the whole tower into the last bucket
+    assert plain.param_bucket[fp.index[id(fe.layer3[0].conv1.weight)]] == plain.param_bucket[fp.index[id(fe.conv1.weight)]]
