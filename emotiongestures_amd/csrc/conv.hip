@@ -1027,9 +1027,7 @@ int launch_conv32_persistent_t(const ConvArgs& a, int batch, const bf8* whi, con
     auto kern = conv3x3_c32_persistent_kernel<TERMS, TH>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (32 -> 32, persistent)")) return rc;
     const int total = a.tiles * batch;
-    int cap = 512;                                               // 2 workgroups per CU
-    if (const char* e = getenv("EG_CONV32_GRID")) cap = atoi(e) > 0 ? atoi(e) : 512;      // occupancy experiment (tools/bench_ops.py)
-    int grid = total < cap ? total : cap;
+    int grid = total < 512 ? total : 512;                        // 2 workgroups per CU
     int tpw = eg_cdiv(total, grid);
     grid = eg_cdiv(total, tpw);
     if (grid >= 8) grid = (int)eg_round_up(grid, 8);             // XCD remap needs a multiple of 8 (surplus workgroups exit at once)
