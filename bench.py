@@ -247,22 +247,28 @@ def gpu_b1_latency(gen, vae, mel, inp, sd_g, sd_v, dev, reps=50):
     from emotiongestures_amd.pipeline import ClipPipeline
     from oracle import emogest_oracle as O
     g1 = {k: torch.from_numpy(v[:1]).to(dev) for k, v in inp.items()}
-    pipe = ClipPipeline((gen, vae, mel), g1, dev, lanes=1)
-    for _ in range(5):
-        pipe.wait(pipe.launch_next())
-    lat = []
-    for _ in range(reps):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        pipe.wait(pipe.launch_next())
-        lat.append((time.perf_counter() - t0) * 1e3)
-    pose = pipe.outputs(0)[0].cpu().numpy()
+    lat_by_mode = {}
+    for branch in (False, True):            # one lane alone: forking the text / prior / CVAE branches onto side streams may shorten the critical path
+        pipe = ClipPipeline((gen, vae, mel), g1, dev, lanes=1, branch_streams=branch)
+        for _ in range(5):
+            pipe.wait(pipe.launch_next())
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            pipe.wait(pipe.launch_next())
+            ts.append((time.perf_counter() - t0) * 1e3)
+        lat_by_mode[branch] = (float(np.median(ts)), float(np.min(ts)), pipe.outputs(0)[0].cpu().numpy())
+        del pipe
+    best = min(lat_by_mode, key=lambda k: lat_by_mode[k][0])
+    pose = lat_by_mode[best][2]
     with torch.no_grad():
         t1 = {k: torch.from_numpy(v[:1]) for k, v in inp.items() if k != "audio"}
         spec = torch.from_numpy(O.melspectrogram(inp["audio"][:1], out_frames=124))
         ref = O.generator_forward(sd_g, O.GenCfg(), spec, t1["text"], t1["pre_pose"], O.cvae_sample(sd_v, t1["label"], t1["z"]))[0]
-    return {"latency_ms_median": round(float(np.median(lat)), 4), "latency_ms_min": round(float(np.min(lat)), 4), "reps": reps,
-            "clips_per_step": 1, "launch": "hipGraph replay, 1 lane, synchronised per clip",
+    return {"latency_ms_median": round(lat_by_mode[best][0], 4), "latency_ms_min": round(lat_by_mode[best][1], 4), "reps": reps,
+            "clips_per_step": 1, "launch": "hipGraph replay, 1 lane, synchronised per clip, " + ("branch streams" if best else "one stream"),
+            "latency_ms_median_one_stream": round(lat_by_mode[False][0], 4), "latency_ms_median_branch_streams": round(lat_by_mode[True][0], 4),
             "pose_rel_l2_vs_cpu_oracle": clip_rel_l2(pose, ref.numpy())}
 
 
