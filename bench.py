@@ -169,6 +169,8 @@ def parse_args():
     ap.add_argument("--no-train-graph", action="store_true",
                     help="--train: issue every kernel through autograd instead of replaying the step from one captured hipGraph")
     ap.add_argument("--train-graph", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--no-train-dropout", action="store_true",
+                    help="--train: run the step with every Dropout at p = 0 (the gradient-parity configuration) instead of the reference's train() graph")
     ap.add_argument("--train-batch", type=int, default=16, help="clips per GPU per training step (16 = global 128 on 8 GPUs, SURVEY.md §8d cfg 3)")
     return ap.parse_args()
 
@@ -497,7 +499,8 @@ def train_worker(args, rank, world, dev, dist, backend):
     launch mode the flags name (default: split-bf16 MFMA, the step replayed from captured hipGraphs); `f32_eager` is the
     gradient-parity configuration (fp32 operators issued through autograd) timed in the same run."""
     B = args.train_batch
-    main_leg = train_leg(dev, B, args.train_precision, not args.no_train_graph, args.steps, args.warmup, rank, world, dist, backend)
+    main_leg = train_leg(dev, B, args.train_precision, not args.no_train_graph, args.steps, args.warmup, rank, world, dist, backend,
+                         dropout=not args.no_train_dropout)
     parity = None
     if not args.no_extra_legs and (args.train_precision != "f32" or not args.no_train_graph):
         parity = train_leg(dev, B, "f32", False, args.steps, args.warmup, rank, world, dist, backend)
@@ -514,7 +517,7 @@ def train_worker(args, rank, world, dev, dist, backend):
             "config": {"workload": "TED clips: spec(128x124) + prior poses -> generator (train mode) -> 100*smooth_l1(pose) + CE(emotion); emotion map -> CVAE (train mode) -> smooth_l1(recon) + KLD; backward -> Adam",
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (25 MB buckets, backward order, side stream)",
                        "trainable_parameters": nparam, "gradient_bytes_per_step": 4 * nparam, "buckets": nb},
-            "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"],
+            "dropout": main_leg["dropout"], "final_loss": main_leg["final_loss"], "allreduce_exposed_ms_per_step": main_leg["allreduce_exposed_ms_per_step"],
             "allreduce_exposed_bytes_per_step": main_leg["allreduce_exposed_bytes_per_step"], "launch": main_leg["launch"],
             "library_launches_per_step": main_leg["library_launches_per_step"], "algorithmic_tflops_per_gpu": main_leg["algorithmic_tflops_per_gpu"],
             "frac_of_mfma_peak": main_leg["frac_of_mfma_peak"]}

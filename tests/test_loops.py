@@ -69,3 +69,26 @@ def test_checkpoint_name_and_alpha_mode_guard(tmp_path):
     assert loops.checkpoint_name("/x", 2, 0, 100) == "/x/checkpoint_fold2_epoch0_iteraction100.pth"  # upstream's spelling (:196)
     with pytest.raises(ValueError):
         loops.train_k_fold([], device="cpu", batch_size=4, alpha_mode="positional")
+
+
+def test_precision_scope_and_reset_state_are_exception_safe():
+    """The training layer's configuration is per process (autograd's backward thread must see the forward's): drivers use the context manager /
+    reset_state so that a failure in one model's step cannot leak its arithmetic mode into the next (emotiongestures_amd/train/functional.py)."""
+    from emotiongestures_amd.train import functional as F
+    assert F.get_precision() == "f32"
+    with F.precision("bf16x3"):
+        assert F.get_precision() == "bf16x3"
+        with F.precision("f32"):
+            assert F.get_precision() == "f32"
+        assert F.get_precision() == "bf16x3"
+    assert F.get_precision() == "f32"
+    with pytest.raises(RuntimeError):
+        with F.precision("bf16x3"):
+            raise RuntimeError("step failed")
+    assert F.get_precision() == "f32"
+    with pytest.raises(ValueError):
+        F.precision("fp8").__enter__()
+    F.set_precision("bf16x3")
+    F.manual_seed(7)
+    F.reset_state()
+    assert F.get_precision() == "f32" and F._DROP["seed"] == 0 and F._DROP["epoch"] is None and not F._IMAGES["reg"]
