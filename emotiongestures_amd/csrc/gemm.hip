@@ -324,22 +324,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 //    fragment reads (16 consecutive rows, same octet) are bank-conflict free; split to (hi, lo) bf16 in registers.
 //  * W: tile-planar bf16 images as above (4 octets per step = 4 contiguous 1-KiB pieces per image).
 //  Rows >= M are clamped (their results are never stored); k >= K is clamped to finite data (the packed weights are zero there).
-template <int TERMS>
+// WN = MFMA tiles of a wave along N: 2 -> 64 (M) x 64 (N) workgroup tile (static 64 KB of LDS, two workgroups per CU); 4 -> 64 x 128 (two
+// 64-row weight image tiles; a wave owns 32 x 64): every X fragment a wave splits now feeds 8 MFMA triples instead of 4 -- the in-kernel split
+// (7-8 vector instructions per MFMA in the 64 x 64 shape) is what paces this kernel -- and X is re-read by half as many workgroups.
+template <int TERMS, int WN = 2>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
-    constexpr int RING = 4, XS = 64 * 8, WS = NIMG * 4 * 64, SLOT = XS + WS;      // 16-byte slots
-    constexpr int G = 2 + NIMG;                                                    // LDS-DMA instructions per wave per step
-    __shared__ f4 lds[RING * SLOT];
+    constexpr int TN = WN / 2;                                                     // 64-row weight image tiles per workgroup
+    constexpr int RING = (WN == 2) ? 4 : 3, XS = 64 * 8, WIMG = 4 * 64, WS = TN * NIMG * WIMG, SLOT = XS + WS;      // 16-byte slots
+    constexpr int G = 2 + TN * NIMG;                                               // LDS-DMA instructions per wave per step
+    extern __shared__ __attribute__((aligned(16))) bf8 lds_raw[];                  // RING * SLOT slots of 16 bytes (bf8 and f4 alike)
+    f4* const lds = reinterpret_cast<f4*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     xcd_tile(bx, by);
-    const int m0 = bx * 64, n0 = by * 64;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int m0 = bx * 64, n0 = by * 64 * TN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * (16 * WN);
     const int kbeg = blockIdx.z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nsteps = (kend - kbeg + 31) / 32;
     const int KO = a.ldw >> 3;
+    const int nt_last = ((a.N + 63) >> 6) - 1;
 
     // X copy role of this lane: rows (p*4 + wave)*8 + (lane>>3), swizzled quad
     const float* xsrc[2];
@@ -361,29 +367,28 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[p] + k),
                                              (__attribute__((address_space(3))) void*)(X + (p * 4 + wave) * 64), 16, 0, 0);
         }
-        const size_t gbase = ((size_t)by * KO + (k0 >> 3)) * 64 + wave * 64 + lane;
         bf8* W = reinterpret_cast<bf8*>(X + XS);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gbase),
-                                         (__attribute__((address_space(3))) void*)(W + wave * 64), 16, 0, 0);
-        if (TERMS == 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gbase),
-                                             (__attribute__((address_space(3))) void*)(W + 256 + wave * 64), 16, 0, 0);
-    };
-    auto wait_groups = [&](int groups_in_flight) {      // all but the youngest `groups_in_flight` step groups have landed
-        if (groups_in_flight >= 2) {
-            if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if (groups_in_flight == 1) {
-            if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {            // weight image tile t of this workgroup (past the last tile: re-read it, those columns are never stored)
+            const size_t gbase = ((size_t)min(by * TN + t, nt_last) * KO + (k0 >> 3)) * 64 + wave * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.whi) + gbase),
+                                             (__attribute__((address_space(3))) void*)(W + t * NIMG * WIMG + wave * 64), 16, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const bf8*>(a.wlo) + gbase),
+                                                 (__attribute__((address_space(3))) void*)(W + t * NIMG * WIMG + WIMG + wave * 64), 16, 0, 0);
         }
     };
+    auto wait_groups = [&](int groups_in_flight) {      // all but the youngest `groups_in_flight` step groups have landed
+        if (groups_in_flight >= 2) wait_vmcnt_imm<2 * G>();
+        else if (groups_in_flight == 1) wait_vmcnt_imm<G>();
+        else wait_vmcnt_imm<0>();
+    };
 
-    f4 acc[2][2];
+    f4 acc[2][WN];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < WN; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int pre = min(nsteps, RING - 1);
     for (int s = 0; s < pre; ++s) issue(s, s);
@@ -392,10 +397,10 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     const int fsw = (li ^ (li >> 1)) & 7;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
-        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) & (RING - 1));
-        const f4* X = lds + (s & (RING - 1)) * SLOT;
+        if (s + RING - 1 < nsteps) issue(s + RING - 1, (s + RING - 1) % RING);
+        const f4* X = lds + (s % RING) * SLOT;
         const bf8* W = reinterpret_cast<const bf8*>(X + XS);
-        bf8 xh[2], xl[2], wh[2], wl[2];
+        bf8 xh[2], xl[2], wh[WN], wl[WN];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const f4* xr = X + (wm + t * 16 + li) * 8;
@@ -403,14 +408,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
             split_octet<TERMS == 3>(q0, q1, xh[t], xl[t]);
         }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            wh[n] = W[kq * 64 + wn + n * 16 + li];
-            if (TERMS == 3) wl[n] = W[256 + kq * 64 + wn + n * 16 + li];
+        for (int n = 0; n < WN; ++n) {
+            const int col = wn + n * 16, tile = col >> 6, r = (col & 63) + li;
+            wh[n] = W[tile * NIMG * WIMG + kq * 64 + r];
+            if (TERMS == 3) wl[n] = W[tile * NIMG * WIMG + WIMG + kq * 64 + r];
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < WN; ++n) {
                 if (TERMS == 3) {
                     acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xh[t], acc[t][n], 0, 0, 0);
                     acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], xl[t], acc[t][n], 0, 0, 0);
@@ -423,7 +429,18 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this step's LDS reads are done before the slot is reused
         wg_barrier();
     }
-    gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+    gemm_epilogue<2, WN>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+}
+
+template <int TERMS, int WN>
+int launch_glds(const GemmArgs& a, int splits, hipStream_t st) {
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1, TN = WN / 2, RING = (WN == 2) ? 4 : 3;
+    constexpr size_t LDS_BYTES = (size_t)RING * (64 * 8 + TN * NIMG * 4 * 64) * 16;
+    auto kern = gemm_glds_kernel<TERMS, WN>;
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_glds")) return rc;
+    dim3 grid(eg_cdiv(a.M, 64), eg_cdiv(a.N, 64 * TN), splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a);
+    return eg_check_launch("gemm_glds");
 }
 
 // ---- split-bf16 path with PRE-SPLIT activations ---------------------------------------------------------------------
@@ -819,8 +836,13 @@ int launch_gemm(GemmArgs& a, int splits, int precision, hipStream_t st) {
         if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_bf16_kernel<3>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gemm_bf16_kernel<1>), grid, block, 0, st, a);
     } else {
-        if (precision == EG_PREC_BF16X3) hipLaunchKernelGGL((gemm_glds_kernel<3>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gemm_glds_kernel<1>), grid, block, 0, st, a);
+        // 64 x 128 workgroup tile once the launch has >= 256 workgroups of that shape (one per CU): 128-clip training steps (M = 4352); below that
+        // the 64 x 64 tile's doubled workgroup count wins.  Same-box A/B of the 128-clip training step, alternating: 28.36 / 28.44 ms (wide) vs
+        // 28.61 / 28.72 ms (64 x 64).  EG_GLDS_TILE = "0" | "1" forces one (A/B runs).  Same K order per output element: bitwise-identical results.
+        bool wide = (long)eg_cdiv(a.M, 64) * eg_cdiv(a.N, 128) * splits >= 256;
+        if (const char* e = getenv("EG_GLDS_TILE")) wide = e[0] == '1';
+        if (precision == EG_PREC_BF16X3) return wide ? launch_glds<3, 4>(a, splits, st) : launch_glds<3, 2>(a, splits, st);
+        return wide ? launch_glds<1, 4>(a, splits, st) : launch_glds<1, 2>(a, splits, st);
     }
     return eg_check_launch("gemm");
 }

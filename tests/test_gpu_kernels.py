@@ -279,6 +279,34 @@ def test_linear_presplit_tile_variants_are_bitwise_equal(prec, M, N, K, monkeypa
         assert torch.equal(outs[tile], outs["64"]), tile
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(4352, 2048, 512), (4352, 512, 2048), (200, 320, 96), (130, 100, 36)])
+def test_linear_wide_tile_of_the_in_kernel_split_product_is_bitwise_equal(prec, M, N, K, monkeypatch):
+    """eg_linear on fp32 input (X split per consuming workgroup) has a 64 x 64 and a 64 x 128 workgroup tile (chosen by size; EG_GLDS_TILE forces
+    one): same K order per output element, so the results are bitwise identical -- also with ragged M / N, odd tile counts and a short K."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd import ops
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    x, w = T("gx", (M, K)), T("gw", (N, K), -0.1, 0.1)
+    bias, res = T("gb", (N,)), T("gr", (M, N))
+    xd, rd = x.to(dev()), res.to(dev())
+    wp, npad, kpad = ops.pack_linear_weight(w, dev())
+    bp = torch.zeros(npad, device=dev()); bp[:N] = bias.to(dev())
+    outs = {}
+    for tile in ("0", "1"):
+        monkeypatch.setenv("EG_GLDS_TILE", tile)
+        y = torch.full((M, N), float("nan"), device=dev())
+        L.check(lib.eg_linear(_ptr(xd), K, _ptr(wp), kpad, _ptr(bp), _ptr(rd), None, N, _ptr(y), N, M, N, K, 1, 0, 0, L.precision_code(prec), _stream(dev())),
+                "eg_linear tile " + tile)
+        torch.cuda.synchronize()
+        outs[tile] = y
+    monkeypatch.delenv("EG_GLDS_TILE")
+    ref = torch.relu(x.double() @ w.double().T + bias.double() + res.double())
+    assert rel_l2(outs["0"].cpu().numpy(), ref.numpy()) < TOL[prec]
+    assert torch.equal(outs["1"], outs["0"])
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 def test_linear_random_shapes(prec):
     """eg_linear over 24 seeded shapes (ragged M / N, K not a multiple of the 32-deep step) vs float64, all epilogue options."""
