@@ -87,6 +87,7 @@ SIGNATURES = {
     "eg_linear_splitk": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "eg_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_attention": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_attention_masked": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _L, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_mha_workspace_bytes": (_L, [_I, _I, _I, _I, _I]),
     "eg_multi_head_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_ffn_workspace_bytes": (_L, [_I, _I, _I]),

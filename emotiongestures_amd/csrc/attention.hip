@@ -26,11 +26,14 @@ constexpr int ATT_P = 68;       // Q / K row pitch in floats
 // DROP (training only, Modules.py:21 `attn = self.dropout(F.softmax(attn, dim=-1))`): the probabilities are masked with the counter-based
 // dropout of common.h (counter = linear index of (clip, head, query, key)) before the P V product; `attn` receives the UNMASKED probabilities
 // (what the backward kernel needs: it recomputes the mask).
+// Optional mask (Modules.py:18-19: `attn = attn.masked_fill(mask == 0, -1e9)` before the softmax): bytes [batch][1 or Lq][Lk], 0 = masked;
+// sq = 0 broadcasts one key row over the queries (MultiHeadAttention unsqueezes the head axis, SubLayers.py:44-45).  The path itself always passes None.
+struct EgAttMask { const unsigned char* m = nullptr; long long sb = 0; int sq = 0; };
 template <int PREC, int KT, bool DROP = false>     // KT = key tiles of 16 (Lk <= 16*KT)
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                              const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
                                                              float* __restrict__ attn, int H, int Lq, int Lk, float inv_temp,
-                                                             unsigned short* __restrict__ oimg, int rows_total, EgDropout dr) {
+                                                             unsigned short* __restrict__ oimg, int rows_total, EgDropout dr, EgAttMask mk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int LKP = KT * 16;            // padded key count
     constexpr int VP = LKP + 4;             // V^T row pitch (floats): 16-byte aligned rows, consecutive d rows 4 banks apart
@@ -97,6 +100,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[st], s[t], 0, 0, 0);
                 }
             }
+        }
+        if (mk.m) {         // masked_fill(mask == 0, -1e9): the literal, so that a fully masked row softmaxes to uniform as upstream's does
+            const unsigned char* mrow = mk.m + (size_t)b * mk.sb + (size_t)min(q0 + qt * 16 + li, Lq - 1) * mk.sq;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = t * 16 + 4 * g + r;
+                    if (kk < Lk && mrow[kk] == 0) s[t][r] = -1.0e9f;
+                }
         }
         // ---- softmax over k (torch.softmax(dim=-1), Modules.py:21): row max, exp, row sum, normalise
         float m = -3.0e38f;
@@ -201,23 +214,24 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 
 template <int PREC, int KT, bool DROP = false>
 int launch_att(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, float* attn, void* oimg,
-               int batch, int heads, int lq, int lk, float inv_temp, hipStream_t st, EgDropout dr = EgDropout()) {
+               int batch, int heads, int lq, int lk, float inv_temp, hipStream_t st, EgDropout dr = EgDropout(), EgAttMask mk = EgAttMask()) {
     constexpr size_t smem = sizeof(float) * ((size_t)ATT_QC * ATT_P + (size_t)KT * 16 * ATT_P + (size_t)64 * (KT * 16 + 4));
     auto kern = attention_mfma_kernel<PREC, KT, DROP>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "eg_attention")) return rc;
     dim3 grid(eg_cdiv(lq, ATT_QC), heads, batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q, ldq, k, ldk, v, ldv, out, ldo, attn, heads, lq, lk, inv_temp,
-                       reinterpret_cast<unsigned short*>(oimg), batch * lq, dr);
+                       reinterpret_cast<unsigned short*>(oimg), batch * lq, dr, mk);
     return eg_check_launch("attention");
 }
 
 template <int PREC>
 int launch_att_kt(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, float* attn, void* oimg,
-                  int batch, int heads, int lq, int lk, float inv_temp, hipStream_t st) {
-    if (lk <= 48) return launch_att<PREC, 3>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st);
-    if (lk <= 64) return launch_att<PREC, 4>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st);
-    if (lk <= 128) return launch_att<PREC, 8>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st);
-    return launch_att<PREC, 16>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st);
+                  int batch, int heads, int lq, int lk, float inv_temp, hipStream_t st, EgAttMask mk = EgAttMask()) {
+    const EgDropout nd;
+    if (lk <= 48) return launch_att<PREC, 3>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st, nd, mk);
+    if (lk <= 64) return launch_att<PREC, 4>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st, nd, mk);
+    if (lk <= 128) return launch_att<PREC, 8>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st, nd, mk);
+    return launch_att<PREC, 16>(q, ldq, k, ldk, v, ldv, out, ldo, attn, oimg, batch, heads, lq, lk, inv_temp, st, nd, mk);
 }
 
 }  // namespace
@@ -242,6 +256,26 @@ extern "C" int eg_attention(const float* q, int32_t ldq, const float* k, int32_t
                             float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
                             int32_t dk, int32_t precision, void* stream) {
     return egi_attention(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, dk, precision, (hipStream_t)stream);
+}
+
+extern "C" int eg_attention_masked(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const uint8_t* mask,
+                                   int64_t mask_batch_stride, int32_t mask_query_stride, float* out, int32_t ldo, float* attn, int32_t batch,
+                                   int32_t heads, int32_t lq, int32_t lk, int32_t dk, int32_t precision, void* stream) {
+    EG_REQUIRE(q && k && v && out && mask && batch > 0 && heads > 0 && lq > 0 && lk > 0, EG_ERR_BAD_ARG, "eg_attention_masked: null pointer or empty shape");
+    EG_REQUIRE(dk == 64, EG_ERR_UNSUPPORTED, "eg_attention_masked: d_k=%d (64 supported)", dk);
+    EG_REQUIRE(lk <= 256, EG_ERR_UNSUPPORTED, "eg_attention_masked: Lk=%d > 256", lk);
+    EG_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, EG_ERR_ALIGN, "eg_attention_masked: row strides must be multiples of 4");
+    EG_REQUIRE(eg_aligned16(q) && eg_aligned16(k) && eg_aligned16(v) && eg_aligned16(out), EG_ERR_ALIGN, "eg_attention_masked: 16-byte alignment");
+    EG_REQUIRE(precision >= 0 && precision <= 2, EG_ERR_BAD_ARG, "eg_attention_masked: precision %d", precision);
+    EG_REQUIRE(mask_query_stride == 0 || mask_query_stride >= lk, EG_ERR_BAD_ARG, "eg_attention_masked: query stride %d (0 = one row per clip, else >= Lk)", mask_query_stride);
+    EgAttMask mk;
+    mk.m = mask; mk.sb = mask_batch_stride; mk.sq = mask_query_stride;
+    const float inv_temp = 1.0f / sqrtf((float)dk);
+    hipStream_t st = (hipStream_t)stream;
+    EgProfScope prof(6, 4.0 * batch * heads * (double)lq * lk * dk, st);
+    if (precision == EG_PREC_F32) return launch_att_kt<EG_PREC_F32>(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, inv_temp, st, mk);
+    if (precision == EG_PREC_BF16X3) return launch_att_kt<EG_PREC_BF16X3>(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, inv_temp, st, mk);
+    return launch_att_kt<EG_PREC_BF16>(q, ldq, k, ldk, v, ldv, out, ldo, attn, nullptr, batch, heads, lq, lk, inv_temp, st, mk);
 }
 
 // ---- training: forward with dropout on the probabilities, MFMA backward -------------------------------------------------------------------

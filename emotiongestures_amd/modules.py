@@ -253,7 +253,7 @@ class ResNetSE(nn.Module):
 # transformer blocks
 # ------------------------------------------------------------------------------------------------
 class ScaledDotProductAttention(nn.Module):
-    """Full_model/Modules.py:5-23 (mask must be None: it always is on this path)."""
+    """Full_model/Modules.py:5-23 (the gesture path always passes mask = None; a mask is honoured: masked_fill(mask == 0, -1e9))."""
 
     def __init__(self, temperature, attn_dropout=0.1):
         super().__init__()
@@ -262,13 +262,11 @@ class ScaledDotProductAttention(nn.Module):
 
     def forward(self, q, k, v, mask=None):
         _eval_only(self)
-        if mask is not None:
-            raise NotImplementedError("attention mask is not used on the EmotionGesture path (Models_spatial_memory.py:574)")
         b, h, lq, d = q.shape
         if abs(self.temperature - d ** 0.5) > 1e-6:
             raise NotImplementedError("temperature must be sqrt(d_k)")
         flat = lambda t: t.transpose(1, 2).reshape(t.shape[0], t.shape[2], h * d)
-        out, attn = ops.attention(flat(q), flat(k), flat(v), h, want_attn=True)
+        out, attn = ops.attention(flat(q), flat(k), flat(v), h, want_attn=True, mask=mask)
         return out.view(b, lq, h, d).transpose(1, 2), attn
 
 
@@ -289,12 +287,26 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, q, k, v, mask=None):
         _eval_only(self)
-        if mask is not None or (k is not v and not torch.equal(k, v)):
-            raise NotImplementedError("HIP MultiHeadAttention: mask=None and k is v, as on the reference path")
+        if k is not v and not torch.equal(k, v):
+            raise NotImplementedError("HIP MultiHeadAttention: k is v, as on the reference path")
         ws = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight)
         ver = (str(q.device),) + tuple(w._version for w in ws)
         if getattr(self, "_pack", None) is None or self._pack[0] != ver:        # packed once per weight version (standalone use)
             self._pack = (ver, [ops.pack_linear_weight(w, q.device)[0] for w in ws])
+        if mask is not None:
+            # the fused block (eg_multi_head_attention) has no mask argument -- the path never passes one; with a mask the same kernels run
+            # operator by operator: projections, masked attention (SubLayers.py:44-47: the head axis is broadcast), output projection +
+            # residual, LayerNorm
+            B, Lq, D = q.shape
+            pk = self._pack[1]
+            lin = lambda x, w, p, res=None: ops.linear(x.reshape(-1, x.shape[-1]).contiguous(), w, None, res1=res, precision=self.precision,
+                                                       packed=(p, (w.shape[0] + 63) // 64 * 64, (w.shape[1] + 63) // 64 * 64))
+            qp = lin(q, ws[0], pk[0]).view(B, Lq, -1)
+            kp = lin(k, ws[1], pk[1]).view(B, k.shape[1], -1)
+            vp = lin(v, ws[2], pk[2]).view(B, v.shape[1], -1)
+            o, attn = ops.attention(qp, kp, vp, self.n_head, want_attn=True, precision=self.precision, mask=mask)
+            pre = lin(o, ws[3], pk[3], res=q.reshape(-1, D).contiguous())
+            return ops.layernorm(pre, self.layer_norm.weight, self.layer_norm.bias, eps=1e-6).view(B, Lq, D), attn
         return ops.multi_head_attention(q, k, *ws, self.layer_norm.weight, self.layer_norm.bias, self.n_head, self.precision,
                                         packed=self._pack[1])
 

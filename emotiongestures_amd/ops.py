@@ -168,8 +168,24 @@ def layernorm(x, gamma, beta, eps=1e-6):
     return y
 
 
-def attention(q, k, v, heads: int, want_attn=False, precision="f32"):
-    """q [B,Lq,H*64], k/v [B,Lk,H*64] -> out [B,Lq,H*64] (Full_model/Modules.py:13-23); both products on MFMA in `precision`."""
+def _attention_mask_bytes(mask, B, Lq, Lk, dev):
+    """The reference's mask ([B, Lq, Lk], [B, 1, Lk] or anything broadcastable to one of them; `mask == 0` = masked, Modules.py:18-19) as the
+    contiguous uint8 array eg_attention_masked reads: returns (bytes [B, 1 or Lq, Lk], batch stride, query stride)."""
+    m = mask
+    if m.dim() == 4:                      # already unsqueezed for the head axis (SubLayers.py:44-45)
+        if m.shape[1] != 1:
+            raise NotImplementedError("attention mask: per-head masks are not used by the reference (the head axis is broadcast)")
+        m = m[:, 0]
+    if m.dim() == 2:
+        m = m[:, None, :]
+    rows = Lq if m.shape[1] != 1 else 1
+    m = (m != 0).expand(B, rows, Lk).to(device=dev, dtype=torch.uint8).contiguous()
+    return m, rows * Lk, (Lk if rows > 1 else 0)
+
+
+def attention(q, k, v, heads: int, want_attn=False, precision="f32", mask=None):
+    """q [B,Lq,H*64], k/v [B,Lk,H*64] -> out [B,Lq,H*64] (Full_model/Modules.py:13-23); both products on MFMA in `precision`.
+    mask: the reference's optional mask (masked_fill(mask == 0, -1e9) before the softmax)."""
     lib = L.load()
     q, k, v = _need_cuda(q, "q"), _need_cuda(k, "k"), _need_cuda(v, "v")
     dev = q.device
@@ -177,6 +193,11 @@ def attention(q, k, v, heads: int, want_attn=False, precision="f32"):
     Lk = k.shape[1]
     out = torch.empty_like(q)
     attn = torch.empty(B, heads, Lq, Lk, device=dev) if want_attn else None
+    if mask is not None:
+        mb, sb, sq = _attention_mask_bytes(mask, B, Lq, Lk, dev)
+        L.check(lib.eg_attention_masked(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(mb), sb, sq, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk,
+                                        D // heads, L.precision_code(precision), _stream(dev)), "eg_attention_masked")
+        return (out, attn) if want_attn else out
     L.check(lib.eg_attention(_ptr(q), D, _ptr(k), D, _ptr(v), D, _ptr(out), D, _ptr(attn), B, heads, Lq, Lk, D // heads,
                              L.precision_code(precision), _stream(dev)), "eg_attention")
     return (out, attn) if want_attn else out

@@ -311,6 +311,14 @@ int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y
 int eg_attention(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv,
                  float* out, int32_t ldo, float* attn, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
                  int32_t dk, int32_t precision, void* stream);
+/* The same with the reference's mask argument (Modules.py:18-19: `attn = attn.masked_fill(mask == 0, -1e9)` before the softmax): mask bytes
+ * [batch][1 or lq][lk], 0 = masked; mask_query_stride = 0 broadcasts one key row per clip over the queries, else it is the byte distance of
+ * consecutive query rows (>= lk); mask_batch_stride the byte distance of consecutive clips.  The head axis is broadcast, as
+ * MultiHeadAttention.forward does with `mask.unsqueeze(1)` (SubLayers.py:44-45).  The gesture path itself always passes mask = None
+ * (Models_spatial_memory.py:574,611); this entry exists so that Encoder / Decoder / MultiHeadAttention keep their full signature. */
+int eg_attention_masked(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const uint8_t* mask,
+                        int64_t mask_batch_stride, int32_t mask_query_stride, float* out, int32_t ldo, float* attn, int32_t batch,
+                        int32_t heads, int32_t lq, int32_t lk, int32_t dk, int32_t precision, void* stream);
 
 /* MultiHeadAttention.forward (Full_model/SubLayers.py:30-59): LN(fc(attn(q Wq, k Wk, v Wv)) + q).
  * xq [B*Lq, D], xkv [B*Lk, D]; wq/wk/wv packed nn.Linear [heads*64, D], wo packed [D, heads*64] (d_k = d_v = 64; D need not

@@ -221,16 +221,20 @@ def prior_memory_encoder(sd: SD, p: str, prior: torch.Tensor, cfg: GenCfg) -> to
 # a7-a10  transformer
 # --------------------------------------------------------------------------------------------
 
-def multi_head_attention(sd: SD, p: str, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cfg: GenCfg):
+def multi_head_attention(sd: SD, p: str, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cfg: GenCfg, mask: Optional[torch.Tensor] = None):
     """MultiHeadAttention.forward, Full_model/SubLayers.py:30-59; ScaledDotProductAttention.forward,
-    Full_model/Modules.py:13-23 (q is divided by sqrt(d_k) before the product; mask is None)."""
+    Full_model/Modules.py:13-23 (q is divided by sqrt(d_k) before the product).  mask (None on the gesture path): unsqueezed for the head
+    axis (SubLayers.py:44-45), then `attn.masked_fill(mask == 0, -1e9)` before the softmax (Modules.py:18-19)."""
     b, lq, lk = q.shape[0], q.shape[1], k.shape[1]
     h, dk, dv = cfg.n_head, cfg.d_k, cfg.d_v
     residual = q
     qh = F.linear(q, sd[p + ".w_qs.weight"]).view(b, lq, h, dk).transpose(1, 2)
     kh = F.linear(k, sd[p + ".w_ks.weight"]).view(b, lk, h, dk).transpose(1, 2)
     vh = F.linear(v, sd[p + ".w_vs.weight"]).view(b, lk, h, dv).transpose(1, 2)
-    attn = torch.softmax(torch.matmul(qh / (dk ** 0.5), kh.transpose(2, 3)), dim=-1)
+    scores = torch.matmul(qh / (dk ** 0.5), kh.transpose(2, 3))
+    if mask is not None:
+        scores = scores.masked_fill(mask.unsqueeze(1) == 0, -1e9)
+    attn = torch.softmax(scores, dim=-1)
     o = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(b, lq, -1)
     o = F.linear(o, sd[p + ".fc.weight"]) + residual
     return _ln(sd, p + ".layer_norm", o), attn

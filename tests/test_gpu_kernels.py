@@ -332,3 +332,28 @@ def test_linear_random_shapes(prec):
         assert rel_l2(got.numpy(), ref.numpy()) < TOL[prec] * 2, (case, M, N, K)
 
 
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_attention_mask_matches_reference_golden(prec):
+    """MultiHeadAttention / ScaledDotProductAttention with the reference's mask argument (eg_attention_masked) against the REFERENCE's module
+    (tests/golden/make_golden_mask.py): [B, 1, Lk] padding mask, [B, Lq, Lk] causal mask, fully masked rows; and mask = None still takes the
+    fused block with the same result as an all-ones mask."""
+    import os
+    from emotiongestures_amd.modules import MultiHeadAttention
+    from emotiongestures_amd.synth import hash_unit, load_synth_weights
+    from test_oracle_golden import GOLDEN, _mask_inputs
+    z = np.load(os.path.join(GOLDEN, "attention_mask.npz"))
+    q, kv, masks = _mask_inputs()
+    mha = load_synth_weights(MultiHeadAttention(8, 512, 64, 64, dropout=0.2), 31).eval().to(dev())
+    mha.precision = prec
+    qd, kd = torch.from_numpy(q).to(dev()), torch.from_numpy(kv).to(dev())
+    tol = {"f32": 3e-6, "bf16x3": 3e-5}[prec]
+    with torch.no_grad():
+        for name, m in masks.items():
+            y, attn = mha(qd, kd, kd, mask=torch.from_numpy(m).to(dev()))
+            assert rel_l2(y.cpu().numpy()[:, :, ::4], z[f"{name}/out"]) < tol, name
+            np.testing.assert_allclose(attn.cpu().numpy()[:, ::4], z[f"{name}/attn"], atol=10 * tol)
+        y0, a0 = mha(qd, kd, kd)
+        y1, a1 = mha(qd, kd, kd, mask=torch.ones(3, 1, 40, device=dev()))
+        assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < tol and float((a1 - a0).abs().max()) < 10 * tol

@@ -176,3 +176,38 @@ def test_beat_long_oracle_matches_reference_golden():
     assert clip_rel_l2(pose.numpy(), z["pose"]) < TOL
     assert rel_l2(pred.numpy(), z["emotion_prediction"]) < TOL
     assert rel_l2(digest(emo.numpy(), 8192)["sample"], z["emotion_feature/sample"]) < TOL
+
+
+def _mask_inputs():
+    from emotiongestures_amd.synth import hash_unit
+    B, LQ, LK, D = 3, 34, 40, 512
+    q = ((hash_unit("mask.q", B * LQ * D, 31) * 2 - 1)).astype(np.float32).reshape(B, LQ, D)
+    kv = ((hash_unit("mask.kv", B * LK * D, 31) * 2 - 1)).astype(np.float32).reshape(B, LK, D)
+    pad = np.ones((B, 1, LK), np.int64)
+    pad[0, 0, 30:] = 0
+    pad[1, 0, ::3] = 0
+    pad[2, 0, :] = 0
+    full = np.ones((B, LQ, LK), np.int64)
+    for i in range(LQ):
+        full[:, i, i + 1:] = 0
+    full[1, 5, :] = 0
+    return q, kv, {"pad": pad, "full": full}
+
+
+def _mask_mha():
+    from emotiongestures_amd.modules import MultiHeadAttention
+    return load_synth_weights(MultiHeadAttention(8, 512, 64, 64, dropout=0.2), 31).eval()
+
+
+def test_attention_mask_oracle_matches_reference_golden():
+    """The reference's optional attention mask (Modules.py:18-19, SubLayers.py:44-45; never passed on the gesture path): padding mask broadcast
+    over the queries, a full causal mask, and fully masked rows (uniform over ALL keys, as -1e9 everywhere gives)."""
+    z = np.load(os.path.join(GOLDEN, "attention_mask.npz"))
+    q, kv, masks = _mask_inputs()
+    sd = {"m." + k: v.detach() for k, v in _mask_mha().state_dict().items()}
+    for name, m in masks.items():
+        with torch.no_grad():
+            y, attn = O.multi_head_attention(sd, "m", torch.from_numpy(q), torch.from_numpy(kv), torch.from_numpy(kv), O.GenCfg(), mask=torch.from_numpy(m))
+        assert rel_l2(y.numpy()[:, :, ::4], z[f"{name}/out"]) < 2e-6
+        np.testing.assert_allclose(attn.numpy()[:, ::4], z[f"{name}/attn"], atol=2e-7)
+    assert abs(float(z["pad/attn"][2].max()) - 1.0 / 40) < 1e-7          # every key masked: uniform over all 40
