@@ -423,11 +423,33 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
         return F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
                      F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
 
+    # One rank: the emotion CVAE's forward + backward (its input is the DETACHED emotion map, so nothing of it feeds the generator's gradient) runs
+    # on a side stream beside the generator's losses and backward -- one fork / join pair per step, captured into the step's hipGraph with it.
+    # Same kernels on the same data: the parameters after a step are bitwise those of the one-stream step (tests/test_gpu_training.py).
+    side = torch.cuda.Stream(dev) if (world == 1 and os.environ.get("EG_TRAIN_SIDE_CVAE", "1") != "0") else None
+
+    def forward_backward():
+        if side is None:
+            loss = forward_loss()
+            loss.backward()
+            return loss
+        cur = torch.cuda.current_stream(dev)
+        pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+        emo_d = emo.detach()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            rec, mu, logvar = vae(emo_d, g["label"], eps)
+            loss_v = F.add(F.smooth_l1_loss(rec, emo_d, 1.0, 1.0), F.kld_loss(mu, logvar, 1.0))
+            loss_v.backward()
+        loss_g = F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label))
+        loss_g.backward()
+        cur.wait_stream(side)
+        return F.add(loss_g.detach(), loss_v.detach())
+
     def step(timed=True):
         opt.zero_grad()
         gb.begin()
-        loss = forward_loss()
-        loss.backward()
+        loss = forward_backward()
         if not timed:                   # inside a stream capture: no timing events
             gb.finish()
             opt.step(collected=True)

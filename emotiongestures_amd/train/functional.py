@@ -103,8 +103,9 @@ def grad_out(param, shape=None) -> torch.Tensor:
 
 
 def _scratch(dev, floats: int, tag="ws") -> torch.Tensor:
-    """Reusable scratch (partials of split-K / column reductions).  Stream-ordered use only."""
-    key = (str(dev), tag)
+    """Reusable scratch (partials of split-K / column reductions), one buffer per (device, tag, STREAM): use on a stream is ordered by the
+    stream; two branches of a step running on different streams (bench.py: the emotion CVAE beside the generator's backward) never share one."""
+    key = (str(dev), tag, torch.cuda.current_stream(dev).cuda_stream if torch.device(dev).type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < floats:
         buf = torch.empty(max(int(floats), 1 << 16), dtype=torch.float32, device=dev)

@@ -1329,3 +1329,22 @@ def test_resident_weight_images_match_per_use_packing():
         F.set_precision("f32")
         F.register_weight_images(None)
     assert torch.equal(finals[0], finals[1])
+
+
+def test_bench_train_step_with_the_cvae_on_a_side_stream_is_bitwise_the_one_stream_step():
+    """bench.py's training step runs the emotion CVAE's forward + backward on a side stream beside the generator's backward (one fork / join per step,
+    inside the captured hipGraph; scratch buffers are per stream): same kernels on the same data, so after the same steps the loss is bitwise the
+    one-stream step's (EG_TRAIN_SIDE_CVAE=0), with Dropout active and without."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--no-train-dropout"]):
+        losses = []
+        for side in ("0", "1"):
+            env = dict(os.environ, EG_TRAIN_SIDE_CVAE=side)
+            cmd = [sys.executable, "bench.py", "--train", "--train-batch", "4", "--steps", "4", "--warmup", "2", "--no-extra-legs"] + extra
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+            assert r.returncode == 0, r.stderr[-2000:]
+            line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            assert np.isfinite(line["final_loss"])
+            losses.append(line["final_loss"])
+        assert losses[0] == losses[1], (extra, losses)
