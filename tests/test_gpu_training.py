@@ -836,8 +836,8 @@ def test_two_dropout_forwards_before_one_backward_share_the_steps_mask_epoch():
 
 
 def test_graphed_step_keeps_its_scratch_buffers_alive():
-    """The captured kernels hold raw pointers into functional._WS; a later, larger eager request replaces the registry entry.  The graph
-    keeps the buffers it was captured with, so a replay after that still writes into memory it owns (same result as before)."""
+    """The captured kernels hold raw pointers into functional._WS (one buffer per device, tag and stream); a later, larger request on the same key
+    replaces the registry entry.  The graph keeps the buffers it was captured with, so a replay after that still writes into memory it owns."""
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train.graph import GraphedStep
     from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
@@ -852,10 +852,13 @@ def test_graphed_step_keeps_its_scratch_buffers_alive():
 
     gs = GraphedStep(step, {}, opt, warmup=1)
     want = gs.run().clone()
-    kept = gs._scratch_keep[(str(a.device), "tn")]
-    ptr = kept.data_ptr()
-    big = F._scratch(a.device, kept.numel() * 4, "tn")                  # a larger eager request replaces the registry entry ...
-    assert big.data_ptr() != ptr and gs._scratch_keep[(str(a.device), "tn")].data_ptr() == ptr        # ... the graph still owns its buffer
+    keys = [k for k in gs._scratch_keep if k[1] == "tn"]
+    assert keys, list(gs._scratch_keep)
+    ptrs = {k: gs._scratch_keep[k].data_ptr() for k in keys}
+    kept = max((gs._scratch_keep[k] for k in keys), key=lambda t: t.numel())
+    for k in keys:                                                       # a larger request on every such key replaces the registry entries ...
+        F._WS[k] = torch.empty(gs._scratch_keep[k].numel() * 4, device=DEV)
+    assert all(F._WS[k].data_ptr() != ptrs[k] and gs._scratch_keep[k].data_ptr() == ptrs[k] for k in keys)      # ... the graph still owns its buffers
     junk = [torch.full((kept.numel(),), 7.0, device=DEV) for _ in range(4)]        # allocations that would have landed on a freed block
     got = gs.run().clone()
     assert torch.equal(got, want)
