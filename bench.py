@@ -427,6 +427,8 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     # on a side stream beside the generator's losses and backward -- one fork / join pair per step, captured into the step's hipGraph with it.
     # Same kernels on the same data: the parameters after a step are bitwise those of the one-stream step (tests/test_gpu_training.py).
     side = torch.cuda.Stream(dev) if (world == 1 and os.environ.get("EG_TRAIN_SIDE_CVAE", "1") != "0") else None
+    if side is not None:
+        model.aux_stream = torch.cuda.Stream(dev)            # the generator's gradient-free text branch beside its audio tower (train/nets.py)
 
     def forward_backward():
         if side is None:

@@ -296,8 +296,17 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     memory encoder only).  The text branch does not feed the pose or the emotion head (:577,616), so it is evaluated without gradient on the
     inference kernels."""
     _dropout_on(model)
+    # `model.aux_stream` (a torch.cuda.Stream, optional): the text branch -- no gradient, feeds neither head -- runs there beside the audio tower
+    # and is joined before this function returns (one fork / join; nothing crosses streams but its inputs and the returned embedding)
+    aux = getattr(model, "aux_stream", None) if text.is_cuda else None
     try:
-        text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
+        if aux is not None:
+            cur = torch.cuda.current_stream(text.device)
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
+        else:
+            text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
         spectrum_feature = audio_encoder_forward(model.audio_encoder, input_spectrum)
         prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
         sa, sb = F.fork(spectrum_feature)
@@ -313,6 +322,9 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
         enc_out = encoder_forward(model.encoder, fusion)
         dec_out = decoder_forward(model.decoder, prior, enc_out)
         pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
+        if aux is not None:
+            cur.wait_stream(aux)
+            text_embedding.record_stream(cur)           # allocated on the side stream, handed to the caller's
     finally:
         _P["on"] = False
         F.flush_batch_counters()
