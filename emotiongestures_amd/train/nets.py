@@ -296,8 +296,10 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
     memory encoder only).  The text branch does not feed the pose or the emotion head (:577,616), so it is evaluated without gradient on the
     inference kernels."""
     _dropout_on(model)
-    # `model.aux_stream` (a torch.cuda.Stream, optional): the text branch -- no gradient, feeds neither head -- runs there beside the audio tower
-    # and is joined before this function returns (one fork / join; nothing crosses streams but its inputs and the returned embedding)
+    # `model.aux_stream` (a torch.cuda.Stream, optional): the text branch (no gradient, feeds neither head) and the prior-pose branch (meets the
+    # rest only at the decoder) run there beside the audio tower: one fork, one join in front of the decoder.  The prior branch's backward then
+    # runs on that stream too (autograd replays a node on its forward's stream and orders the gradient hand-over with events).  The host-side
+    # call order -- and with it the dropout stream's offsets -- is the one-stream order.
     aux = getattr(model, "aux_stream", None) if text.is_cuda else None
     try:
         if aux is not None:
@@ -308,7 +310,11 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
         else:
             text_embedding = text_encoder_forward_nograd(model.text_encoder, text)
         spectrum_feature = audio_encoder_forward(model.audio_encoder, input_spectrum)
-        prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
+        if aux is not None:
+            with torch.cuda.stream(aux):
+                prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
+        else:
+            prior = prior_encoder_forward(model.prior_seq_encoder, prior_seq)
         sa, sb = F.fork(spectrum_feature)
         emotion_feature = _seq_linear(model.emotion_proj, (0, 2), sa, drop=0.2)
         semantic_feature = _seq_linear(model.semantic_proj, (0, 2), sb, drop=0.2)
@@ -320,11 +326,12 @@ def generator_forward(model, input_spectrum, text, prior_seq, sampled_emotion_fe
         emotion_prediction = _seq_linear(model.emotion_classifer_header, (0, 2, 4, 6), e_cls.reshape(B, -1), relu_between=True)
         fusion = _seq_linear(model.fusion_proj, (0, 2), F.add(e_fus, semantic_feature), relu_between=True)
         enc_out = encoder_forward(model.encoder, fusion)
-        dec_out = decoder_forward(model.decoder, prior, enc_out)
-        pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
         if aux is not None:
             cur.wait_stream(aux)
             text_embedding.record_stream(cur)           # allocated on the side stream, handed to the caller's
+            prior.record_stream(cur)
+        dec_out = decoder_forward(model.decoder, prior, enc_out)
+        pose = _seq_linear(model.post_projector, (0, 2, 4, 6), dec_out, drop=0.2)
     finally:
         _P["on"] = False
         F.flush_batch_counters()
