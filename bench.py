@@ -411,7 +411,8 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     fp = flatten_parameters(both)
     fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
     opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
-    gb = GradBuckets(fp, bucket_mb=25.0, split_at=stage_splits(model, fp) if world > 1 else ()).attach()     # buckets end at the segmented backward's phase boundaries
+    collective = world > 1 or (dist is not None and os.environ.get("EG_FORCE_COLLECTIVES") == "1")       # world 1 + EG_FORCE_COLLECTIVES: the data-parallel step over a 1-rank RCCL group
+    gb = GradBuckets(fp, bucket_mb=25.0, split_at=stage_splits(model, fp) if collective else ()).attach()     # buckets end at the segmented backward's phase boundaries
     ar_ms = []
     seg = [None]
 
@@ -426,7 +427,7 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     # One rank: the emotion CVAE's forward + backward (its input is the DETACHED emotion map, so nothing of it feeds the generator's gradient) runs
     # on a side stream beside the generator's losses and backward -- one fork / join pair per step, captured into the step's hipGraph with it.
     # Same kernels on the same data: the parameters after a step are bitwise those of the one-stream step (tests/test_gpu_training.py).
-    side = torch.cuda.Stream(dev) if (world == 1 and os.environ.get("EG_TRAIN_SIDE_CVAE", "1") != "0") else None
+    side = torch.cuda.Stream(dev) if (not collective and os.environ.get("EG_TRAIN_SIDE_CVAE", "1") != "0") else None
     if side is not None:
         model.aux_stream = torch.cuda.Stream(dev)            # the generator's gradient-free text branch beside its audio tower (train/nets.py)
 
@@ -477,7 +478,7 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     mode = "eager (autograd issues every kernel)"
     if graph:
         from emotiongestures_amd.train.graph import GraphedStep, SegmentedStep
-        if world == 1:
+        if not collective:
             gs = GraphedStep(lambda _inputs: step(timed=False), g, opt, warmup=max(1, warmup), stochastic=bool(dropout))
             run = gs.run
             mode = "one captured hipGraph per step"
@@ -513,8 +514,32 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
            "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
            "allreduce_exposed_bytes_per_step": None if seg[0] is None else seg[0].exposed_bytes(),
            "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
+    if os.environ.get("EG_TRAIN_DIGEST") == "1":     # bitwise identity of the parameters after warmup + steps (tests: segmented step over RCCL vs the one-graph step)
+        import hashlib
+        out["param_digest"] = hashlib.sha256(fp.flat.cpu().numpy().tobytes()).hexdigest()
     del model, vae, both, fp, opt, gb
     return out
+
+
+def collective_facts(dist, backend, dev):
+    """What the process group really is: backend, RCCL version, and the ranks an all_reduce / all_gather actually reached (every rank calls)."""
+    if dist is None:
+        return None
+    on = dev if backend == "nccl" else "cpu"
+    one = torch.ones(1, device=on, dtype=torch.float64)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([dist.get_rank()], device=on, dtype=torch.int64)
+    seen = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(seen, mine)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001
+            ver = f"unavailable ({type(e).__name__})"
+    return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "rccl_version": ver, "world_size": dist.get_world_size(),
+            "ranks_seen_by_all_reduce": int(one.item()), "ranks_seen_by_all_gather": sorted(int(t.item()) for t in seen),
+            "forced_at_world_1": os.environ.get("EG_FORCE_COLLECTIVES") == "1" and dist.get_world_size() == 1}
 
 
 def train_worker(args, rank, world, dev, dist, backend):
@@ -528,6 +553,7 @@ def train_worker(args, rank, world, dev, dist, backend):
     parity = None
     if not args.no_extra_legs and (args.train_precision != "f32" or not args.no_train_graph):
         parity = train_leg(dev, B, "f32", False, args.steps, args.warmup, rank, world, dist, backend)
+    facts = collective_facts(dist, backend, dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -545,6 +571,10 @@ def train_worker(args, rank, world, dev, dist, backend):
             "allreduce_exposed_bytes_per_step": main_leg["allreduce_exposed_bytes_per_step"], "launch": main_leg["launch"],
             "library_launches_per_step": main_leg["library_launches_per_step"], "algorithmic_tflops_per_gpu": main_leg["algorithmic_tflops_per_gpu"],
             "frac_of_mfma_peak": main_leg["frac_of_mfma_peak"]}
+        if "param_digest" in main_leg:
+            line["param_digest"] = main_leg["param_digest"]
+        if facts is not None:
+            line["collectives"] = facts
         if parity is not None:
             parity.pop("trainable_parameters"); parity.pop("buckets")
             line["f32_eager"] = parity
@@ -575,9 +605,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("EG_FORCE_COLLECTIVES") == "1":      # the latter: a 1-rank RCCL group, so that every collective site really issues its call
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -837,6 +868,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_g, sd_v, inp)
 
+    facts = collective_facts(dist, backend, dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -854,6 +886,8 @@ def main():
             "pose_rel_l2_vs_cpu_oracle": parity, "parity_clips_checked": B, "fgd_vs_cpu_oracle": fgd,
             "lanes_bitwise_equal": lanes_equal, "sustained": sustained, "f32": f32, "extra_legs": extra, "train": train, "roofline": roof, "cpu_baseline": cpu,
         }
+        if facts is not None:       # N > 1 (or EG_FORCE_COLLECTIVES): what the barrier / max-over-ranks really ran over
+            line["collectives"] = facts
         print(json.dumps(line))
     return 0
 

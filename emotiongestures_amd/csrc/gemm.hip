@@ -748,8 +748,7 @@ int launch_presplit128(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xk
 }
 
 // Tile choice of the pre-split product.  Default policy (measured on the 4-lane headline and on tools/bench_ops.py):
-//   >= 1024 workgroups of 128 x 128  -> 128 x 128, 8 waves (diversity sampling, M = 69 632)
-//   otherwise the policy of `presplit_tile_default` below.
+//   the policy of `presplit_tile_default` below (stand-alone: 64 x 64 up to 1024 workgroups; with the caller's shared-chip hint: 128 x 128 from 64).
 // EG_GEMM_TILE overrides it for A/B runs: "64" | "128x64" (4-slot ring, one workgroup per CU) | "128x64r3" (3-slot ring, two per CU) | "128".
 enum PresplitTile { TILE_64 = 0, TILE_128x64 = 1, TILE_128x64_R3 = 2, TILE_128 = 3, TILE_64_R8 = 4, TILE_128x64_R6 = 5, TILE_128_R4 = 6, TILE_AUTO = -1 };
 int presplit_tile_override() {          // read per call (a tool / test switches it between launches; a captured graph keeps what it was captured with)
@@ -764,19 +763,21 @@ int presplit_tile_override() {          // read per call (a tool / test switches
     if (!strcmp(e, "128r4")) return TILE_128_R4;
     return TILE_AUTO;
 }
-int presplit_tile_default(int m, int n) {
-    // 128 x 128 (8 waves, 32 KB of operands per 192 MFMAs) from 64 workgroups up.  At the headline's 2176-row products it is SLOWER alone
-    // (13.3 vs 9.3 us at N = 512: 68 workgroups leave 188 CUs idle) but FASTER in the step as it is run, four batches in flight: it occupies a
-    // quarter of the CUs for half the operand traffic, and the other lanes' convolutions take the rest -- same-box A/B of the default bench
-    // line, twice each: 25 537 / 25 605 clips/s against 25 311 / 25 288 with the 64 x 64 tile (profiles/r04c_gemm_tile_ab.txt).  Below that
-    // (16-clip training steps, M = 544) the 64 x 64 tile's 4 x more workgroups win.
-    if ((long)eg_cdiv(m, 128) * eg_cdiv(n, 128) >= 64) return TILE_128;
+int presplit_tile_default(int m, int n, int shared_chip) {
+    // Stand-alone (one stream, nothing else resident) the 64 x 64 tile is the faster one below ~1000 workgroups: at the headline's 2176-row products
+    // 9.3 vs 13.3 us (N = 512), 25.6 vs 39.2 us (K = 2048) -- 68 workgroups of 128 x 128 leave 188 CUs idle (profiles/r04b_gemm_tile_sweep.txt).
+    // The 128 x 128 tile (8 waves, 32 KB of operands per 192 MFMAs) wins from ~1024 workgroups up (diversity sampling, M = 69 632) -- and, from 64
+    // workgroups up, when the CALLER says other work fills the chip (`shared_chip`: ClipPipeline with several batches in flight sets it through
+    // EgGeneratorConfig.reserved[4]): a product then costs CU time, not latency, and the large tile holds a quarter of the CUs for half the
+    // operand traffic -- same-box A/B of the 4-lane bench line, twice each: 25 537 / 25 605 clips/s against 25 311 / 25 288 (profiles/r04c_gemm_tile_ab.txt).
+    const long wgs = (long)eg_cdiv(m, 128) * eg_cdiv(n, 128);
+    if (wgs >= (shared_chip ? 64 : 1024)) return TILE_128;
     return TILE_64;
 }
-int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int precision, hipStream_t st, EgProfScope* prof = nullptr) {
+int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int precision, hipStream_t st, EgProfScope* prof = nullptr, int shared_chip = 0) {
     const int mt = eg_cdiv(a.M, 64), nt = eg_cdiv(a.N, 64);
     int tile = presplit_tile_override();
-    if (tile == TILE_AUTO) tile = presplit_tile_default(a.M, a.N);
+    if (tile == TILE_AUTO) tile = presplit_tile_default(a.M, a.N, shared_chip);
     if (prof) {
         const int tm = (tile == TILE_64 || tile == TILE_64_R8) ? 1 : 2, tn = (tile == TILE_128 || tile == TILE_128_R4) ? 2 : 1;
         prof->workgroups(eg_cdiv(mt, tm) * eg_cdiv(nt, tn));
@@ -894,7 +895,7 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
-        return dispatch_presplit(a, xhi, xlo, xko, p.precision, st, &prof);
+        return dispatch_presplit(a, xhi, xlo, xko, p.precision, st, &prof, p.shared_chip);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
     prof.workgroups(eg_cdiv(p.m, 64) * eg_cdiv(p.n, 64));

@@ -258,6 +258,7 @@ struct EgGenerator {
     LinW a_fc1, a_fc2, emosem0, emo2, sem2, fus0, fus2, cls[4], post[4], prior_h0, prior_h2, txt_dec;
     bool fuse_se = true;        // identity SE blocks: gate from input moments + tail in conv2's epilogue (cfg.reserved[3] = 1 disables)
     bool fold = false;          // cfg.reserved[2]: the chains below replace their members
+    bool shared_chip = false;   // cfg.reserved[4]: several batches in flight (ClipPipeline lanes): products choose their tile for CU time
     LinW f_audio, f_emo, f_sem, f_post, f_prior;
     int64_t pos_table;
     std::vector<MhaW> enc_attn, dec_attn;
@@ -391,6 +392,7 @@ int lin(const EgGenerator* g, const float* arena, const LinW& w, const Act& x, i
     EgiLinear p;
     p.w = arena + w.w; p.ldw = w.kpad; p.bias = w.b >= 0 ? arena + w.b : nullptr;
     p.res1 = res1; p.ldr = ldr; p.m = m; p.n = n_override ? n_override : w.n; p.relu = relu; p.precision = g->cfg.precision;
+    p.shared_chip = g->shared_chip ? 1 : 0;
     if (img_ok && x.img) {
         p.ximg = x.img; p.xK = x.kimg; p.xk0 = xk0; p.k = w.kpad;
     } else {
@@ -599,6 +601,7 @@ extern "C" int eg_generator_create(const EgGeneratorConfig* cfg, EgGenerator** o
     g->concurrent = cfg->reserved[1] != 0;
     g->fold = cfg->reserved[2] != 0;
     g->fuse_se = cfg->reserved[3] == 0;
+    g->shared_chip = cfg->reserved[4] != 0;
     const EgGeneratorConfig& c = g->cfg;
     g->H1 = c.n_mels; g->W1 = c.spec_len;
     g->H2 = (g->H1 - 1) / 2 + 1; g->W2 = (g->W1 - 1) / 2 + 1;

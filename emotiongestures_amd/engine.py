@@ -6,6 +6,8 @@ allocator) and for the current HIP stream; every FLOP of the path runs in libemo
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import threading
 from typing import Dict, Mapping, Optional
 
 import torch
@@ -30,12 +32,23 @@ def _need_cuda(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t.contiguous()
 
 
+def _locked(fn):
+    """Serialise the host-side enqueue of one engine: a call carves the engine's workspace and enqueues ~200 kernels on the current stream;
+    two threads on one device (nn.DataParallel replicas, device_ids with repeats) must not interleave theirs."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self._lock:
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class GeneratorEngine:
     """Host handle for eg_generator_* (Transformer.forward, Full_model/Models_spatial_memory.py:566-616)."""
 
     def __init__(self, *, frames=34, pose_dim=126, prior_frames=4, chunk=4, d_model=512, d_inner=2048, n_layers=3,
                  n_head=8, d_k=64, n_mels=128, spec_len=124, text_len=60, n_words=200, embed_dim=300, tcn_hidden=300,
-                 tcn_layers=3, variant="spatial", precision="f32", n_position=60, keep_taps=False, concurrent=False, fold_affine=False, fuse_se=True):
+                 tcn_layers=3, variant="spatial", precision="f32", n_position=60, keep_taps=False, concurrent=False, fold_affine=False, fuse_se=True,
+                 shared_chip=False):
         lib = L.load()
         cfg = L.EgGeneratorConfig()
         L.check(lib.eg_generator_default_config(C.byref(cfg)), "eg_generator_default_config")
@@ -50,6 +63,7 @@ class GeneratorEngine:
         cfg.reserved[1] = 1 if concurrent else 0
         cfg.reserved[2] = 1 if fold_affine else 0
         cfg.reserved[3] = 0 if fuse_se else 1
+        cfg.reserved[4] = 1 if shared_chip else 0     # several batches in flight (ClipPipeline): GEMM tiles chosen for CU time, not latency
         self.cfg = cfg
         h = C.c_void_p()
         L.check(lib.eg_generator_create(C.byref(cfg), C.byref(h)), "eg_generator_create")
@@ -59,6 +73,8 @@ class GeneratorEngine:
         self.arena_floats = lib.eg_generator_arena_floats(h)
         self.arena: Optional[torch.Tensor] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._lock = threading.RLock()
+        self.uploads = 0                 # arena packs + uploads so far (tests: once per device and weight version)
 
     def __del__(self):
         try:
@@ -71,8 +87,10 @@ class GeneratorEngine:
     # ---- weights ----
     def load_weights(self, sd: Mapping[str, torch.Tensor], device) -> None:
         cpu = packing.build_arena(packing.strip_module_prefix(sd), self.entries, self.arena_floats)
-        self.arena = cpu.to(device)
-        self._ws.clear()
+        with self._lock:
+            self.arena = cpu.to(device)
+            self._ws.clear()
+            self.uploads += 1
 
     def _workspace(self, key, nbytes: int, device) -> torch.Tensor:
         ws = self._ws.get(key)
@@ -82,6 +100,7 @@ class GeneratorEngine:
         return ws
 
     # ---- Transformer.forward ----
+    @_locked
     def forward(self, spec, text, prior, sampled=None, want_aux=True, slot=0):
         if self.arena is None:
             raise L.EgError("GeneratorEngine.forward before load_weights")
@@ -113,6 +132,7 @@ class GeneratorEngine:
                                                _stream(dev)), "eg_generator_forward")
         return pose, emo, sem, pred, txt
 
+    @_locked
     def forward_draws(self, spec, prior, sampled):
         """BASELINE config 5: sampled [B, R, frames, d_model] -> pose [B, R, frames, pose_dim]."""
         dev = self.arena.device
@@ -151,6 +171,8 @@ class CvaeEngine:
         self.arena_floats = lib.eg_cvae_arena_floats(h)
         self.arena = None
         self._ws = {}
+        self._lock = threading.RLock()
+        self.uploads = 0
 
     def __del__(self):
         try:
@@ -161,8 +183,10 @@ class CvaeEngine:
             pass
 
     def load_weights(self, sd, device):
-        self.arena = packing.build_arena(packing.strip_module_prefix(sd), self.entries, self.arena_floats).to(device)
-        self._ws.clear()
+        with self._lock:
+            self.arena = packing.build_arena(packing.strip_module_prefix(sd), self.entries, self.arena_floats).to(device)
+            self._ws.clear()
+            self.uploads += 1
 
     def _workspace(self, n, device, slot=0):
         nbytes = self._lib.eg_cvae_workspace_bytes(self._h, n)
@@ -172,6 +196,7 @@ class CvaeEngine:
             self._ws[(n, slot)] = ws
         return ws, nbytes
 
+    @_locked
     def sample(self, y, z, slot=0):
         dev = self.arena.device
         y, z = _need_cuda(y, "y"), _need_cuda(z, "z")
@@ -182,6 +207,7 @@ class CvaeEngine:
                                          _stream(dev)), "eg_cvae_sample")
         return out
 
+    @_locked
     def forward(self, x, y, eps):
         dev = self.arena.device
         x, y, eps = _need_cuda(x, "x"), _need_cuda(y, "y"), _need_cuda(eps, "eps")

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .modules import Encoder, Linear, _eval_only, _seq
+from .modules import Encoder, Linear, ReplicaAware, _eval_only, _seq, replica_forward
 
 __all__ = ["MLP_Reconstruct", "SkeletonTransformer", "Prior_Encoder", "compute_acc", "l2_distance_pose", "mpjre", "calc_motion",
            "calculate_frechet_distance", "calculate_diversity", "diversity_score", "evaluate"]
@@ -66,7 +66,7 @@ def _affine_chain(cache: _PackCache, x: torch.Tensor, layers, relu_between: bool
     return x
 
 
-class MLP_Reconstruct(nn.Module):
+class MLP_Reconstruct(ReplicaAware, nn.Module):
     """model/FGD.py:26-82: per-frame pose auto-encoder whose 512-d latent is the FGD feature.  ``pose_dim`` is 282 upstream
     (hard-coded :32,58); Dropout layers are identity in eval."""
 
@@ -77,6 +77,7 @@ class MLP_Reconstruct(nn.Module):
         self.precision = precision
         self._cache = _PackCache()
 
+    @replica_forward
     def forward(self, Input):
         _eval_only(self)
         shp = Input.shape
@@ -94,7 +95,7 @@ class Prior_Encoder(nn.Module):
         self.fc1, self.fc2 = Linear(pose_dim, d_model), Linear(d_model, d_model)
 
 
-class SkeletonTransformer(nn.Module):
+class SkeletonTransformer(ReplicaAware, nn.Module):
     """skeleton_classifer/Models.py:199-283: emotion classifier on a pose sequence -> (logits [B,8], mid_feature [B,T,d])."""
 
     def __init__(self, class_dim=8, pose_dim=242, src_pad_idx=1, trg_pad_idx=1, d_word_vec=64, d_model=64, d_inner=512,
@@ -113,6 +114,7 @@ class SkeletonTransformer(nn.Module):
         self.precision = precision
         self._cache = _PackCache()
 
+    @replica_forward
     def forward(self, prior_seq):
         _eval_only(self)
         B, T, D = prior_seq.shape
@@ -128,7 +130,7 @@ class SkeletonTransformer(nn.Module):
 
 
 # ---- training-side types on the path, forward only ---------------------------------------------------
-class Motion_Discriminator(nn.Module):
+class Motion_Discriminator(ReplicaAware, nn.Module):
     """Full_model/Models_spatial_memory.py:620-669 (identical class in Models_memory.py): encoder over the motion offsets,
     per-frame Linear+ReLU, 6-layer ReLU MLP -> [B, 1] logit (no sigmoid).  Its forward needs pose_dim == d_word_vec == d_model
     (the encoder adds a d_word_vec-wide table to the raw offsets and fc1 consumes the d_model-wide encoder output as if it were
@@ -154,6 +156,7 @@ class Motion_Discriminator(nn.Module):
         self.precision = precision
         self._cache = _PackCache()
 
+    @replica_forward
     def forward(self, x):
         B, T, D = x.shape
         if T != self.frames or D != self.d_model:
@@ -170,7 +173,7 @@ class Motion_Discriminator(nn.Module):
         return _affine_chain(self._cache, h.reshape(B, -1).contiguous(), head, True, self.precision)
 
 
-class Pose_Discriminator(nn.Module):
+class Pose_Discriminator(ReplicaAware, nn.Module):
     """Full_model/Models_spatial_memory.py:671-704: encoder over a pose sequence -> per-frame Linear(282, 64) -> Dropout(0.2) -> Linear(64, 1)
     -> sigmoid: one real / fake probability per frame, [B, T, 1].  The head is hard-coded to 282 inputs and consumes the d_model-wide encoder
     output directly, and the encoder adds a d_word_vec-wide positional table to the raw poses: the forward is consistent only for
@@ -193,6 +196,7 @@ class Pose_Discriminator(nn.Module):
                 nn.init.xavier_uniform_(p)
         self.precision = precision
 
+    @replica_forward
     def forward(self, x):
         B, T, D = x.shape
         if D != self.d_model:

@@ -10,10 +10,10 @@ import torch.nn as nn
 
 from .. import ops
 from ..harness import _PackCache, _affine_chain
-from ..modules import Linear, ResNetSE, SEBasicBlock, _eval_only, _seq
+from ..modules import Linear, ReplicaAware, ResNetSE, SEBasicBlock, _eval_only, _seq, replica_forward
 
 
-class EmotionNet(nn.Module):
+class EmotionNet(ReplicaAware, nn.Module):
     def __init__(self, *, precision="f32"):
         super().__init__()
         num_filters = [32, 64, 128, 256]
@@ -35,6 +35,7 @@ class EmotionNet(nn.Module):
             self._fc0 = (ver, ops.pack_linear_weight(w, device))
         return self._fc0[1]
 
+    @replica_forward
     def forward(self, mfcc):
         if self.training:           # train() mode (train_audio_classifier_K_fold.py:155-175): differentiable HIP operators
             from ..train import nets

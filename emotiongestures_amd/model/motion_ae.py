@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules import BatchNorm, Conv1d, ConvTranspose1d, Linear, _eval_only, _seq
+from ..modules import BatchNorm, Conv1d, ConvTranspose1d, Linear, ReplicaAware, _eval_only, _seq, replica_forward
 
 
 def ConvNormRelu(in_channels, out_channels, downsample=False, padding=0, batchnorm=True):
@@ -105,12 +105,13 @@ class PoseDecoderConv(nn.Module):
         return x.transpose(1, 2)
 
 
-class MotionAE(nn.Module):
+class MotionAE(ReplicaAware, nn.Module):
     def __init__(self, pose_dim, latent_dim):
         super().__init__()
         self.encoder = PoseEncoderConv(34, pose_dim, latent_dim)
         self.decoder = PoseDecoderConv(34, pose_dim, latent_dim)
 
+    @replica_forward
     def forward(self, pose):
         pose = pose.view(pose.size(0), pose.size(1), -1)
         z = self.encoder(pose)

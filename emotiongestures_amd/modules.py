@@ -12,7 +12,10 @@ and backward operators under torch.autograd); the other modules are eval-only an
 """
 from __future__ import annotations
 
+import copy
+import functools
 import math
+import threading
 from typing import Optional
 
 import numpy as np
@@ -46,6 +49,114 @@ def _eval_only(m: nn.Module) -> None:
         raise NotImplementedError(
             f"{type(m).__name__}: only the eval-mode forward is implemented on the HIP path (call .eval()); "
             "there is no PyTorch fallback")
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.DataParallel support (the reference's caller wraps every model in it when device_count() > 1:
+# test_emotion_gesture_diversity_iterative.py:137-138,150-151,160-161,169-170; train_audio_classifier_K_fold.py:129-130)
+# ------------------------------------------------------------------------------------------------
+class _DpState:
+    """Per-ORIGIN state that must outlive DataParallel's per-forward replicas: a lock, the per-device engines of the arena-based
+    modules and the per-device parameter shadows of the operator-composed ones.  Copies (deepcopy / pickle) start empty."""
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.engines = {}          # str(device) -> [engine, key]
+        self.shadows = {}          # str(device) -> [module copy on that device, weights version, lock]
+
+    def __deepcopy__(self, memo):
+        return _DpState()
+
+    def __reduce__(self):
+        return (_DpState, ())
+
+
+def _tensor_device(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.device
+    return None
+
+
+def _weights_version_of(m: nn.Module):
+    # (_version, data_ptr): `param.data = new_tensor` keeps or collides version counters but moves the storage
+    return tuple((t._version, t.data_ptr()) for t in list(m.parameters()) + list(m.buffers()))
+
+
+class ReplicaAware:
+    """Mixin for the modules the reference's caller hands to ``nn.DataParallel``.
+
+    ``torch.nn.parallel.replicate`` rebuilds every replica per forward with ``_parameters == {}`` (the broadcast copies are plain
+    attributes), so a replica has no ``parameters()`` / ``state_dict()`` and nothing cached on it survives the call.  A replica
+    therefore keeps a reference to its ORIGIN, and the work is done by state that lives on the origin (``_DpState``):
+
+    * arena modules (``Transformer``, ``MLP_Reconstruct_v3``): one engine + packed arena per device, keyed by the origin's weight
+      version -- packed and uploaded once per device and weight version, not per forward (``engine(device)``);
+    * operator-composed modules (FGD auto-encoder, skeleton classifier, EmotionNet, MotionAE): the origin itself on its own
+      device, a cached parameter shadow (deep copy, refreshed when the origin's weights change) on the others, so their packed
+      weight images persist as well.
+
+    Replicas of one device run under that device's lock (DataParallel runs replicas on threads; two of them on one GPU share
+    workspaces).  train() mode under DataParallel is refused: the training layer is one trainer per process
+    (``bench.py --gpus N`` / ``train.loops.train_k_fold`` are the data-parallel paths)."""
+
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_dp_origin"] = self.__dict__.get("_dp_origin") or self
+        return replica
+
+    def _origin(self):
+        return self.__dict__.get("_dp_origin") or self
+
+    def _dp(self) -> _DpState:
+        o = self._origin()
+        st = o.__dict__.get("_dp_state")
+        if st is None:
+            st = o.__dict__.setdefault("_dp_state", _DpState())
+        return st
+
+    def _refuse_replica_training(self):
+        if self.training and self.__dict__.get("_dp_origin") is not None:
+            raise RuntimeError(
+                f"{type(self).__name__}: train() mode under nn.DataParallel is not supported by the HIP path (one trainer per process); "
+                "use one process per GPU: `python bench.py --gpus N --train` or emotiongestures_amd.train.loops.train_k_fold under "
+                "torch.distributed.run (gradient all-reduce over RCCL)")
+
+    def _device_twin(self, dev):
+        """The module that computes for `dev`: the origin on its own device, else a cached shadow of it on `dev`.  -> (module, lock)"""
+        o = self._origin()
+        st = self._dp()
+        home = next(o.parameters()).device
+        if dev is None or dev == home:
+            return o, st.lock
+        with st.lock:
+            ver = _weights_version_of(o)
+            ent = st.shadows.get(str(dev))
+            if ent is None:
+                twin = copy.deepcopy(o).to(dev)
+                twin.train(o.training)
+                ent = st.shadows[str(dev)] = [twin, ver, threading.RLock()]
+            elif ent[1] != ver:
+                with torch.no_grad():
+                    for dst, src in zip(list(ent[0].parameters()) + list(ent[0].buffers()), list(o.parameters()) + list(o.buffers())):
+                        dst.copy_(src)                    # in place: the shadow's packed images see a new _version and refresh
+                ent[1] = ver
+            ent[0].train(o.training)
+            return ent[0], ent[2]
+
+
+def replica_forward(fwd):
+    """Decorator for the forward of an operator-composed ReplicaAware module: a DataParallel replica runs the origin's (or its
+    per-device shadow's) forward under that device's lock."""
+    @functools.wraps(fwd)
+    def wrapper(self, *args, **kwargs):
+        if self.__dict__.get("_dp_origin") is None:
+            return fwd(self, *args, **kwargs)
+        self._refuse_replica_training()
+        twin, lock = self._device_twin(_tensor_device(args, kwargs))
+        with lock:
+            return fwd(twin, *args, **kwargs)
+    return wrapper
 
 
 # ------------------------------------------------------------------------------------------------
@@ -534,7 +645,7 @@ class Audio_ResNetEncoder(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # the generator
 # ------------------------------------------------------------------------------------------------
-class Transformer(nn.Module):
+class Transformer(ReplicaAware, nn.Module):
     """Full_model/Models_spatial_memory.py:471-616 and Full_model/Models_memory.py:426-565 (``_variant``).
 
     Extra keyword-only arguments (not in the reference, defaults reproduce it): ``spec_len`` /
@@ -583,33 +694,51 @@ class Transformer(nn.Module):
         self.concurrent = False          # fork the text / prior branches onto side streams (engine option)
         self.fold_affine = False         # fold the Dropout-only Linear chains at pack time (fewer launches / FLOPs; off for parity runs)
         self.train_dropout = False       # train(): activate the reference's Dropout layers (default: p = 0, the gradient-parity configuration)
+        self.shared_chip = False         # several batches in flight on this GPU (ClipPipeline sets it): GEMM tiles chosen for CU time, not stand-alone latency
         self.fuse_se = True              # identity SE blocks: gate from conv1's output moments, tail in conv2's epilogue (same arithmetic order per element)
-        self._engine: Optional[GeneratorEngine] = None
-        self._engine_key = None
 
     # ---- engine management: repack the arena only when weights / device / mode changed ----
     def _weights_version(self):
-        # (_version, data_ptr): `param.data = new_tensor` keeps or collides version counters but moves the storage
-        return tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers()))
+        return _weights_version_of(self._origin())
 
-    def engine(self) -> GeneratorEngine:
-        dev = next(self.parameters()).device
+    @property
+    def _engine(self) -> Optional[GeneratorEngine]:
+        """The engine of the module's own device (None before the first forward)."""
+        o = self._origin()
+        ent = self._dp().engines.get(str(next(o.parameters()).device))
+        return None if ent is None else ent[0]
+
+    def engine(self, device=None) -> GeneratorEngine:
+        """The engine (packed weight arena + workspaces) for `device` (default: the parameters' device).  One per device, kept on
+        the ORIGIN module, so nn.DataParallel's per-forward replicas reuse it: weights and the version key come from the origin's
+        parameters, the arena is packed and uploaded once per device and weight version."""
+        o = self._origin()
+        dev = torch.device(device) if device is not None else next(o.parameters()).device
         if dev.type != "cuda":
             raise L.EgError("emotiongestures_amd.Transformer runs only on a GPU (model.to('cuda')); there is no CPU fallback")
-        key = (str(dev), self.precision, self.keep_taps, self.concurrent, self.fold_affine, self.fuse_se, self._weights_version())
-        if self._engine is None or self._engine_key != key:
-            if self._engine is None or self._engine_key[:6] != key[:6]:
-                self._engine = GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=self.concurrent,
-                                               fold_affine=self.fold_affine, fuse_se=self.fuse_se, **self._cfg)
-            self._engine.load_weights(self.state_dict(), dev)
-            self._engine_key = key
-        return self._engine
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        st = self._dp()
+        with st.lock:
+            mode = (str(dev), self.precision, self.keep_taps, self.concurrent, self.fold_affine, self.fuse_se, self.shared_chip)
+            key = (mode, self._weights_version())
+            ent = st.engines.get(str(dev))
+            if ent is None or ent[1] != key:
+                if ent is None or ent[1][0] != mode:
+                    ent = st.engines[str(dev)] = [GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=self.concurrent,
+                                                                  fold_affine=self.fold_affine, fuse_se=self.fuse_se, shared_chip=self.shared_chip,
+                                                                  **self._cfg), None]
+                ent[0].load_weights(o.state_dict(), dev)
+                ent[1] = key
+            return ent[0]
 
     def forward(self, input_spectrum, text, prior_seq, sampled_emotion_feature=None, *, slot=0):
         if self.training:           # train() mode: differentiable HIP operators, BatchNorm on batch statistics (train/nets.py)
+            self._refuse_replica_training()
             from .train import nets
             return nets.generator_forward(self, input_spectrum, text, prior_seq, sampled_emotion_feature)
-        return self.engine().forward(input_spectrum, text, prior_seq, sampled_emotion_feature, slot=slot)
+        dev = input_spectrum.device if self.__dict__.get("_dp_origin") is not None and input_spectrum.is_cuda else None
+        return self.engine(dev).forward(input_spectrum, text, prior_seq, sampled_emotion_feature, slot=slot)
 
     def forward_draws(self, input_spectrum, prior_seq, sampled_emotion_features):
         """Diversity sampling (BASELINE config 5): sampled [B,R,frames,d_model] -> pose [B,R,frames,pose_dim]."""
@@ -624,7 +753,7 @@ class TransformerMemory(Transformer):
 # ------------------------------------------------------------------------------------------------
 # emotion CVAE
 # ------------------------------------------------------------------------------------------------
-class MLP_Reconstruct_v3(nn.Module):
+class MLP_Reconstruct_v3(ReplicaAware, nn.Module):
     """CAVE/BEAT_CVAE.py:312-460.  ``frames`` (60 upstream, hard-coded :320,365-368) is a keyword here."""
 
     def __init__(self, bath=True, *, frames=60, d_model=512):
@@ -640,20 +769,30 @@ class MLP_Reconstruct_v3(nn.Module):
                             Conv1d(f, f, 3, 1, 1))
         self.fusion_z_posterior = _seq(Linear(64, 128), None, Linear(128, 4 * q))
         self._frames, self._d_model = frames, d_model
-        self._engine = None
-        self._engine_key = None
 
-    def engine(self) -> CvaeEngine:
-        dev = next(self.parameters()).device
+    @property
+    def _engine(self) -> Optional[CvaeEngine]:
+        ent = self._dp().engines.get(str(next(self._origin().parameters()).device))
+        return None if ent is None else ent[0]
+
+    def engine(self, device=None) -> CvaeEngine:
+        """One engine + arena per device on the origin module (see Transformer.engine)."""
+        o = self._origin()
+        dev = torch.device(device) if device is not None else next(o.parameters()).device
         if dev.type != "cuda":
             raise L.EgError("emotiongestures_amd MLP_Reconstruct_v3 runs only on a GPU; there is no CPU fallback")
-        key = (str(dev), tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers())))
-        if self._engine is None or self._engine_key != key:
-            if self._engine is None:
-                self._engine = CvaeEngine(self._frames, self._d_model)
-            self._engine.load_weights(self.state_dict(), dev)
-            self._engine_key = key
-        return self._engine
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        st = self._dp()
+        with st.lock:
+            key = (str(dev), _weights_version_of(o))
+            ent = st.engines.get(str(dev))
+            if ent is None or ent[1] != key:
+                if ent is None:
+                    ent = st.engines[str(dev)] = [CvaeEngine(self._frames, self._d_model), None]
+                ent[0].load_weights(o.state_dict(), dev)
+                ent[1] = key
+            return ent[0]
 
     def reparameterize(self, mu, logvar):
         return ops.reparameterize(mu, logvar, torch.randn_like(mu))          # :389-399
@@ -664,7 +803,7 @@ class MLP_Reconstruct_v3(nn.Module):
         _eval_only(self)
         if z is None:
             z = torch.randn(*[y.shape[0], 32])
-        return self.engine().sample(y, z.to(y.device), slot=slot)
+        return self.engine(y.device if y.is_cuda else None).sample(y, z.to(y.device), slot=slot)
 
     def forward(self, Input, y, eps=None):
         """:403-424.  eval(): running-statistics BatchNorm on the fused engine; train(): differentiable HIP operators with
@@ -672,6 +811,7 @@ class MLP_Reconstruct_v3(nn.Module):
         if eps is None:
             eps = torch.randn(Input.shape[0], 32, device=Input.device)
         if self.training:
+            self._refuse_replica_training()
             from .train import nets
             return nets.cvae_forward(self, Input, y, eps.to(Input.device))
-        return self.engine().forward(Input, y, eps)
+        return self.engine(Input.device if Input.is_cuda else None).forward(Input, y, eps)

@@ -37,6 +37,7 @@ class ClipPipeline:
         if branch_streams and lanes > 1:
             raise ValueError("branch_streams forks use per-handle side streams: only with lanes == 1")
         self.gen.concurrent = bool(branch_streams)
+        self.gen.shared_chip = lanes > 1          # other lanes fill the chip: the products' tile is chosen for CU time (EgGeneratorConfig.reserved[4])
         self.lanes: List[_Lane] = []
         self._next = 0
         for i in range(lanes):

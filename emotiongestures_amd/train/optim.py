@@ -13,6 +13,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -264,6 +265,10 @@ class GradBuckets:
         import torch.distributed as dist
         self.fp, self.group = fp, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # the collectives are issued when there is someone to reduce with -- or, EG_FORCE_COLLECTIVES=1 with an initialised process group, even at
+        # world 1: every all_reduce / staging conversion / stream hand-off of the data-parallel step then really runs (over RCCL on a GPU box),
+        # which proves the issue order and the bf16 staging on one GPU before an 8-GPU node does (sum over one rank and x 1/1 are identities)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("EG_FORCE_COLLECTIVES") == "1")
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         n = fp.grad.numel()
         forced = set(int(o) for o in split_at)
@@ -330,7 +335,7 @@ class GradBuckets:
     def _launch(self, b):
         import torch.distributed as dist
         self.launched.append(b)
-        if self.world == 1 or self.deferred:
+        if not self.active or self.deferred:
             return
         lo, hi = self.buckets[b]
         g = self.fp.grad[lo:hi]
@@ -365,7 +370,7 @@ class GradBuckets:
 
     def reduce_deferred(self):
         """After a replayed forward + backward (deferred mode): the bucket all-reduces in backward order on the caller's stream, then 1/world."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 self.reduce_bucket(b)
         self._scale()
@@ -376,7 +381,7 @@ class GradBuckets:
         (fp32 -> bf16 -> all_reduce -> fp32: two HIP conversion launches; the sum itself is then taken in bf16 by the collective: every
         gradient element carries a relative error of ~2^-9 per addend, measured in tests/test_gpu_training.py)."""
         import torch.distributed as dist
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.buckets[b]
         g = self.fp.grad[lo:hi]
@@ -400,13 +405,13 @@ class GradBuckets:
     def all_reduce(self):
         import torch.distributed as dist
         self.fp.collect()
-        if self.world > 1:
+        if self.active:
             for lo, hi in self.buckets:
                 dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         self._scale()
 
     def _scale(self):
-        if self.world == 1:
+        if not self.active:
             return
         g = self.fp.grad
         if g.is_cuda:

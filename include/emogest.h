@@ -136,7 +136,9 @@ typedef struct EgGeneratorConfig {
                                    audio fc1 -> fc2 :128-130) into one product each at pack time -- exact algebra in eval mode,
                                    different rounding, fewer FLOPs than the reference graph: OFF for parity runs
                                    [3] 1 = keep the SE tail of identity blocks as a separate pass (default 0: gate from conv1's output
-                                   moments + relu(y*gate + x) in conv2's epilogue, eg_se_gate_pre / eg_conv3x3_se) */
+                                   moments + relu(y*gate + x) in conv2's epilogue, eg_se_gate_pre / eg_conv3x3_se)
+                                   [4] 1 = the caller keeps several batches in flight on this GPU (ClipPipeline lanes): the pre-split products
+                                   take the 128 x 128 tile from 64 workgroups up (less CU time, more latency); 0 = tile for stand-alone latency */
 } EgGeneratorConfig;
 
 typedef struct EgGenerator EgGenerator;

@@ -1,0 +1,237 @@
+"""nn.DataParallel over the module mirrors -- what the reference's caller does to every model when device_count() > 1
+(test_emotion_gesture_diversity_iterative.py:137-138 generator, :150-151 FGD, :160-161 skeleton classifier, :169-170 CVAE;
+train_audio_classifier_K_fold.py:129-130 EmotionNet).
+
+torch.nn.parallel.replicate rebuilds the replicas on every forward with `_parameters == {}`; the mirrors keep what must
+persist (engines + packed arenas, per-device parameter shadows, locks) on the ORIGIN module (modules.ReplicaAware).
+CPU tests: the replica bookkeeping.  GPU tests: `DataParallel(model, device_ids=[0, 0])` -- replicate + scatter + threads +
+gather on the one GPU of the test box -- equals the unwrapped model, with the arena uploaded once."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import build_mirror
+from emotiongestures_amd.synth import load_synth_weights, synth_inputs
+
+
+def _wrapped_classes():
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.harness import MLP_Reconstruct, SkeletonTransformer
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    from emotiongestures_amd.model.motion_ae import MotionAE
+    return [lambda: build_mirror("spatial", 34, 126, 4, 4, seed=1), lambda: MLP_Reconstruct_v3(frames=34).eval(),
+            lambda: MLP_Reconstruct(pose_dim=126).eval(),
+            lambda: SkeletonTransformer(class_dim=8, pose_dim=126, d_word_vec=64, d_model=64, d_inner=128, n_layers=1, n_head=2, d_k=32, d_v=32,
+                                        n_position=34).eval(),
+            lambda: EmotionNet().eval(), lambda: MotionAE(126, 32).eval()]
+
+
+# ---- CPU: bookkeeping ------------------------------------------------------------------------------------------------------
+def _replicate_like_torch(network):
+    """torch.nn.parallel.replicate for ONE target device without the CUDA broadcast (torch/nn/parallel/replicate.py): every module
+    is `_replicate_for_data_parallel()`-ed, children are re-wired to the replicas, parameters / buffers become plain tensor attributes."""
+    modules = list(network.modules())
+    index = {m: i for i, m in enumerate(modules)}
+    copies = [m._replicate_for_data_parallel() for m in modules]
+    for m, r in zip(modules, copies):
+        for key, child in m._modules.items():
+            r._modules[key] = None if child is None else copies[index[child]]
+        for key, p in m._parameters.items():
+            setattr(r, key, None if p is None else p.detach().clone())
+        for key, b in m._buffers.items():
+            r._buffers[key] = None if b is None else b.detach().clone()
+    return copies[0]
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_replica_keeps_its_origin_and_shares_the_origins_state(idx):
+    from emotiongestures_amd.modules import ReplicaAware
+    m = _wrapped_classes()[idx]()
+    assert isinstance(m, ReplicaAware) and m._origin() is m
+    r = _replicate_like_torch(m)
+    assert len(list(r.parameters())) == 0 and len(list(m.parameters())) > 0     # the situation the mixin exists for
+    assert r._origin() is m and r._dp() is m._dp()
+    rr = r._replicate_for_data_parallel()                # a replica of a replica still points at the real origin
+    assert rr._origin() is m
+    # the state is per origin: copies start empty and the module stays picklable / deep-copyable with its lock
+    m._dp().engines["cuda:7"] = ["sentinel", None]
+    c = copy.deepcopy(m)
+    assert c._dp() is not m._dp() and c._dp().engines == {} and c._origin() is c
+    p = pickle.loads(pickle.dumps(m._dp()))
+    assert p.engines == {} and p.shadows == {}
+    # state_dict schema untouched by the bookkeeping attributes
+    assert not any(k.startswith("_dp") for k in m.state_dict())
+
+
+def test_replica_in_train_mode_is_refused_with_the_data_parallel_launcher_named():
+    m = build_mirror("spatial", 34, 126, 4, 4, seed=1).train()
+    r = _replicate_like_torch(m)
+    x = torch.zeros(1, 128, 124)
+    with pytest.raises(RuntimeError, match=r"bench\.py --gpus N"):
+        r(x, torch.zeros(1, 60, dtype=torch.long), torch.zeros(1, 4, 126), None)
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    e = _replicate_like_torch(EmotionNet().train())
+    with pytest.raises(RuntimeError, match="one trainer per process"):
+        e(torch.zeros(1, 128, 128))
+
+
+def test_engine_on_cpu_still_refuses_and_replica_resolves_version_from_origin():
+    from emotiongestures_amd import _lib as L
+    m = build_mirror("spatial", 34, 126, 4, 4, seed=1)
+    r = _replicate_like_torch(m)
+    assert len(list(r.parameters())) == 0 and len(r.state_dict()) < len(m.state_dict())
+    assert r._weights_version() == m._weights_version() and len(r._weights_version()) > 400
+    with pytest.raises(L.EgError, match="no CPU fallback"):
+        r.engine()
+    with pytest.raises(L.EgError, match="no CPU fallback"):
+        m.engine("cpu")
+    assert m._engine is None
+
+
+def test_device_shadow_is_built_once_and_refreshed_on_weight_change():
+    """The operator-composed mirrors compute on a per-device shadow of the origin (here on the `meta` device: the bookkeeping
+    needs no GPU): built once, reused by every later replica, refreshed in place when the origin's weights change."""
+    from emotiongestures_amd.harness import MLP_Reconstruct
+    m = MLP_Reconstruct(pose_dim=126).eval()
+    r1, r2 = _replicate_like_torch(m), _replicate_like_torch(m)
+    meta = torch.device("meta")
+    t_home, _ = r1._device_twin(next(m.parameters()).device)
+    assert t_home is m
+    t1, lock1 = r1._device_twin(meta)
+    t2, lock2 = r2._device_twin(meta)
+    assert t1 is t2 and lock1 is lock2 and t1 is not m and next(t1.parameters()).device == meta
+    assert list(t1.state_dict()) == list(m.state_dict())
+    ver = m._dp().shadows["meta"][1]
+    with torch.no_grad():
+        m.Encoder[0].weight.add_(1.0)
+    t3, _ = _replicate_like_torch(m)._device_twin(meta)
+    assert t3 is t1 and m._dp().shadows["meta"][1] != ver
+    m.train()
+    assert _replicate_like_torch(m)._device_twin(meta)[0].training
+
+
+# ---- GPU: the wrap the reference's caller performs ------------------------------------------------------------------------
+def _dp(model):
+    # the reference's order: wrap, then .to(device), load_state_dict with the 'module.' prefix, .eval() (:137-143)
+    return nn.DataParallel(model, device_ids=[0, 0])
+
+
+@pytest.mark.gpu
+def test_generator_and_cvae_under_data_parallel_equal_the_unwrapped_modules():
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    dev = torch.device("cuda:0")
+    B = 6
+    inp = {k: torch.from_numpy(v) for k, v in synth_inputs(B, 34, 126, 4, seed=11).items()}
+    gen = build_mirror("spatial", 34, 126, 4, 4, seed=11, precision="bf16x3")
+    sd = {"module." + k: v.clone() for k, v in gen.state_dict().items()}
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 11).eval()
+    wrapped = _dp(build_mirror("spatial", 34, 126, 4, 4, seed=5, precision="bf16x3"))       # other weights until load_state_dict
+    wrapped.to(dev)
+    wrapped.load_state_dict(sd)
+    wrapped = wrapped.eval()
+    vae_w = _dp(vae).to(dev).eval()
+    gen.to(dev)
+    spec, text, pre, label = (inp[k].to(dev) for k in ("spec", "text", "pre_pose", "label"))
+    with torch.no_grad():
+        sampled = vae_w.module.sample(label, z=inp["z"])              # `sample` is not a DataParallel method: through .module
+        ref = gen(spec, text, pre, sampled)
+        for _ in range(3):                                            # replicas are rebuilt per forward; the engine must not be
+            out = wrapped(spec, text, pre, sampled)
+        rec_w = vae_w(sampled, label, inp["z"].to(dev))               # CVAE.forward under DataParallel (scattered, gathered)
+        rec = vae.forward(sampled, label, inp["z"].to(dev))
+    assert len(out) == 5
+    for a, r in zip(out, ref):
+        assert a.shape == r.shape and torch.equal(a, r)               # the spatial variant is per-clip: scatter changes nothing
+    for a, r in zip(rec_w, rec):
+        assert torch.equal(a, r)
+    eng = wrapped.module._engine
+    assert eng is not None and eng.uploads == 1, "the arena must be packed + uploaded once per device, not per forward"
+    assert list(wrapped.module._dp().engines) == ["cuda:0"]
+    assert vae._engine.uploads == 1
+    # a weight change is seen through the wrap (version key from the origin's parameters): one more upload, new outputs
+    with torch.no_grad():
+        wrapped.module.post_projector[6].bias.add_(0.5)
+        out2 = wrapped(spec, text, pre, sampled)
+    assert wrapped.module._engine.uploads == 2
+    np.testing.assert_allclose((out2[0] - out[0]).cpu().numpy(), 0.5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_memory_variant_under_data_parallel_equals_per_chunk_forwards():
+    """Models_memory couples the clips of a batch (TM_Memory_Net, Models_memory.py:288-289): under DataParallel each replica sees
+    its chunk, as in the reference -- the wrapped output equals the unwrapped model run chunk by chunk."""
+    dev = torch.device("cuda:0")
+    B = 8
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in synth_inputs(B, 34, 126, 4, seed=12).items() if k != "z"}
+    gen = build_mirror("memory", 34, 126, 4, 4, seed=12).to(dev)
+    wrapped = _dp(gen).eval()
+    with torch.no_grad():
+        out = wrapped(inp["spec"], inp["text"], inp["pre_pose"], None)
+        halves = [gen(inp["spec"][s], inp["text"][s], inp["pre_pose"][s], None) for s in (slice(0, 4), slice(4, 8))]
+    assert torch.equal(out[0], torch.cat([h[0] for h in halves]))
+    assert gen._engine.uploads == 1
+
+
+@pytest.mark.gpu
+def test_fgd_classifier_emotionnet_motion_ae_under_data_parallel():
+    from emotiongestures_amd.harness import MLP_Reconstruct, SkeletonTransformer
+    from emotiongestures_amd.model.audio_emotion_classifer import EmotionNet
+    from emotiongestures_amd.model.motion_ae import MotionAE
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    pose = torch.randn(6, 34, 126, generator=g).to(dev)
+    cases = [
+        (load_synth_weights(MLP_Reconstruct(pose_dim=126), 2).eval(), (pose,)),
+        (load_synth_weights(SkeletonTransformer(class_dim=8, pose_dim=126, d_word_vec=512, d_model=512, d_inner=2048, n_layers=3, n_head=8,
+                                                d_k=64, d_v=64, n_position=34), 2).eval(), (pose,)),
+        (load_synth_weights(EmotionNet(), 2).eval(), (torch.randn(4, 128, 128, generator=g).to(dev),)),
+        (load_synth_weights(MotionAE(126, 32), 2).eval(), (pose,)),
+    ]
+    for model, args in cases:
+        model.to(dev)
+        wrapped = _dp(model).eval()
+        with torch.no_grad():
+            ref = model(*args)
+            out = wrapped(*args)
+            out = wrapped(*args)
+        for a, r in zip(out if isinstance(out, tuple) else (out,), ref if isinstance(ref, tuple) else (ref,)):
+            assert a.shape == r.shape
+            # row-independent operators: bitwise, except where a product's tile policy depends on the row count (then 1e-5)
+            assert torch.allclose(a, r, rtol=1e-5, atol=1e-5), type(model).__name__
+        assert model._dp().shadows == {}, "same-device replicas compute on the origin; no shadow copy"
+    # train() under the wrap: the clear error, not a StopIteration from an empty replica
+    net = cases[2][0]
+    wrapped = _dp(net).train()
+    with pytest.raises(RuntimeError, match=r"bench\.py --gpus N"):
+        wrapped(cases[2][1][0])
+
+
+@pytest.mark.gpu
+def test_eval_loop_runs_with_every_model_wrapped_like_the_reference_caller():
+    """harness.evaluate (the reference's test_model hot loop) with generator, FGD and classifier wrapped; the CVAE through `.module`."""
+    from emotiongestures_amd import harness as H
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    dev = torch.device("cuda:0")
+    gen = build_mirror("spatial", 34, 126, 4, 4, seed=21).to(dev)
+    vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 21).eval().to(dev)
+    fgd = load_synth_weights(H.MLP_Reconstruct(pose_dim=126), 21).eval().to(dev)
+    cls = load_synth_weights(H.SkeletonTransformer(class_dim=8, pose_dim=126, d_word_vec=512, d_model=512, d_inner=2048, n_layers=3, n_head=8,
+                                                   d_k=64, d_v=64, n_position=34), 21).eval().to(dev)
+    batches, zs = [], []
+    for i in range(2):
+        inp = synth_inputs(4, 34, 126, 4, seed=30 + i)
+        tgt = torch.from_numpy(np.concatenate([inp["pre_pose"], np.tile(inp["pre_pose"][:, -1:], (1, 30, 1))], 1))
+        batches.append({"spec": torch.from_numpy(inp["spec"]), "text": torch.from_numpy(inp["text"]), "pose_seq": tgt,
+                        "label": torch.from_numpy(inp["label"])})
+        zs.append(torch.from_numpy(inp["z"]))
+    np.random.seed(0)
+    plain = H.evaluate(gen, vae, fgd, cls, batches, 4, dev, z_list=zs)
+    np.random.seed(0)
+    wrapped = H.evaluate(_dp(gen).eval(), _dp(vae).eval().module, _dp(fgd).eval(), _dp(cls).eval(), batches, 4, dev, z_list=zs)
+    assert plain.keys() == wrapped.keys()
+    for k in plain:
+        assert abs(plain[k] - wrapped[k]) <= 1e-4 * max(1.0, abs(plain[k])), (k, plain[k], wrapped[k])

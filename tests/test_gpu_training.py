@@ -1255,6 +1255,40 @@ def test_bench_train_two_ranks_share_one_gpu_over_gloo(graph):
         assert line["allreduce_exposed_ms_per_step"] is not None
 
 
+def test_segmented_step_over_a_one_rank_rccl_group_equals_the_single_graph_step():
+    """EG_FORCE_COLLECTIVES=1: `bench.py --gpus 1 --train` initialises a 1-rank RCCL group (`init_process_group("nccl", device_id=dev)`) and runs
+    the data-parallel step -- 4 hipGraph segments, every bucket's all_reduce issued by torch.distributed on the side stream between the segments
+    (f32 payload, then the bf16 staging: eg_f32_to_bf16 -> all_reduce -> eg_bf16_to_f32), 1/world scaling, Adam -- exactly as the N-GPU run will.
+    A sum over one rank is the identity, so with the f32 payload the parameters after the run are BITWISE those of the one-graph step; with the bf16
+    payload every gradient is rounded to bfloat16 once (the final loss stays within 2 %).  Nothing about xGMI is measured here; the stream order,
+    the staging and the `device_id` init are executed on hardware before the first multi-GPU run."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "bench.py", "--gpus", "1", "--train", "--train-batch", "2", "--steps", "3", "--warmup", "1", "--no-extra-legs"]
+
+    def run(extra_env):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", EG_TRAIN_DIGEST="1", EG_TRAIN_SIDE_CVAE="0", **extra_env)
+        env.pop("EG_BENCH_BACKEND", None)
+        r = subprocess.run(base, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    plain = run({})
+    f32 = run({"EG_FORCE_COLLECTIVES": "1"})
+    bf16 = run({"EG_FORCE_COLLECTIVES": "1", "EG_GRAD_PAYLOAD": "bf16"})
+    assert plain["launch"].startswith("one captured hipGraph") and "collectives" not in plain
+    for line, payload in ((f32, "f32"), (bf16, "bf16")):
+        assert line["launch"].startswith("4 hipGraph segments") and f"({payload} payload)" in line["launch"], line["launch"]
+        c = line["collectives"]
+        assert c["backend"].startswith("rccl") and c["world_size"] == 1 and c["ranks_seen_by_all_reduce"] == 1 and c["ranks_seen_by_all_gather"] == [0]
+        assert c["forced_at_world_1"] and c["rccl_version"] and c["rccl_version"][0].isdigit(), c
+        assert 0 < line["allreduce_exposed_bytes_per_step"] < 0.01 * line["config"]["gradient_bytes_per_step"]
+    assert f32["param_digest"] == plain["param_digest"], (f32["final_loss"], plain["final_loss"])
+    assert f32["final_loss"] == plain["final_loss"]
+    assert bf16["param_digest"] != plain["param_digest"]
+    assert abs(bf16["final_loss"] - plain["final_loss"]) < 0.02 * abs(plain["final_loss"]), (bf16["final_loss"], plain["final_loss"])
+
+
 def test_eval_after_training_sees_the_updated_weights_and_statistics():
     """FlatAdam and the BatchNorm kernels write through raw pointers; the version bumps make the inference engine repack: after a few training
     steps `model.eval()` equals a fresh mirror loaded with the trained state_dict (and differs from the untrained one)."""
