@@ -409,7 +409,8 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     F.manual_seed(1234 + rank)
     both = torch.nn.ModuleList([model, vae])         # one flat parameter / gradient buffer, one optimiser, one set of buckets
     fp = flatten_parameters(both)
-    fp.enable_weight_images()                        # every Linear / conv weight image of a step from one launch (after the optimiser)
+    from emotiongestures_amd.train import nets as _nets
+    fp.enable_weight_images(*_nets.weight_image_plan(both))     # every Linear / conv weight image of a step from one launch (after the optimiser); Q|K|V and K|V as one image each
     opt = FlatAdam(fp, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)           # test_emotion_gesture_diversity_iterative.py:355-366 (lr 2e-4)
     collective = world > 1 or (dist is not None and os.environ.get("EG_FORCE_COLLECTIVES") == "1")       # world 1 + EG_FORCE_COLLECTIVES: the data-parallel step over a 1-rank RCCL group
     gb = GradBuckets(fp, bucket_mb=25.0, split_at=stage_splits(model, fp) if collective else ()).attach()     # buckets end at the segmented backward's phase boundaries

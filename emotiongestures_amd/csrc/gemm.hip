@@ -22,7 +22,18 @@ struct GemmArgs {
     unsigned short* yimg = nullptr;
     int yKO = 0, yoct0 = 0;
     int xoct0 = 0;              // pre-split X: first octet of this product's K range inside the X images
+    // training epilogue (eg_linear_ex): ReLU-backward gate and nn.Dropout on the product, both before the residual add
+    const float* gate = nullptr; int ldg = 0;       // v = gate[m][n] > 0 ? v : 0
+    EgDropout drop;                                 // thr = 0: off; counter = offset + m * N + n (the flat index eg_dropout uses on a [M, N] tensor)
 };
+
+// v = acc + bias, then the two training masks: ReLU backward by the saved activation, Dropout from the counter hash (shared by the GEMM epilogue and
+// the split-K fold)
+__device__ __forceinline__ float epi_masks(const GemmArgs& a, float v, int m, int n, unsigned int dseed) {
+    if (a.gate && !(a.gate[(size_t)m * a.ldg + n] > 0.f)) v = 0.f;
+    if (a.drop.thr) v = dropout_keep(dseed, a.drop.offset + (unsigned long long)m * a.N + n, a.drop.thr) ? v * a.drop.inv_keep : 0.f;
+    return v;
+}
 
 __device__ __forceinline__ f4 load_x_quad(const GemmArgs& a, int m, int k, int kend) {
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
@@ -39,9 +50,12 @@ __device__ __forceinline__ f4 load_x_quad(const GemmArgs& a, int m, int k, int k
 }
 
 
-// v = acc + bias + res1; relu; (+res2, relu); lane owns 4 consecutive n of row m (+16 per t), n += 16 per tile
-template <int MT, int NT>
+// v = acc + bias; (gate, dropout: training); + res1; relu; (+res2, relu); lane owns 4 consecutive n of row m (+16 per t), n += 16 per tile
+// TRAIN: compile the two training masks in (the fp32-input kernels that carry the training path); the pre-split inference kernels leave them out.
+template <int MT, int NT, bool TRAIN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[MT][NT], int mbase, int nbase) {
+    const bool masks = TRAIN && (a.gate != nullptr || a.drop.thr != 0) && !a.partial;
+    const unsigned int dseed = (masks && a.drop.thr) ? dropout_seed(a.drop.seed, a.drop.epoch) : 0u;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = mbase + t * 16;
@@ -63,6 +77,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[MT][N
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (nn + r < a.N) v[r] += a.bias[nn + r];
+            }
+            if (masks) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nn + r < a.N) v[r] = epi_masks(a, v[r], m, nn + r, dseed);
             }
             if (a.res1) {
                 const float* rp = a.res1 + (size_t)m * a.ldr + nn;
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    gemm_epilogue<2, 2>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+    gemm_epilogue<2, 2, true>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
 }
 
 // ---- split-bf16 path: 64x64 tile, K-step 64 -----------------------------------------------------------------
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this step's LDS reads are done before the slot is reused
         wg_barrier();
     }
-    gemm_epilogue<2, WN>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
+    gemm_epilogue<2, WN, true>(a, acc, m0 + wm + li, n0 + wn + kq * 4);
 }
 
 template <int TERMS, int WN>
@@ -819,15 +838,18 @@ __global__ __launch_bounds__(256) void split_tile_kernel(const float* __restrict
     (void)total;
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
-                                                            float* __restrict__ y, int ldc, int M, int N, int splits, int relu) {
+// fold of the split-K partials with the full epilogue of gemm_epilogue (bias, gate, dropout, res1, relu, res2), fixed order over the splits
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a, int splits) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * N) return;
-    const int m = i / N, n = i - m * N;
-    float s = bias ? bias[n] : 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * M * N + i];
-    if (relu) s = fmaxf(s, 0.f);
-    y[(size_t)m * ldc + n] = s;
+    if (i >= a.M * a.N) return;
+    const int m = i / a.N, n = i - m * a.N;
+    float s = a.bias ? a.bias[n] : 0.f;
+    for (int z = 0; z < splits; ++z) s += a.partial[(size_t)z * a.M * a.N + i];
+    if (a.gate || a.drop.thr) s = epi_masks(a, s, m, n, a.drop.thr ? dropout_seed(a.drop.seed, a.drop.epoch) : 0u);
+    if (a.res1) s += a.res1[(size_t)m * a.ldr + n];
+    if (a.relu) s = fmaxf(s, 0.f);
+    if (a.res2) s = fmaxf(s + a.res2[(size_t)m * a.ldr + n], 0.f);
+    a.y[(size_t)m * a.ldc + n] = s;
 }
 
 int launch_gemm(GemmArgs& a, int splits, int precision, hipStream_t st) {
@@ -846,6 +868,15 @@ int launch_gemm(GemmArgs& a, int splits, int precision, hipStream_t st) {
         return wide ? launch_glds<1, 4>(a, splits, st) : launch_glds<1, 2>(a, splits, st);
     }
     return eg_check_launch("gemm");
+}
+
+// split-K: raw partial sums from `splits` K slices, then one fold that applies the whole epilogue (fixed order: deterministic)
+int launch_splitk(GemmArgs& a, int splits, int precision, hipStream_t st) {
+    a.k_per_split = (int)eg_round_up(eg_cdiv(a.K, splits), 64);
+    const int nsplit = eg_cdiv(a.K, a.k_per_split);
+    if (int rc = launch_gemm(a, nsplit, precision, st)) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(eg_cdiv(a.M * a.N, 256)), dim3(256), 0, st, a, nsplit);
+    return eg_check_launch("splitk_reduce");
 }
 
 int fill_common(GemmArgs& a, const float* x, int lda, const float* w, int ldw, int m, int n, int k, int precision,
@@ -925,15 +956,34 @@ extern "C" int eg_linear_splitk(const float* x, int32_t lda, const float* w, int
     int rc = fill_common(a, x, lda, w, ldw, m, n, k, precision, "eg_linear_splitk");
     if (rc) return rc;
     EG_REQUIRE(y && partial && splits > 0, EG_ERR_BAD_ARG, "eg_linear_splitk: null output/partial");
-    a.bias = nullptr; a.res1 = a.res2 = nullptr; a.ldr = 0; a.y = y; a.ldc = ldc; a.relu = 0;
+    a.bias = bias; a.res1 = a.res2 = nullptr; a.ldr = 0; a.y = y; a.ldc = ldc; a.relu = relu;
     a.a_shift = 0; a.a_seq = 1; a.partial = partial;
-    a.k_per_split = (int)eg_round_up(eg_cdiv(k, splits), 64);
-    const int nsplit = eg_cdiv(k, a.k_per_split);
-    rc = launch_gemm(a, nsplit, precision, (hipStream_t)stream);
+    return launch_splitk(a, splits, precision, (hipStream_t)stream);
+}
+
+// The extended product of the training path (see include/emogest.h: EgLinearArgs).
+extern "C" int eg_linear_ex(const EgLinearArgs* p, void* stream) {
+    EG_REQUIRE(p, EG_ERR_BAD_ARG, "eg_linear_ex: null argument block");
+    GemmArgs a;
+    int rc = fill_common(a, p->x, p->lda, p->w, p->ldw, p->m, p->n, p->k, p->precision, "eg_linear_ex");
     if (rc) return rc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(eg_cdiv(m * n, 256)), dim3(256), 0, (hipStream_t)stream, partial, bias, y, ldc,
-                       m, n, nsplit, relu);
-    return eg_check_launch("splitk_reduce");
+    EG_REQUIRE(p->y, EG_ERR_BAD_ARG, "eg_linear_ex: null output");
+    EG_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, EG_ERR_BAD_ARG, "eg_linear_ex: drop_p=%f", (double)p->drop_p);
+    a.bias = p->bias; a.res1 = p->res1; a.res2 = p->res2; a.ldr = p->ldr; a.y = p->y; a.ldc = p->ldc; a.relu = p->relu;
+    a.a_shift = 0; a.a_seq = 1; a.k_per_split = (int)eg_round_up(p->k, 64); a.partial = nullptr;
+    a.gate = p->gate_src; a.ldg = p->ldg;
+    if (p->drop_p > 0.f) {
+        a.drop.thr = (unsigned int)((double)p->drop_p * 4294967296.0);
+        a.drop.inv_keep = 1.0f / (1.0f - p->drop_p);
+        a.drop.seed = p->drop_seed; a.drop.offset = p->drop_offset; a.drop.epoch = p->drop_epoch;
+    }
+    if (p->splits >= 2) {
+        EG_REQUIRE(p->partial, EG_ERR_BAD_ARG, "eg_linear_ex: split-K needs a partial buffer of splits*M*N floats");
+        a.partial = p->partial;
+        return launch_splitk(a, p->splits, p->precision, (hipStream_t)stream);
+    }
+    EgProfScope prof(p->precision == EG_PREC_F32 ? 5 : 2, 2.0 * p->m * (double)p->n * p->k, (hipStream_t)stream);
+    return launch_gemm(a, 1, p->precision, (hipStream_t)stream);
 }
 
 // X -> pre-split tile-planar bf16 images (workspace-resident; consumed by eg_linear_presplit).  images must hold

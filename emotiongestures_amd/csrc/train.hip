@@ -972,6 +972,87 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// LayerNorm backward for the fused transformer blocks: a wave walks RW rows with the row held in registers (NC column slots per lane), keeps the two
+// affine-gradient column sums (sum dy, sum dy * xhat) in registers across its rows, and the workgroup's four waves are folded through LDS in a fixed
+// order into one partial per workgroup ([blk][2][D], the layout col_finalize_kernel folds).  Optional second output: dx with the Dropout mask of the
+// branch that precedes the residual add.
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_ex_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                        float* __restrict__ dx, float* __restrict__ dxm, float* __restrict__ part, int rows, int D,
+                                                        int RW, float eps, EgDropout dr) {
+    extern __shared__ float lsum[];                      // [4 waves][2][D]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * RW;
+    const unsigned int dseed = dr.thr ? dropout_seed(dr.seed, dr.epoch) : 0u;
+    const float invD = 1.0f / (float)D;
+    float sb[NC], sg[NC], gm[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        sb[i] = sg[i] = 0.f;
+        gm[i] = (i * 64 + lane < D) ? gamma[i * 64 + lane] : 0.f;
+    }
+    for (int j = 0; j < RW; ++j) {
+        const int row = row0 + j;
+        if (row >= rows) break;
+        const float* xr = x + (size_t)row * D;
+        const float* dr_ = dy + (size_t)row * D;
+        float xv[NC], dv[NC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const bool ok = i * 64 + lane < D;
+            xv[i] = ok ? xr[i * 64 + lane] : 0.f;
+            dv[i] = ok ? dr_[i * 64 + lane] : 0.f;
+            s += xv[i];
+        }
+        const float mean = wave_sum(s) * invD;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float d = (i * 64 + lane < D) ? xv[i] - mean : 0.f;
+            ss += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) * invD + eps);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float xh = (xv[i] - mean) * rstd, gd = gm[i] * dv[i];      // columns >= D: gm = dv = 0
+            xv[i] = xh;
+            a += gd;
+            b += gd * xh;
+        }
+        a = wave_sum(a) * invD;
+        b = wave_sum(b) * invD;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D) {
+                const float g = rstd * (gm[i] * dv[i] - a - xv[i] * b);
+                dx[(size_t)row * D + c] = g;
+                if (dxm) dxm[(size_t)row * D + c] = dropout_keep(dseed, dr.offset + (unsigned long long)row * D + c, dr.thr) ? g * dr.inv_keep : 0.f;
+                sb[i] += dv[i];
+                sg[i] += dv[i] * xv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < D) {
+            lsum[(wave * 2) * D + c] = sb[i];
+            lsum[(wave * 2 + 1) * D + c] = sg[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c / D, col = c - which * D;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += lsum[(w * 2 + which) * D + col];
+        part[((size_t)blockIdx.x * 2 + which) * D + col] = t;
+    }
+}
+
 // ---- attention backward (Full_model/Modules.py:13-23), one workgroup per (head, clip), Lq, Lk <= 64 -------------------------
 // given P (the forward's probabilities) and dO:  dV = P^T dO;  dP = dO V^T;  dS = P * (dP - rowsum(dP * P));
 // dQ = dS K / temp;  dK = dS^T Q / temp
@@ -1653,6 +1734,34 @@ extern "C" int eg_layernorm_backward(const float* x, const float* dy, const floa
     EG_REQUIRE(x && dy && gamma && dx && xhat && rows > 0 && d > 0, EG_ERR_BAD_ARG, "eg_layernorm_backward: bad argument");
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(eg_cdiv(rows, 4)), dim3(256), 0, ST, x, dy, gamma, dx, xhat, rows, d, eps);
     return eg_check_launch("layernorm_backward");
+}
+
+namespace {
+inline int ln_ex_rows_per_wave(int rows) { const int rw = eg_cdiv(rows, 4 * 256); return rw < 1 ? 1 : (rw > 8 ? 8 : rw); }
+}  // namespace
+extern "C" int64_t eg_layernorm_backward_ex_workspace_floats(int32_t rows, int32_t d) {
+    return (int64_t)eg_cdiv(rows, 4 * ln_ex_rows_per_wave(rows)) * 2 * d;
+}
+extern "C" int eg_layernorm_backward_ex(const float* x, const float* dy, const float* gamma, float* dx, float* dx_dropped, float* dgamma, float* dbeta,
+                                        int32_t rows, int32_t d, float eps, float drop_p, uint32_t drop_seed, uint64_t drop_offset,
+                                        const int32_t* epoch_dev, float* workspace, void* stream) {
+    EG_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && workspace && rows > 0, EG_ERR_BAD_ARG, "eg_layernorm_backward_ex: bad argument");
+    EG_REQUIRE(d > 0 && (d & 63) == 0 && d <= 1024, EG_ERR_UNSUPPORTED, "eg_layernorm_backward_ex: d=%d (multiple of 64, <= 1024)", d);
+    EG_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f) == (dx_dropped == nullptr), EG_ERR_BAD_ARG,
+               "eg_layernorm_backward_ex: dx_dropped goes with drop_p > 0 (p=%f)", (double)drop_p);
+    EgDropout dr;
+    if (drop_p > 0.f) {
+        dr.thr = (unsigned int)((double)drop_p * 4294967296.0);
+        dr.inv_keep = 1.0f / (1.0f - drop_p);
+        dr.seed = drop_seed; dr.offset = drop_offset; dr.epoch = epoch_dev;
+    }
+    const int rw = ln_ex_rows_per_wave(rows), nblk = eg_cdiv(rows, 4 * rw);
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    if (d <= 512) hipLaunchKernelGGL((ln_bwd_ex_kernel<8>), dim3(nblk), dim3(256), smem, ST, x, dy, gamma, dx, dx_dropped, workspace, rows, d, rw, eps, dr);
+    else hipLaunchKernelGGL((ln_bwd_ex_kernel<16>), dim3(nblk), dim3(256), smem, ST, x, dy, gamma, dx, dx_dropped, workspace, rows, d, rw, eps, dr);
+    if (int rc = eg_check_launch("layernorm_backward_ex")) return rc;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(d, 4)), dim3(256), 0, ST, workspace, nblk, d, dbeta, dgamma, 1.0f);
+    return eg_check_launch("layernorm_backward_ex_fold");
 }
 
 extern "C" int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,

@@ -305,9 +305,10 @@ def mpjre(target: torch.Tensor, pred: torch.Tensor) -> float:
     return float(torch.mean(torch.absolute(target.reshape(b, -1, 6) - pred.reshape(b, -1, 6))))
 
 
-def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
-    """model/FHD_score.py:159-217: ||mu1-mu2||^2 + Tr(C1 + C2 - 2 sqrt(C1 C2)), float64, scipy sqrtm; returns 100 when the
-    square root has a non-negligible imaginary part (as upstream)."""
+def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6, imaginary="return_100"):
+    """model/FHD_score.py:159-217: ||mu1-mu2||^2 + Tr(C1 + C2 - 2 sqrt(C1 C2)), float64, scipy sqrtm.  A square root with a non-negligible
+    imaginary part returns 100 as that file does (`imaginary="return_100"`); model/embedding_space_evaluator.py:156-209 carries the same
+    formula but raises ValueError there (`imaginary="raise"`) -- its one difference, so that copy delegates here."""
     from scipy import linalg
 
     mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
@@ -320,6 +321,8 @@ def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
         covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
     if np.iscomplexobj(covmean):
         if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            if imaginary == "raise":
+                raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
             return 100
         covmean = covmean.real
     return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)

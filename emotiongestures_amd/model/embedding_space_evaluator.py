@@ -74,20 +74,7 @@ class EmbeddingSpaceEvaluator:
 
     @staticmethod
     def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
-        """:156-209: the pytorch-fid formula in float64; unlike model/FHD_score.py's copy it raises ValueError on a
-        non-negligible imaginary part (get_scores maps that to 1e10)."""
-        from scipy import linalg
-        mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
-        sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
-        assert mu1.shape == mu2.shape, "Training and test mean vectors have different lengths"
-        assert sigma1.shape == sigma2.shape, "Training and test covariances have different dimensions"
-        diff = mu1 - mu2
-        covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
-        if not np.isfinite(covmean).all():
-            offset = np.eye(sigma1.shape[0]) * eps
-            covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
-        if np.iscomplexobj(covmean):
-            if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
-                raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
-            covmean = covmean.real
-        return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+        """:156-209: the Frechet distance of harness.calculate_frechet_distance; unlike model/FHD_score.py's variant a non-negligible
+        imaginary part raises ValueError (get_scores maps that to 1e10)."""
+        from ..harness import calculate_frechet_distance as frechet
+        return frechet(mu1, sigma1, mu2, sigma2, eps=eps, imaginary="raise")

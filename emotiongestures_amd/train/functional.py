@@ -178,10 +178,30 @@ def _pack_linear(w, transpose=False):
     return img, (k + 63) // 64 * 64
 
 
-def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False):
-    """y[M,N] = x[M,K] w[N,K]^T (+bias) (+res) (relu) on the MFMA GEMM (eg_linear): fp32, or split-bf16 under set_precision("bf16x3").
-    w_transposed: w is [K,N] and the product is x w (the input gradient of a Linear)."""
-    lib = _lib()
+def _linear_ex(x, lda, w, ldw, bias, res, y, M, N, K, relu, prec, gate=None, drop=None, splits=0):
+    """One eg_linear_ex call (include/emogest.h: EgLinearArgs).  drop = (p, seed, offset, epoch tensor | None) of a Dropout site or None."""
+    a = L.EgLinearArgs()
+    a.x, a.w, a.bias, a.res1, a.res2, a.y = x.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None), \
+        (res.data_ptr() if res is not None else None), None, y.data_ptr()
+    a.gate_src = gate.data_ptr() if gate is not None else None
+    a.lda, a.ldw, a.ldr, a.ldc, a.ldg = lda, ldw, N, N, N
+    a.m, a.n, a.k, a.relu, a.precision, a.splits = M, N, K, int(relu), prec, int(splits)
+    a.drop_p = 0.0
+    if drop is not None and drop[0] > 0.0:
+        a.drop_p, a.drop_seed, a.drop_offset = float(drop[0]), int(drop[1]), int(drop[2])
+        a.drop_epoch = drop[3].data_ptr() if drop[3] is not None else None
+    part = None
+    if splits >= 2:
+        part = _scratch(y.device, splits * M * N, "splitk")
+        a.partial = part.data_ptr()
+    L.check(_lib().eg_linear_ex(C.byref(a), _stream(y.device)), "eg_linear_ex")
+    return y
+
+
+def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False, gate=None, drop=None):
+    """y[M,N] = epi(x[M,K] w[N,K]^T) on the MFMA GEMM (eg_linear_ex): fp32, or split-bf16 under set_precision("bf16x3").
+    epi: + bias; `gate` ([M,N]): ReLU backward (v = gate > 0 ? v : 0); `drop` = (p, seed, offset, epoch): nn.Dropout on the product from the
+    counter hash; + res; relu.  w_transposed: w is [K,N] and the product is x w (the input gradient of a Linear)."""
     if _PREC["gemm"] != F32:
         x = _pad_cols(x)
         M, K = x.shape
@@ -189,37 +209,23 @@ def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False):
         wimg, ldw = _pack_linear(w, w_transposed)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         splits = 0
-        if res is None and M <= 128 and K >= 4096:
+        if M <= 128 and K >= 4096:
             splits = min(64, K // 1024)
-        elif res is None and K >= 1024:
+        elif K >= 1024:
             # few output tiles and a deep K (the FFN's second product and the first one's input gradient at 16 clips: 544 x 512 x 2048 = 72 tiles
-            # on 256 CUs, 64 serial K-steps, 29.7 us): split K until ~256 workgroups exist, fold with the bias / ReLU pass
+            # on 256 CUs, 64 serial K-steps, 29.7 us): split K until ~256 workgroups exist, fold with the epilogue pass
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
             if tiles <= 96:
                 splits = min(K // 512, max(2, 256 // tiles))
-        if splits >= 2:
-            part = _scratch(x.device, splits * M * N, "splitk")
-            L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part), _PREC["gemm"],
-                                         _stream(x.device)), "eg_linear_splitk")
-            return y
-        L.check(lib.eg_linear(_ptr(x), K, _ptr(wimg), ldw, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), 0, 0, _PREC["gemm"],
-                              _stream(x.device)), "eg_linear")
-        return y
+        return _linear_ex(x, K, wimg, ldw, bias, res, y, M, N, K, relu, _PREC["gemm"], gate, drop, splits)
     if w_transposed:
         w = raw_transpose(w)
     x, w = _pad_cols(x), _pad_cols(w)
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    if res is None and M <= 128 and K >= 4096:          # short and deep (emotion_classifer_header.0: K = frames * d_model): split K over workgroups
-        splits = min(64, K // 1024)
-        part = _scratch(x.device, splits * M * N, "splitk")
-        L.check(lib.eg_linear_splitk(_ptr(x), K, _ptr(w), K, _ptr(bias), _ptr(y), N, M, N, K, int(relu), splits, _ptr(part), F32, _stream(x.device)),
-                "eg_linear_splitk")
-        return y
-    L.check(lib.eg_linear(_ptr(x), K, _ptr(w), K, _ptr(bias), _ptr(res), None, N, _ptr(y), N, M, N, K, int(relu), 0, 0, F32, _stream(x.device)),
-            "eg_linear")
-    return y
+    splits = min(64, K // 1024) if (M <= 128 and K >= 4096) else 0      # short and deep (emotion_classifer_header.0: K = frames * d_model)
+    return _linear_ex(x, K, w, K, bias, res, y, M, N, K, relu, F32, gate, drop, splits)
 
 
 def raw_transpose(x):
@@ -883,6 +889,281 @@ def attention(q, k, v, heads, dropout_p: float = 0.0):
         off = next_dropout_offset(B * heads * Lq * k.shape[1])
         return _Attention.apply(q, k, v, heads, dropout_p, _DROP["seed"], off, _DROP.get("epoch"))
     return _Attention.apply(q, k, v, heads, 0.0, 0, 0, None)
+
+
+# ---- fused transformer blocks (verdict r04 item 2: fewer, fatter launches) ---------------------------------------------------------------
+# One autograd node per MultiHeadAttention / PositionwiseFeedForward / Linear chain instead of one per operator.  What that buys:
+#  * Q|K|V (self attention) and K|V (cross attention) are ONE product each way: the three weights are adjacent rows of the flat parameter buffer
+#    (`fused_rows`), so the forward, the input gradient (K = 1536 / 1024) and the weight gradient are one launch each instead of three, the
+#    attention kernels read / write the [rows, 3D] buffer through row strides, and the fan-out adds of the old `fork`s disappear;
+#  * nn.Dropout + residual ride in the producing GEMM's epilogue (eg_linear_ex: the mask is the stateless counter hash); in the backward the
+#    LayerNorm kernel emits the gradient twice -- plain for the residual, Dropout-masked for the branch -- and its affine gradients from the same
+#    pass; ReLU's backward is a gate in the epilogue of the input-gradient product, the residual's gradient an epilogue add.
+# Same arithmetic per element as the operator-by-operator composition (same kernels, same K order), so the gradient goldens hold unchanged.
+FUSE_BLOCKS = True          # False: train/nets.py composes the blocks operator by operator (the A/B switch of the tests)
+
+
+def drop_site(p: float, numel: int, like: torch.Tensor):
+    """(p, seed, offset, epoch) of ONE nn.Dropout call site for a tensor of `numel` elements, None when p == 0.  Advances the mask stream."""
+    if p <= 0.0:
+        return None
+    if like.is_cuda and torch.cuda.is_current_stream_capturing() and _DROP.get("epoch") is None:
+        raise L.EgError("dropout inside a stream capture needs the device-resident mask epoch (functional.use_device_dropout_epoch); "
+                        "train/graph.GraphedStep enables it when told the model trains with dropout (stochastic=True)")
+    return (float(p), _DROP["seed"], next_dropout_offset(numel), _DROP.get("epoch"))
+
+
+def fused_rows(ws):
+    """[n_i, k] matrices -> (one [sum n_i, k] matrix, is_view).  A view when they lie back to back in one storage (parameters flattened by
+    optim.flatten_parameters in registration order: w_qs, w_ks, w_vs), else a concatenation (data movement)."""
+    w0 = ws[0]
+    k = w0.shape[1]
+    ptr, ok = w0.data_ptr(), True
+    for w in ws:
+        ok = ok and w.is_contiguous() and w.shape[1] == k and w.data_ptr() == ptr and w.untyped_storage().data_ptr() == w0.untyped_storage().data_ptr()
+        ptr += w.numel() * 4
+    n = sum(w.shape[0] for w in ws)
+    if ok:
+        return torch.as_strided(w0, (n, k), (k, 1)), True
+    return torch.cat([w.reshape(-1, k) for w in ws], 0), False
+
+
+def fused_grad_out(params, k):
+    """Destination of the weight gradient of a fused product: ONE [sum n_i, k] view over the parameters' adjacent slices of the flat gradient
+    buffer when there is one (nothing wrote them yet this step), else fresh memory.  -> (matrix, per-parameter views to hand to autograd)."""
+    slots = [getattr(p, "_eg_slot", None) for p in params]
+    n = sum(p.shape[0] for p in params)
+    if all(sl is not None for sl in slots) and all(id(p) not in p._eg_fp.written for p in params):
+        ptr, ok = slots[0].data_ptr(), True
+        for sl in slots:
+            ok = ok and sl.data_ptr() == ptr
+            ptr += sl.numel() * 4
+        if ok:
+            for p in params:
+                p._eg_fp.written.add(id(p))
+            return torch.as_strided(slots[0], (n, k), (k, 1)), [sl.view(sl.shape) for sl in slots]
+    m = torch.empty(n, k, dtype=torch.float32, device=params[0].device)
+    outs, r = [], 0
+    for p in params:
+        outs.append(m[r:r + p.shape[0]].view(p.shape))
+        r += p.shape[0]
+    return m, outs
+
+
+def raw_wgrad(x, dy, dw, db=None):
+    """dw[N,K] = dy[R,N]^T x[R,K] (+ db = colsum(dy)) into the given tensors: one split-bf16 MFMA launch (csrc/lingrad.hip) under "bf16x3",
+    the fp32 TN GEMM + column sum under "f32"."""
+    lib = _lib()
+    R, N = dy.shape
+    K = x.shape[1]
+    if _PREC["gemm"] != F32:
+        need = int(lib.eg_linear_wgrad_mfma_workspace_floats(R, N, K))
+        ws = _scratch(dy.device, need, "tn") if need else None
+        L.check(lib.eg_linear_wgrad_mfma(_ptr(dy), N, _ptr(x), K, _ptr(dw), K, _ptr(db), R, N, K, _ptr(ws), ws.numel() if ws is not None else 0,
+                                         _stream(dy.device)), "eg_linear_wgrad_mfma")
+    else:
+        raw_gemm_tn(dy, x, out=dw)
+        if db is not None:
+            raw_colsum(dy, out0=db)
+    return dw, db
+
+
+def _ln_forward(x2, g, b, eps):
+    y = torch.empty_like(x2)
+    L.check(_lib().eg_layernorm(_ptr(x2), _ptr(g), _ptr(b), _ptr(y), x2.shape[0], x2.shape[1], float(eps), _stream(x2.device)), "eg_layernorm")
+    return y
+
+
+def _ln_backward_ex(pre, dy2, g, eps, site, g_param, b_param):
+    """-> (d pre, d pre through the Dropout `site` (the same tensor when the site is off), dgamma, dbeta): eg_layernorm_backward_ex."""
+    lib = _lib()
+    rows, D = pre.shape
+    dpre = torch.empty_like(pre)
+    dbr = torch.empty_like(pre) if site is not None else None
+    dg, db = grad_out(g_param), grad_out(b_param)
+    ws = _scratch(pre.device, int(lib.eg_layernorm_backward_ex_workspace_floats(rows, D)), "lnx")
+    p, seed, off, ep = site if site is not None else (0.0, 0, 0, None)
+    L.check(lib.eg_layernorm_backward_ex(_ptr(pre), _ptr(dy2), _ptr(g), _ptr(dpre), _ptr(dbr), _ptr(dg), _ptr(db), rows, D, float(eps), float(p), int(seed),
+                                         int(off), _ptr(ep), _ptr(ws), _stream(pre.device)), "eg_layernorm_backward_ex")
+    return dpre, (dbr if dbr is not None else dpre), dg, db
+
+
+def blocks_fusable(d_model: int) -> bool:
+    return FUSE_BLOCKS and d_model % 64 == 0 and d_model <= 1024
+
+
+class _MHABlock(torch.autograd.Function):
+    """MultiHeadAttention.forward (SubLayers.py:30-59): LN(dropout(fc(attention(q Wq, k Wk, v Wv))) + q) as one node; xkv None = self attention."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, wq, wk, wv, wfc, g, b, heads, p_attn, p_fc, eps):
+        lib = _lib()
+        B, Lq, D = xq.shape
+        xq2 = _chk(xq).reshape(B * Lq, D)
+        selfa = xkv is None
+        wqd, wkd, wvd, wfd, gd, bd = _chk(wq), _chk(wk), _chk(wv), _chk(wfc), _chk(g), _chk(b)
+        dev = xq2.device
+        if selfa:
+            Lk, xkv2 = Lq, None
+            wcat, _ = fused_rows([wqd, wkd, wvd])
+            qkv = raw_linear(xq2, wcat)                                   # [rows, 3D]
+            q, k, v, ldq, ldk = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, 3 * D
+            saved_proj = (qkv,)
+        else:
+            Lk = xkv.shape[1]
+            xkv2 = _chk(xkv).reshape(B * Lk, D)
+            wcat, _ = fused_rows([wkd, wvd])
+            qb = raw_linear(xq2, wqd)
+            kv = raw_linear(xkv2, wcat)                                   # [rows_k, 2D]
+            q, k, v, ldq, ldk = qb, kv, kv[:, D:], D, 2 * D
+            saved_proj = (qb, kv)
+        o = torch.empty(B * Lq, D, device=dev)
+        attn = torch.empty(B, heads, Lq, Lk, device=dev)
+        site_a = drop_site(p_attn, B * heads * Lq * Lk, xq2)
+        pa, sa, oa, ea = site_a if site_a is not None else (0.0, 0, 0, None)
+        L.check(lib.eg_attention_train(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldk, _ptr(o), D, _ptr(attn), B, heads, Lq, Lk, D // heads,
+                                       float(pa), sa, oa, _ptr(ea), _stream(dev)), "eg_attention_train")
+        site_f = drop_site(p_fc, B * Lq * D, xq2)
+        pre = raw_linear(o, wfd, res=xq2, drop=site_f)                    # dropout(fc(.)) + residual in the product's epilogue (SubLayers.py:54)
+        y = _ln_forward(pre, gd, bd, eps)
+        ctx.save_for_backward(xq2, xkv2, attn, o, pre, wqd, wkd, wvd, wfd, gd, *saved_proj)
+        ctx.cfg = (B, Lq, Lk, D, heads, selfa, site_a, site_f, float(eps), xq.requires_grad, (xkv is not None and xkv.requires_grad))
+        ctx.params = (wq, wk, wv, wfc, g, b)
+        return y.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        xq2, xkv2, attn, o, pre, wq, wk, wv, wfc, g = ctx.saved_tensors[:10]
+        proj = ctx.saved_tensors[10:]
+        B, Lq, Lk, D, heads, selfa, site_a, site_f, eps, need_dxq, need_dxkv = ctx.cfg
+        pq, pk, pv, pfc, pg, pb = ctx.params
+        dev = pre.device
+        dy2 = _chk(dy).reshape(B * Lq, D)
+        dpre, dfc, dg, db = _ln_backward_ex(pre, dy2, g, eps, site_f, pg, pb)
+        do = raw_linear(dfc, wfc, w_transposed=True)
+        dwfc, _ = raw_wgrad(o, dfc, grad_out(pfc))
+        pa, sa, oa, ea = site_a if site_a is not None else (0.0, 0, 0, None)
+        if selfa:
+            (qkv,) = proj
+            dqkv = torch.empty_like(qkv)
+            L.check(lib.eg_attention_backward_train(qkv.data_ptr(), 3 * D, qkv[:, D:].data_ptr(), 3 * D, qkv[:, 2 * D:].data_ptr(), 3 * D, _ptr(attn), _ptr(do), D,
+                                                    dqkv.data_ptr(), 3 * D, dqkv[:, D:].data_ptr(), 3 * D, dqkv[:, 2 * D:].data_ptr(), 3 * D, B, heads, Lq, Lk,
+                                                    D // heads, float(pa), sa, oa, _ptr(ea), _stream(dev)), "eg_attention_backward_train")
+            wcat, _ = fused_rows([wq, wk, wv])
+            dx = raw_linear(dqkv, wcat, w_transposed=True, res=dpre) if need_dxq else None      # the residual's gradient rides in the epilogue
+            dwm, dws = fused_grad_out((pq, pk, pv), D)
+            raw_wgrad(xq2, dqkv, dwm)
+            return (dx.view(B, Lq, D) if dx is not None else None), None, dws[0], dws[1], dws[2], dwfc, dg, db, None, None, None, None
+        qb, kv = proj
+        dq, dkv = torch.empty_like(qb), torch.empty_like(kv)
+        L.check(lib.eg_attention_backward_train(_ptr(qb), D, kv.data_ptr(), 2 * D, kv[:, D:].data_ptr(), 2 * D, _ptr(attn), _ptr(do), D, _ptr(dq), D,
+                                                dkv.data_ptr(), 2 * D, dkv[:, D:].data_ptr(), 2 * D, B, heads, Lq, Lk, D // heads, float(pa), sa, oa, _ptr(ea),
+                                                _stream(dev)), "eg_attention_backward_train")
+        wcat, _ = fused_rows([wk, wv])
+        dxq = raw_linear(dq, wq, w_transposed=True, res=dpre) if need_dxq else None
+        dxkv = raw_linear(dkv, wcat, w_transposed=True) if need_dxkv else None
+        dwq, _ = raw_wgrad(xq2, dq, grad_out(pq))
+        dwm, dws = fused_grad_out((pk, pv), D)
+        raw_wgrad(xkv2, dkv, dwm)
+        return ((dxq.view(B, Lq, D) if dxq is not None else None), (dxkv.view(B, Lk, D) if dxkv is not None else None), dwq, dws[0], dws[1], dwfc, dg, db,
+                None, None, None, None)
+
+
+def mha_block(m, xq, xkv=None, p_attn=0.0, p_fc=0.0):
+    """m: a MultiHeadAttention parameter holder.  xkv None: self attention (k = v = q = xq); else k = v = xkv."""
+    return _MHABlock.apply(xq, xkv, m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.fc.weight, m.layer_norm.weight, m.layer_norm.bias, m.n_head,
+                           float(p_attn), float(p_fc), m.layer_norm.eps)
+
+
+class _FFNBlock(torch.autograd.Function):
+    """PositionwiseFeedForward.forward (SubLayers.py:74-84): LN(dropout(w_2(relu(w_1 x))) + x) as one node: 3 launches forward, 6 backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, g, b, p_drop, eps):
+        xs = x.shape
+        D = xs[-1]
+        x2 = _chk(x).reshape(-1, D)
+        w1d, b1d, w2d, b2d, gd, bd = _chk(w1), _chk(b1), _chk(w2), _chk(b2), _chk(g), _chk(b)
+        h = raw_linear(x2, w1d, b1d, relu=True)
+        site = drop_site(p_drop, x2.numel(), x2)
+        pre = raw_linear(h, w2d, b2d, res=x2, drop=site)                  # x = self.dropout(x); x += residual (SubLayers.py:79)
+        y = _ln_forward(pre, gd, bd, eps)
+        ctx.save_for_backward(x2, h, pre, w1d, w2d, gd)
+        ctx.cfg = (xs, site, float(eps), x.requires_grad)
+        ctx.params = (w1, b1, w2, b2, g, b)
+        return y.view(xs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, pre, w1, w2, g = ctx.saved_tensors
+        xs, site, eps, need_dx = ctx.cfg
+        p1, pb1, p2, pb2, pg, pb = ctx.params
+        dy2 = _chk(dy).reshape(-1, xs[-1])
+        dpre, dff, dg, db = _ln_backward_ex(pre, dy2, g, eps, site, pg, pb)
+        dh = raw_linear(dff, w2, w_transposed=True, gate=h)               # ReLU backward as the epilogue gate
+        dw2, db2 = raw_wgrad(h, dff, grad_out(p2), grad_out(pb2))
+        dx = raw_linear(dh, w1, w_transposed=True, res=dpre) if need_dx else None     # + the residual's gradient
+        dw1, db1 = raw_wgrad(x2, dh, grad_out(p1), grad_out(pb1))
+        return (dx.view(xs) if dx is not None else None), dw1, db1, dw2, db2, dg, db, None, None
+
+
+def ffn_block(f, x, p_drop=0.0):
+    return _FFNBlock.apply(x, f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias, f.layer_norm.weight, f.layer_norm.bias, float(p_drop), f.layer_norm.eps)
+
+
+class _LinearChain(torch.autograd.Function):
+    """Linear -> [ReLU] -> [Dropout] -> Linear -> ... (the reference's nn.Sequential MLPs: Models_spatial_memory.py:488-536, BEAT_CVAE.py:336-380): ReLU and
+    Dropout between consecutive layers are epilogue options of the producing product forward, and of the NEXT layer's input-gradient product
+    backward -- no elementwise launch either way."""
+
+    @staticmethod
+    def forward(ctx, x, relu_between, drop_p, n_layers, *wb):
+        xs = x.shape
+        h = _chk(x).reshape(-1, xs[-1])
+        ws = [_chk(wb[2 * i]) for i in range(n_layers)]
+        bs = [(_chk(wb[2 * i + 1]) if wb[2 * i + 1] is not None else None) for i in range(n_layers)]
+        ins, sites = [], []
+        for i in range(n_layers):
+            last = i + 1 == n_layers
+            ins.append(h)
+            site = drop_site(drop_p, h.shape[0] * ws[i].shape[0], h) if (drop_p > 0.0 and not last) else None
+            sites.append(site)
+            h = raw_linear(h, ws[i], bs[i], relu=relu_between and not last, drop=site)
+        ctx.save_for_backward(*ins, *ws)
+        ctx.cfg = (xs, n_layers, bool(relu_between), sites, x.requires_grad)
+        ctx.params = wb
+        return h.view(*xs[:-1], ws[-1].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, n, relu_between, sites, need_dx = ctx.cfg
+        ins, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        g = _chk(dy).reshape(-1, ws[-1].shape[0])
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            pw, pbias = ctx.params[2 * i], ctx.params[2 * i + 1]
+            same = ins[i].shape[1] == ws[i].shape[1]
+            dw = grad_out(pw) if same else torch.empty(ws[i].shape[0], ins[i].shape[1], dtype=torch.float32, device=g.device)
+            db = grad_out(pbias) if pbias is not None else None
+            raw_wgrad(ins[i], g, dw, db)
+            grads[2 * i], grads[2 * i + 1] = (dw if same else dw[:, :ws[i].shape[1]]), db
+            if i > 0 or need_dx:
+                # the masks of the boundary in FRONT of layer i (ReLU by its saved output = this layer's input; Dropout from that site's scalars)
+                gate = ins[i] if (relu_between and i > 0) else None
+                g = raw_linear(g, ws[i], w_transposed=True, gate=gate, drop=sites[i - 1] if i > 0 else None)
+                if g.shape[1] != (ins[i].shape[1]):
+                    g = g[:, :ins[i].shape[1]]
+        dx = g.reshape(xs) if need_dx else None
+        return (dx, None, None, None, *grads)
+
+
+def linear_chain(x, layers, relu_between=False, drop_p=0.0):
+    """layers: Linear parameter holders.  x [..., K] -> [..., N_last]."""
+    wb = []
+    for lin in layers:
+        wb += [lin.weight, lin.bias]
+    return _LinearChain.apply(x, bool(relu_between), float(drop_p), len(layers), *wb)
 
 
 class _Conv1dCL(torch.autograd.Function):

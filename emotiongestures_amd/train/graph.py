@@ -20,6 +20,14 @@ from . import functional as F
 from .optim import FlatAdam
 
 
+def _drop_stream_scratch(stream) -> None:
+    if stream is None:
+        return
+    sid = stream.cuda_stream
+    for k in [k for k in F._WS if k[2] == sid]:
+        del F._WS[k]
+
+
 class GraphedStep:
     def __init__(self, step_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], inputs: Dict[str, torch.Tensor], optimizer: FlatAdam = None,
                  warmup: int = 3, device=None, stochastic: bool = False):
@@ -30,8 +38,9 @@ class GraphedStep:
         dev = optimizer.fp.flat.device if optimizer is not None else torch.device(device)
         if dev.type != "cuda":
             raise L.EgError("GraphedStep: needs a GPU")
+        self._epoch_keep = None
         if stochastic:                              # the model trains with dropout: the mask epoch moves to the device BEFORE the warm-up steps
-            F.use_device_dropout_epoch(dev)
+            self._epoch_keep = F.use_device_dropout_epoch(dev)     # the captured kernels hold its raw pointer: owned by the step, whatever reset_state() does later
         self.inputs, self.opt = inputs, optimizer
         if optimizer is not None:
             optimizer.use_device_step()
@@ -41,7 +50,10 @@ class GraphedStep:
             def step_fn(i):
                 F.begin_dropout_step()
                 return user_step(i)
-        side = torch.cuda.Stream(dev)
+        # Warm-up and capture run on the SAME side stream: functional._scratch keys its buffers by stream, so the warm-up sizes exactly the
+        # buffers the capture then bakes into the graph (captured on another stream, every scratch buffer would be allocated inside the capture
+        # and the warm-up's copies would stay behind under a dead key).
+        side = self._stream = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):               # warm-up off the capture: lazily sized scratch buffers, kernel attributes, autograd state
             for _ in range(max(1, warmup)):
@@ -49,7 +61,7 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = step_fn(inputs)
         if optimizer is not None:
             optimizer.t -= 1                        # the capture recorded a step without executing it
@@ -58,6 +70,13 @@ class GraphedStep:
         # for as long as the graph exists, or the caching allocator would hand their memory to someone else under a replay.
         self._scratch_keep = dict(F._WS)
         self._images_refreshed = F.get_precision() != "f32"        # FlatAdam.step refreshes the weight images only for the split-bf16 operators
+
+    def close(self) -> None:
+        """Drop the graph and the scratch buffers registered under this step's stream (a loop that builds one step per fold / leg calls this, or
+        the process-wide registry keeps every dead step's split-K / weight-gradient partials)."""
+        self.graph = None
+        self._scratch_keep = None
+        _drop_stream_scratch(self._stream)
 
     def run(self, new_inputs: Dict[str, torch.Tensor] = None) -> torch.Tensor:
         if new_inputs:
@@ -94,8 +113,9 @@ class SegmentedStep:
         self.ctx = nets.CutContext(cuts)
         self.use_graphs = bool(use_graphs)
         self.dev = torch.device(device) if device is not None else buckets.fp.grad.device
+        self._epoch_keep = None
         if stochastic and self.use_graphs and self.dev.type == "cuda":       # the model trains with dropout: device-resident mask epoch, as in GraphedStep
-            F.use_device_dropout_epoch(self.dev)
+            self._epoch_keep = F.use_device_dropout_epoch(self.dev)         # owned by the step: the captured kernels hold its raw pointer
         self.gb.deferred = True                                   # hooks only collect and record completion order; this class issues the collectives
         self.side = torch.cuda.Stream(self.dev) if self.dev.type == "cuda" else None
         self.ready = []                                           # per phase: buckets completed by that phase (recorded at the first run)
@@ -105,15 +125,33 @@ class SegmentedStep:
             if self.dev.type != "cuda":
                 raise L.EgError("SegmentedStep(use_graphs=True): needs a GPU")
             optimizer.use_device_step()
-            warm = torch.cuda.Stream(self.dev)
+            warm = self._stream = torch.cuda.Stream(self.dev)        # warm-up AND capture stream (scratch buffers are keyed by stream, see GraphedStep)
             warm.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(warm):
                 for _ in range(max(1, warmup)):
                     self._eager_step()
             torch.cuda.current_stream(self.dev).wait_stream(warm)
             torch.cuda.synchronize(self.dev)
+            self._check_overlap()
             self._capture()
         self.n_segments = (len(self.graphs) - 1) if self.graphs else None
+
+    def _check_overlap(self):
+        """The overlap this class exists for needs buckets that END at the phase boundaries: with buckets that span phases
+        (`GradBuckets(fp)` without `split_at=optim.stage_splits(model, fp)`) a non-last phase completes no bucket, its segment boundary buys
+        nothing, and every reduction lands in the exposed join.  The step stays correct; say so once."""
+        idle = [i for i, r in enumerate(self.ready[:-1]) if not r]
+        if idle and self.gb.active:
+            import warnings
+            warnings.warn(f"SegmentedStep: backward phase(s) {idle} of {len(self.ready)} complete no gradient bucket, so their all-reduces cannot overlap the "
+                          "next segment; build the buckets with GradBuckets(fp, split_at=optim.stage_splits(model, fp)) or pass fewer cuts",
+                          RuntimeWarning, stacklevel=3)
+        self.idle_phases = idle
+
+    def close(self) -> None:
+        self.graphs = None
+        self._scratch_keep = None
+        _drop_stream_scratch(getattr(self, "_stream", None))
 
     # ---- the phases -------------------------------------------------------------------------------------------------
     def _phase0(self):
@@ -195,13 +233,13 @@ class SegmentedStep:
         pool = torch.cuda.graph_pool_handle()
         graphs, ready = [], []
         g0 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g0, pool=pool):
+        with torch.cuda.graph(g0, pool=pool, stream=self._stream):
             ready.append(self._phase0())
         graphs.append(g0)
         n_cuts = len(self.ctx.cuts)
         for i in range(n_cuts):
             gi = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gi, pool=pool):
+            with torch.cuda.graph(gi, pool=pool, stream=self._stream):
                 r = self._phase_cut(i)
                 if i == n_cuts - 1:
                     r = r + self._phase_last_collect()
@@ -210,7 +248,7 @@ class SegmentedStep:
         if n_cuts == 0:
             ready[-1] = ready[-1] + self._phase_last_collect_captured(pool, graphs)
         gt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gt, pool=pool):
+        with torch.cuda.graph(gt, pool=pool, stream=self._stream):
             self._tail()
         graphs.append(gt)
         self.opt.t -= 1                                           # the capture recorded an optimiser step without executing it
@@ -220,7 +258,7 @@ class SegmentedStep:
 
     def _phase_last_collect_captured(self, pool, graphs):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool):
+        with torch.cuda.graph(g, pool=pool, stream=self._stream):
             r = self._phase_last_collect()
         graphs.append(g)
         return r

@@ -147,7 +147,8 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
     hipGraph per fold instead of issuing its ~600 launches through autograd (a batch of 8 is host-bound otherwise); with several ranks the
     bucket all-reduces and Adam follow each replay.  Same kernels, same order: the losses equal the eager loop's.
     shuffle_folds / seed: the fold split is sklearn's KFold(n_splits, shuffle=True, random_state=seed) (:301).
-    keep_models: "last" keeps only the final fold's model on the device in its record (`rec["model"]`), "none" none, "all" every fold's;
+    keep_models: "last" keeps only the final fold's model on the device in its record (`rec["model"]`; None in the other records), "none" none,
+    "all" every fold's;
     every record carries the fold's final `state_dict` on the CPU (`rec["state_dict"]`).  Validation (:177-190) runs as upstream does, with
     train()-mode BatchNorm under no_grad; the test pass (:205-255) in eval() mode."""
     import torch.distributed as dist
@@ -156,6 +157,8 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
     from .optim import FlatAdam, GradBuckets, flatten_parameters
     if alpha_mode not in ("by_label", "positional"):
         raise ValueError("alpha_mode: 'by_label' or 'positional'")
+    if keep_models not in ("last", "none", "all"):
+        raise ValueError(f"keep_models: 'last', 'none' or 'all' (got {keep_models!r})")
     if alpha_mode == "positional" and batch_size != NUM_CLASSES:
         raise ValueError("alpha_mode='positional' is upstream's literal broadcast of 8 class weights over the batch axis: batch_size must be 8")
     device = torch.device(device)
@@ -176,9 +179,10 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
             model.train()
             fp = flatten_parameters(model)
             if precision != "f32":
-                fp.enable_weight_images()
+                from . import nets
+                fp.enable_weight_images(*nets.weight_image_plan(model))
             opt = FlatAdam(fp, lr=lr, betas=betas, weight_decay=weight_decay)
-            gb = GradBuckets(fp).attach() if world > 1 else None
+            gb = GradBuckets(fp).attach() if world > 1 else None     # plain buckets: this loop reduces behind the whole backward (reduce_deferred / hooks), no SegmentedStep
             try:
                 rec = {"fold": fold, "loss": [], "val_acc": [], "test_acc": [], "checkpoints": [], "iterations": 0}
                 global_iter = 0
@@ -252,12 +256,14 @@ def train_k_fold(train_dataset, *, device, n_splits: int = 10, total_epoch: int 
                         break
                 rec["iterations"] = global_iter
                 rec["state_dict"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-                if keep_models == "all" or (keep_models == "last" and (folds is None and fold == n_splits or folds is not None and fold == max(folds))):
-                    rec["model"] = model
+                keep = keep_models == "all" or (keep_models == "last" and (folds is None and fold == n_splits or folds is not None and fold == max(folds)))
+                rec["model"] = model if keep else None        # the key always exists; None = not kept on the device (rec["state_dict"] holds the weights)
                 history.append(rec)
             finally:                            # also on an exception mid-fold: no stale weight images in the registry, no fold's graph / scratch kept alive
                 if fp.images is not None:
                     F.unregister_weight_images(fp.images)
+                if graphed is not None:
+                    graphed.close()             # the fold's graph and the scratch buffers registered under its stream
                 graphed = static = opt = gb = None
     finally:
         F.set_precision("f32")

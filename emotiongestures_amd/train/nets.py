@@ -144,6 +144,9 @@ def emotion_net_forward(model, mfcc):
     """EmotionNet.forward in train() mode -> logits [B, 8]."""
     feat = resnetse_forward(model.emotion_encoder, mfcc)                        # [B,16,16,256]
     h = feat.permute(0, 3, 1, 2).reshape(feat.shape[0], -1)                     # feature.view(B,-1) of the NCHW map (:44)
+    if F.FUSE_BLOCKS:           # five Linear + ReLU and last_fc as one chain: the ReLU backwards are gates of the input-gradient products
+        F.flush_batch_counters()
+        return F.linear_chain(h, [model.emotion_eocder_fc[i] for i in (0, 2, 4, 6, 8)] + [model.last_fc], relu_between=True)
     for i in (0, 2, 4, 6, 8):
         lin = model.emotion_eocder_fc[i]
         h = F.linear(h, lin.weight, lin.bias, relu=True)
@@ -152,6 +155,32 @@ def emotion_net_forward(model, mfcc):
 
 
 # ---- transformer blocks (Full_model/SubLayers.py:30-59,74-84; Layers.py:18-22,50-58) --------------------------------------
+# Default: one fused autograd node per block (functional.mha_block / ffn_block / linear_chain: fused Q|K|V, Dropout + residual in the GEMM epilogue,
+# ReLU backward as an epilogue gate).  functional.FUSE_BLOCKS = False, or a width the fused LayerNorm backward does not take (Pose_Discriminator's 282),
+# composes the same blocks operator by operator below -- the arithmetic per element is the same.
+def weight_image_plan(model):
+    """(groups, skip) for optim.FlatParams.enable_weight_images: which attention weights are used as ONE matrix by the fused blocks.
+    Encoder self attention: Q|K|V (the three single images are never read); a decoder's `enc_attn`: K|V (Q alone); a decoder's `slf_attn` holds
+    parameters the forward never touches (Layers.py:50-58): no image at all."""
+    from ..modules import Decoder, Encoder
+    groups, skip = [], []
+    for mod in model.modules():
+        if isinstance(mod, Encoder):
+            for layer in mod.layer_stack:
+                a = layer.slf_attn
+                if F.blocks_fusable(a.w_qs.weight.shape[1]):
+                    groups.append((a.w_qs.weight, a.w_ks.weight, a.w_vs.weight))
+                    skip += [a.w_qs.weight, a.w_ks.weight, a.w_vs.weight]
+        elif isinstance(mod, Decoder):
+            for layer in mod.layer_stack:
+                a, u = layer.enc_attn, layer.slf_attn
+                if F.blocks_fusable(a.w_qs.weight.shape[1]):
+                    groups.append((a.w_ks.weight, a.w_vs.weight))
+                    skip += [a.w_ks.weight, a.w_vs.weight]
+                skip += [u.w_qs.weight, u.w_ks.weight, u.w_vs.weight, u.fc.weight]
+    return groups, skip
+
+
 def mha_forward(m, xq, xk, xv):
     """MultiHeadAttention.forward: LN(fc(attention(q Wq, k Wk, v Wv)) + q).  xq / xk / xv are separate uses of the inputs."""
     xq_p, xq_r = F.fork(xq)
@@ -180,11 +209,21 @@ class _AddRows(torch.autograd.Function):
         return g, None
 
 
+def _p(p):
+    return p if _P["on"] else 0.0
+
+
 def encoder_forward(enc, x):
     x = _dp(_AddRows.apply(x, enc.position_enc.pos_table[0, :x.shape[1]].contiguous()), enc.dropout_p)        # Models_spatial_memory.py:422
+    fused = F.blocks_fusable(x.shape[-1])
     for layer in enc.layer_stack:
-        a, b, c = _fork_n(x, 3)
-        x = ffn_forward(layer.pos_ffn, mha_forward(layer.slf_attn, a, b, c))
+        if fused:
+            a = layer.slf_attn
+            x = F.mha_block(a, x, None, _p(a.attention.dropout_p), _p(a.dropout_p))
+            x = F.ffn_block(layer.pos_ffn, x, _p(layer.pos_ffn.dropout_p))
+        else:
+            a, b, c = _fork_n(x, 3)
+            x = ffn_forward(layer.pos_ffn, mha_forward(layer.slf_attn, a, b, c))
     return x
 
 
@@ -198,6 +237,8 @@ def motion_discriminator_forward(md, x):
     finally:
         _P["on"] = False
     h = F.linear(enc.reshape(B * T, D), md.fc1[0].weight, md.fc1[0].bias, relu=True).reshape(B, -1)
+    if F.FUSE_BLOCKS:
+        return F.linear_chain(h, [md.fc2[i] for i in (0, 2, 4, 6, 8, 10)], relu_between=True)
     for i in (0, 2, 4, 6, 8):
         h = F.linear(h, md.fc2[i].weight, md.fc2[i].bias, relu=True)
     return F.linear(h, md.fc2[10].weight, md.fc2[10].bias)
@@ -219,15 +260,24 @@ def pose_discriminator_forward(pd, x, dropout=True):
 
 
 def decoder_forward(dec, trg, enc_out):
-    uses = _fork_n(enc_out, 2 * len(dec.layer_stack))
     x = trg
-    for i, layer in enumerate(dec.layer_stack):                                  # enc_attn + pos_ffn only (Layers.py:50-58)
+    if F.blocks_fusable(enc_out.shape[-1]):
+        uses = _fork_n(enc_out, len(dec.layer_stack))                            # one use per layer: K|V is one product
+        for i, layer in enumerate(dec.layer_stack):                              # enc_attn + pos_ffn only (Layers.py:50-58)
+            a = layer.enc_attn
+            x = F.mha_block(a, x, uses[i], _p(a.attention.dropout_p), _p(a.dropout_p))
+            x = F.ffn_block(layer.pos_ffn, x, _p(layer.pos_ffn.dropout_p))
+        return x
+    uses = _fork_n(enc_out, 2 * len(dec.layer_stack))
+    for i, layer in enumerate(dec.layer_stack):
         x = ffn_forward(layer.pos_ffn, mha_forward(layer.enc_attn, x, uses[2 * i], uses[2 * i + 1]))
     return x
 
 
 def _seq_linear(seq, idx, x, relu_between=False, drop=0.0):
     """Linear chain; `drop`: the nn.Dropout between consecutive Linears of the reference's Sequential (no ReLU there)."""
+    if F.FUSE_BLOCKS:
+        return F.linear_chain(x, [seq[i] for i in idx], relu_between, _p(drop))
     for j, i in enumerate(idx):
         x = F.linear(x, seq[i].weight, seq[i].bias, relu=relu_between and j + 1 < len(idx))
         if drop and j + 1 < len(idx):
@@ -269,7 +319,9 @@ def audio_encoder_forward(ae, spec):
     x = F.batch_norm(F.conv3x3(x, ae.final_conv1.weight, ae.final_conv1.bias), ae.bn1)          # [B,H,W,F]
     B, H, W, Fr = x.shape
     x = x.permute(0, 3, 1, 2).reshape(B, Fr, H * W)                              # channel c becomes time step c (:124)
-    return F.linear(_dp(F.linear(x, ae.fc1.weight, ae.fc1.bias), 0.2), ae.fc2.weight, ae.fc2.bias)          # :128-130
+    if F.FUSE_BLOCKS:
+        return F.linear_chain(x, [ae.fc1, ae.fc2], False, _p(0.2))                                          # :128-130
+    return F.linear(_dp(F.linear(x, ae.fc1.weight, ae.fc1.bias), 0.2), ae.fc2.weight, ae.fc2.bias)
 
 
 def text_encoder_forward_nograd(te, text):
@@ -356,16 +408,16 @@ def cvae_forward(vae, Input, y, eps):
         n = h.shape[0]
         latent = h.transpose(1, 2).reshape(n, -1)                          # NCL flatten (:409)
         la, lb = F.fork(latent)
-        mu = F.linear(_dp(F.linear(la, vae.fc_mu[0].weight, vae.fc_mu[0].bias), 0.2), vae.fc_mu[2].weight, vae.fc_mu[2].bias)
-        logvar = F.linear(_dp(F.linear(lb, vae.fc_var[0].weight, vae.fc_var[0].bias), 0.2), vae.fc_var[2].weight, vae.fc_var[2].bias)
+        mu = _seq_linear(vae.fc_mu, (0, 2), la, drop=0.2)
+        logvar = _seq_linear(vae.fc_var, (0, 2), lb, drop=0.2)
         mu_z, mu_out = F.fork(mu)
         lv_z, lv_out = F.fork(logvar)
         z = F.reparameterize(mu_z, lv_z, eps)
         py = vae.Posterior_Y_embedding
-        post_y = F.linear(_dp(F.linear(y, py[0].weight, py[0].bias), 0.2), py[2].weight, py[2].bias)
+        post_y = _seq_linear(py, (0, 2), y, drop=0.2)
         zc = torch.cat((z, post_y), 1)
         fz = vae.fusion_z_posterior
-        zc = F.linear(_dp(F.linear(zc, fz[0].weight, fz[0].bias), 0.2), fz[2].weight, fz[2].bias)
+        zc = _seq_linear(fz, (0, 2), zc, drop=0.2)
     finally:
         _P["on"] = False
     h = _cl(zc.reshape(n, 4, -1))                                      # [n, L = d_model/4, C = 4]

@@ -42,11 +42,12 @@ class FlatParams:
             p.grad = None
         self.written.clear()
 
-    def enable_weight_images(self):
-        """Keep the split-bf16 weight images of all Linear / conv3x3 parameters resident and refresh them once per optimiser step."""
+    def enable_weight_images(self, groups=(), skip=()):
+        """Keep the split-bf16 weight images of all Linear / conv3x3 parameters resident and refresh them once per optimiser step.
+        groups / skip: the fused-product plan of the model (`nets.weight_image_plan(model)`), see WeightImages."""
         from . import functional as F
         if self.images is None:
-            self.images = WeightImages(self)
+            self.images = WeightImages(self, groups, skip)
         F.register_weight_images(self.images)
         return self.images
 
@@ -114,7 +115,9 @@ class WeightImages:
     live at fixed addresses, so the table is built once.  `train/functional.py` looks an image up by (storage address, orientation) and
     checks the parameter's version; a miss (reshaped weights, a stale version) falls back to the per-use packer."""
 
-    def __init__(self, fp: "FlatParams"):
+    def __init__(self, fp: "FlatParams", groups=(), skip=()):
+        """groups: tuples of 2-D parameters that lie back to back in the flat buffer and are used as ONE matrix (the fused Q|K|V / K|V products of
+        train/functional.py: `nets.weight_image_plan(model)`); skip: parameters that are only ever used through a group (no image of their own)."""
         import numpy as np
         lib = L.load()
         dev = fp.flat.device
@@ -122,24 +125,44 @@ class WeightImages:
             raise L.EgError("WeightImages: needs a GPU")
         entries, self.images, self.params = [], {}, []
         first = 0
+        skip_ids = {id(p) for p in skip}
+
+        def add(ptr, owners, kinds):
+            nonlocal first
+            for kind, a, b, c, flag, floats, rows in kinds:
+                img = torch.empty(floats, dtype=torch.float32, device=dev)
+                self.images[(ptr, kind, flag, rows)] = (img, owners)
+                entries.append((ptr, img.data_ptr(), kind, a, b, c, flag, first))
+                first += int(lib.eg_pack_table_blocks(kind, a, b, flag))
+
         for p in fp.params:
+            if id(p) in skip_ids:
+                continue
             kinds = []
             if p.dim() == 2 or (p.dim() == 4 and tuple(p.shape[2:]) == (1, 1)):        # nn.Linear, or a 1x1 convolution used as one
                 n, k = p.shape[:2]
-                kinds = [(0, n, k, k, 0, int(lib.eg_linear_packed_floats(n, k))), (0, k, n, k, 1, int(lib.eg_linear_packed_floats(k, n)))]
+                kinds = [(0, n, k, k, 0, int(lib.eg_linear_packed_floats(n, k)), n), (0, k, n, k, 1, int(lib.eg_linear_packed_floats(k, n)), n)]
             elif p.dim() == 4 and tuple(p.shape[2:]) == (3, 3):
                 co, ci = p.shape[:2]
                 if ci % 8 == 0:
-                    kinds.append((1, co, ci, 0, 0, int(lib.eg_conv3x3_packed_floats(ci, (co + 15) // 16 * 16))))
+                    kinds.append((1, co, ci, 0, 0, int(lib.eg_conv3x3_packed_floats(ci, (co + 15) // 16 * 16)), co))
                 if co % 8 == 0:
-                    kinds.append((1, co, ci, 0, 1, int(lib.eg_conv3x3_packed_floats(co, (ci + 15) // 16 * 16))))
-            for kind, a, b, c, flag, floats in kinds:
-                img = torch.empty(floats, dtype=torch.float32, device=dev)
-                self.images[(p.data_ptr(), kind, flag)] = (img, p)
-                entries.append((p.data_ptr(), img.data_ptr(), kind, a, b, c, flag, first))
-                first += int(lib.eg_pack_table_blocks(kind, a, b, flag))
+                    kinds.append((1, co, ci, 0, 1, int(lib.eg_conv3x3_packed_floats(co, (ci + 15) // 16 * 16)), co))
+            add(p.data_ptr(), (p,), kinds)
             if kinds:
                 self.params.append(p)
+        for grp in groups:
+            k = grp[0].shape[1]
+            ptr = grp[0].data_ptr()
+            for q in grp:
+                if q.dim() != 2 or q.shape[1] != k or q.data_ptr() != ptr:
+                    raise ValueError("WeightImages: a fused group must be 2-D parameters of one width lying back to back in the flat buffer")
+                ptr += q.numel() * 4
+            n = sum(q.shape[0] for q in grp)
+            add(grp[0].data_ptr(), tuple(grp), [(0, n, k, k, 0, int(lib.eg_linear_packed_floats(n, k)), n), (0, k, n, k, 1, int(lib.eg_linear_packed_floats(k, n)), n)])
+            for q in grp:
+                if all(q is not r for r in self.params):
+                    self.params.append(q)
         self.count, self.total_blocks = len(entries), first
         rec = np.zeros(self.count, dtype=np.dtype([("src", "<u8"), ("img", "<u8"), ("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4"), ("flag", "<i4"),
                                                    ("first", "<i4")]))
@@ -160,13 +183,17 @@ class WeightImages:
         self.versions = {id(p): p._version for p in self.params}
 
     def lookup(self, w: torch.Tensor, kind: int, flag: int):
-        hit = self.images.get((w.data_ptr(), kind, flag))
+        hit = self.images.get((w.data_ptr(), kind, flag, w.shape[0]))
         if hit is None:
             return None
-        img, p = hit
-        same = tuple(w.shape) == tuple(p.shape) or (p.dim() == 4 and tuple(p.shape[2:]) == (1, 1) and tuple(w.shape) == tuple(p.shape[:2]))
-        if not same or self.versions.get(id(p)) != w._version:
-            return None                 # a different view of that storage, or the parameter changed since the last refresh
+        img, owners = hit
+        p = owners[0]
+        if len(owners) == 1:
+            same = tuple(w.shape) == tuple(p.shape) or (p.dim() == 4 and tuple(p.shape[2:]) == (1, 1) and tuple(w.shape) == tuple(p.shape[:2]))
+        else:               # a fused group: the [sum n_i, k] matrix over its members
+            same = w.dim() == 2 and w.shape[1] == p.shape[1] and w.shape[0] == sum(q.shape[0] for q in owners) and w.is_contiguous()
+        if not same or any(self.versions.get(id(q)) != q._version for q in owners):
+            return None                 # a different view of that storage, or a parameter changed since the last refresh
         return img
 
 

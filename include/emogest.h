@@ -301,6 +301,29 @@ int eg_linear_splitk(const float* x, int32_t lda, const float* w, int32_t ldw, c
                      int32_t ldc, int32_t m, int32_t n, int32_t k, int32_t relu, int32_t splits,
                      float* partial, int32_t precision, void* stream);
 
+/* The extended product of the TRAINING path: eg_linear / eg_linear_splitk plus the two element masks a train()-mode transformer block needs
+ * around a product, so that they cost no launch of their own (Full_model/SubLayers.py:54,79: `q = self.dropout(self.fc(q)); q += residual`,
+ * `x = self.dropout(x); x += residual`; Models_spatial_memory.py:488-536: the Dropout(0.2) between the Linears of the projection MLPs):
+ *   v = acc + bias[n]
+ *   gate_src:  v = gate_src[m,n] > 0 ? v : 0      -- ReLU backward fused into the input-gradient product (gate_src = the forward's ReLU output)
+ *   drop_p>0:  v = keep(seed, epoch, drop_offset + m*n_cols + n) ? v / (1 - drop_p) : 0   -- nn.Dropout on the product; the mask is the counter
+ *              hash of eg_dropout_dev on the flat [M, N] index, so a backward pass re-draws it (here or with eg_dropout_dev) from the same scalars
+ *   v += res1[m,n];  relu;  res2 as eg_linear.
+ * splits >= 2: split-K (partial >= splits*M*N floats) with the same epilogue applied by the fixed-order fold.
+ * precision f32: w is [N, ldw] fp32; bf16 modes: the EG_PACK_LINEAR image (eg_pack_linear_device), ldw % 64 == 0. */
+typedef struct EgLinearArgs {
+    const float* x; const float* w; const float* bias; const float* res1; const float* res2; float* y;
+    const float* gate_src;          /* [M, ldg] or NULL */
+    const int32_t* drop_epoch;      /* device-resident step counter or NULL (eg_dropout_dev) */
+    float* partial;                 /* split-K scratch or NULL */
+    uint64_t drop_offset;
+    int32_t lda, ldw, ldr, ldc, ldg;
+    int32_t m, n, k, relu, precision, splits;
+    uint32_t drop_seed;
+    float drop_p;
+} EgLinearArgs;
+int eg_linear_ex(const EgLinearArgs* args, void* stream);
+
 /* nn.LayerNorm(D, eps) over the last axis (Full_model/SubLayers.py:55-57,80-82).  rows x D, D%4==0, D<=2048. */
 int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
                  float eps, void* stream);
@@ -510,6 +533,14 @@ int eg_se_scale(const float* a, const float* gate, const float* add, float* y, i
  * (dbeta, dgamma) = (sum dy, sum dy*xhat) = eg_colsum(dy, xhat, dbeta, dgamma, ...) */
 int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* xhat, int32_t rows, int32_t d, float eps,
                           void* stream);
+/* LayerNorm backward for the fused transformer blocks of the training path: dx as eg_layernorm_backward, the affine gradients from the SAME pass
+ * (per-workgroup partial column sums + one fixed-order fold: no xhat round trip, no separate column reduction), and -- drop_p > 0 -- a second
+ * output dx_dropped = nn.Dropout's backward applied to dx (the gradient that continues into the Dropout'ed branch `dropout(fc(.))` while dx itself
+ * goes to the residual; mask = eg_dropout_dev's on the flat [rows, d] index).  d % 64 == 0, d <= 1024.  workspace: eg_layernorm_backward_ex_workspace_floats. */
+int64_t eg_layernorm_backward_ex_workspace_floats(int32_t rows, int32_t d);
+int eg_layernorm_backward_ex(const float* x, const float* dy, const float* gamma, float* dx, float* dx_dropped, float* dgamma, float* dbeta,
+                             int32_t rows, int32_t d, float eps, float drop_p, uint32_t drop_seed, uint64_t drop_offset, const int32_t* epoch_dev,
+                             float* workspace, void* stream);
 /* ScaledDotProductAttention backward (Modules.py:13-23) from the forward's probabilities; Lq, Lk <= 64-ish (LDS-resident) */
 int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
                           const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,

@@ -1385,3 +1385,110 @@ def test_bench_train_step_with_the_cvae_on_a_side_stream_is_bitwise_the_one_stre
             assert np.isfinite(line["final_loss"])
             losses.append(line["final_loss"])
         assert losses[0] == losses[1], (extra, losses)
+
+
+# ---- round 5: fused transformer blocks (functional.mha_block / ffn_block / linear_chain, eg_linear_ex, eg_layernorm_backward_ex) ---------------
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_linear_ex_epilogue_masks_match_the_separate_kernels(precision):
+    """eg_linear_ex: Dropout from the counter hash and the ReLU-backward gate inside the product's epilogue (before the residual add) equal the
+    separate launches they replace (eg_dropout_dev on the product, the elementwise ReLU backward), bitwise, with and without split-K."""
+    from emotiongestures_amd.train import functional as F
+    with F.precision(precision):
+        for (M, K, N) in ((70, 512, 512), (544, 2048, 512), (37, 126, 126)):
+            x, w, b = T("x", (M, K)).to(DEV), (T("w", (N, K)) * 0.05).to(DEV), T("b", (N,)).to(DEV)
+            res, gate = T("r", (M, N), seed=3).to(DEV), T("g", (M, N), seed=5).to(DEV)
+            site = (0.2, 77, 4096, None)
+            plain = F.raw_linear(x, w, b)
+            want_d = torch.empty_like(plain)
+            from emotiongestures_amd import _lib as L
+            from emotiongestures_amd.engine import _ptr, _stream
+            L.check(L.load().eg_dropout_dev(_ptr(plain), _ptr(want_d), plain.numel(), 0.2, 77, 4096, None, _stream(DEV)), "eg_dropout_dev")
+            got = F.raw_linear(x, w, b, res=res, drop=site)
+            assert torch.equal(got, want_d + res), (precision, M, K, N)
+            got_g = F.raw_linear(x, w, b, gate=gate)
+            assert torch.equal(got_g, torch.where(gate > 0, plain, torch.zeros_like(plain)))
+            both = F.raw_linear(x, w, b, gate=gate, drop=site, res=res, relu=True)
+            assert torch.equal(both, torch.relu(torch.where(gate > 0, want_d, torch.zeros_like(plain)) + res))
+            assert float((want_d == 0).float().mean()) > 0.1
+
+
+@pytest.mark.parametrize("rows,D,p", [(68, 512, 0.0), (544, 512, 0.1), (4352, 512, 0.1), (130, 128, 0.2), (70, 1024, 0.0)])
+def test_layernorm_backward_ex_matches_torch_and_the_dropout_kernel(rows, D, p):
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    from emotiongestures_amd.train import functional as F
+    x, dy, g = T("x", (rows, D), seed=1), T("dy", (rows, D), seed=2), T("g", (D,), 0.5, 1.5, seed=3)
+    xr = x.clone().double().requires_grad_(True)
+    gr, br = g.clone().double().requires_grad_(True), torch.zeros(D, dtype=torch.float64, requires_grad=True)
+    TF.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.double())
+    gp, bp = torch.nn.Parameter(g.clone().to(DEV)), torch.nn.Parameter(torch.zeros(D, device=DEV))
+    site = (p, 5, 8192, None) if p > 0 else None
+    dpre, dbr, dg, db = F._ln_backward_ex(x.to(DEV), dy.to(DEV), gp.detach(), 1e-6, site, gp, bp)
+    assert rel(dpre, xr.grad) < 2e-6 and rel(dg, gr.grad) < 2e-6 and rel(db, br.grad) < 2e-6
+    if p > 0:
+        want = torch.empty_like(dpre)
+        L.check(L.load().eg_dropout_dev(_ptr(dpre), _ptr(want), dpre.numel(), p, 5, 8192, None, _stream(DEV)), "eg_dropout_dev")
+        assert torch.equal(dbr, want) and not torch.equal(dbr, dpre)
+    else:
+        assert dbr is dpre
+    again = F._ln_backward_ex(x.to(DEV), dy.to(DEV), gp.detach(), 1e-6, site, gp, bp)
+    assert all(torch.equal(a, b) for a, b in zip(again, (dpre, dbr, dg, db)))          # fixed-order partial sums: bitwise reproducible
+
+
+@pytest.mark.parametrize("precision,flat,dropout", [("f32", False, False), ("f32", True, True), ("bf16x3", True, True), ("bf16x3", True, False)])
+def test_fused_blocks_step_equals_the_operator_by_operator_step(precision, flat, dropout):
+    """The fused transformer blocks (one autograd node per MultiHeadAttention / FFN / Linear chain: Q|K|V and K|V as one product, Dropout + residual
+    and the ReLU backward in GEMM epilogues, LayerNorm backward with both gradients and the affine sums) against the operator-by-operator
+    composition they replace, on the whole generator + CVAE step: same loss, same gradient for every parameter.  With Dropout on, both draw the
+    SAME masks (same call sites in the same order on the counter stream), so the comparison is as tight as without.  `flat`: parameters in the
+    flat buffer (fused weights are views, weight gradients land in adjacent flat slices, resident fused weight images)."""
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train import nets
+    from emotiongestures_amd.train.optim import flatten_parameters
+    B = 3
+    inp = synth_inputs(B, 34, 126, 4, seed=31)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    target = T("tgt", (B, 34, 126), -0.5, 0.5).to(DEV)
+    label = g["label"].argmax(1)
+    eps = g["z"]
+    out = []
+    try:
+        for fused in (False, True):
+            F.FUSE_BLOCKS = fused
+            F.set_precision(precision)
+            model = build_mirror("spatial", 34, 126, 4, 4, seed=2, precision="f32").to(DEV).train()
+            vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 2).to(DEV).train()
+            model.train_dropout = vae.train_dropout = dropout
+            both = torch.nn.ModuleList([model, vae])
+            if flat:
+                fp = flatten_parameters(both)
+                if precision != "f32":
+                    fp.enable_weight_images(*nets.weight_image_plan(both))
+            F.manual_seed(99)
+            n0 = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count())
+            pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+            rec, mu, logvar = vae(emo.detach(), g["label"], eps)
+            loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
+                         F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
+            loss.backward()
+            torch.cuda.synchronize()
+            launches = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count()) - n0
+            grads = {n: p.grad.detach().clone() for n, p in both.named_parameters() if p.grad is not None}
+            out.append((float(loss.detach()), grads, launches))
+            if flat:
+                if fp.images is not None:
+                    F.unregister_weight_images(fp.images)
+                # the fused weight gradients were written straight into the flat buffer (adjacent slices of w_qs | w_ks | w_vs)
+                a = model.encoder.layer_stack[0].slf_attn
+                assert all(w.grad.data_ptr() == w._eg_slot.data_ptr() for w in (a.w_qs.weight, a.w_ks.weight, a.w_vs.weight)) or not fused
+    finally:
+        F.FUSE_BLOCKS = True
+        F.reset_state()
+    (l0, g0, n0), (l1, g1, n1) = out
+    assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys()
+    tol = 2e-5 if precision == "f32" else 1e-4
+    worst = max((rel(g1[k], g0[k]), k) for k in g0 if float(g0[k].norm()) > 0)
+    assert worst[0] < tol, worst
+    assert n1 <= n0 - 120, (n0, n1)            # the point of the exercise: fewer launches per step
