@@ -305,7 +305,7 @@ def beat_long_leg(precision, dev, steps, B=16, lanes=4):
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     pose = pipe.outputs(0)[0].cpu().numpy()
-    n_chk = 4                                   # oracle cost: ~0.1 s per long clip on the host
+    n_chk = B                                   # every clip of the step (oracle: ~0.1-0.2 s per long clip on the host)
     with torch.no_grad():
         t = {k: torch.from_numpy(inp[k][:n_chk]) for k in ("text", "pre_pose", "label", "z")}
         spec = torch.from_numpy(O.melspectrogram(inp["audio"][:n_chk], out_frames=T))
@@ -336,17 +336,41 @@ def diversity_leg(precision, dev, steps, B=64, R=32):
     lab = g["label"][:, None, :].expand(B, R, 8).reshape(B * R, 8).contiguous()
     zd = torch.from_numpy(z).reshape(B * R, 32).to(dev)
 
-    def step():
+    # hipGraph replay with `lanes` steps in flight, like every other leg: one captured step (CVAE draws -> forward_draws) per lane, each lane its own
+    # stream, workspaces (slot) and outputs; the lanes share the models and the weight arena
+    lanes = 2
+
+    def step(slot=0):
         with torch.no_grad():
-            return model.forward_draws(g["spec"], g["pre_pose"], vae.sample(lab, z=zd).view(B, R, 34, 512))
-    for _ in range(2):
-        poses = step()
+            return model.forward_draws(g["spec"], g["pre_pose"], vae.sample(lab, z=zd, slot=slot).view(B, R, 34, 512), slot=slot)
+    graphs = []
+    for i in range(lanes):
+        st = torch.cuda.Stream(dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                step(i)
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            out_i = step(i)
+        graphs.append((gr, st, out_i))
+
+    def launch(k):
+        gr, st, _o = graphs[k % lanes]
+        with torch.cuda.stream(st):
+            gr.replay()
+    for k in range(2 * lanes):
+        launch(k)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        poses = step()
+    for k in range(steps):
+        launch(k)
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
+    poses = graphs[0][2]
+    if lanes > 1 and not all(torch.equal(graphs[i][2], poses) for i in range(1, lanes)):
+        raise SystemExit("bench.py: diversity lanes disagree on the same batch (invalid run)")
     clips, draws = [0, 31, 63], [0, 15, 31]
     err = 0.0
     t = {k: torch.from_numpy(v[clips]) for k, v in inp.items()}
@@ -355,7 +379,7 @@ def diversity_leg(precision, dev, steps, B=64, R=32):
             ref = O.generator_forward(sd, O.GenCfg(), t["spec"], t["text"], t["pre_pose"], O.cvae_sample(sdv, t["label"], torch.from_numpy(z[clips, r])))[0]
         err = max(err, clip_rel_l2(poses[clips, r].cpu().numpy(), ref.numpy()))
     return {"value": round(B * R * steps / el, 1), "unit": "pose sequences/s", "clips_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
-            "dtype": precision, "config": f"{B} clips x {R} CVAE draws per step (audio tower once per clip, transformer per draw), eager launch, 1 step in flight",
+            "dtype": precision, "config": f"{B} clips x {R} CVAE draws per step (audio tower once per clip, transformer per draw), hipGraph replay, {lanes} steps in flight",
             "pose_rel_l2_vs_cpu_oracle": err, "parity_pairs_checked": len(clips) * len(draws)}
 
 
@@ -858,6 +882,8 @@ def main():
                 par = train_leg(dev, tb, "f32", False, 3, 1)
                 for k in ("trainable_parameters", "buckets", "allreduce_exposed_ms_per_step"):
                     rec.pop(k, None)
+                rec["parity"] = ("p0 only: gradients are pinned against the reference's autograd with every Dropout at p = 0 (`parity_p0` times that step); with Dropout "
+                                 "on the mask stream is the library's own (not torch's), checked for keep rate / reproducibility, not element-wise")
                 rec["parity_p0"] = {k: p0[k] for k in ("value", "ms_per_step", "first_loss", "final_loss", "library_launches_per_step", "frac_of_mfma_peak")}
                 rec["f32_eager"] = {k: par[k] for k in ("value", "ms_per_step", "first_loss", "library_launches_per_step", "frac_of_mfma_peak")}
                 rec["hbm"] = train_hbm_gb_per_step(tb)

@@ -133,14 +133,14 @@ class GeneratorEngine:
         return pose, emo, sem, pred, txt
 
     @_locked
-    def forward_draws(self, spec, prior, sampled):
-        """BASELINE config 5: sampled [B, R, frames, d_model] -> pose [B, R, frames, pose_dim]."""
+    def forward_draws(self, spec, prior, sampled, slot=0):
+        """BASELINE config 5: sampled [B, R, frames, d_model] -> pose [B, R, frames, pose_dim].  slot: a private workspace (one per step in flight)."""
         dev = self.arena.device
         c = self.cfg
         spec, prior, sampled = _need_cuda(spec, "spec"), _need_cuda(prior, "prior"), _need_cuda(sampled, "sampled")
         B, R = sampled.shape[0], sampled.shape[1]
         ws_bytes = self._lib.eg_generator_draws_workspace_bytes(self._h, B, R)
-        ws = self._workspace(("draws", B, R), ws_bytes, dev)
+        ws = self._workspace(("draws", B, R) if slot == 0 else ("draws", B, R, slot), ws_bytes, dev)
         pose = torch.empty(B, R, c.frames, c.pose_dim, device=dev)
         L.check(self._lib.eg_generator_forward_draws(self._h, _ptr(self.arena), B, R, _ptr(spec), _ptr(prior), _ptr(sampled),
                                                      _ptr(pose), _ptr(ws), ws_bytes, _stream(dev)), "eg_generator_forward_draws")

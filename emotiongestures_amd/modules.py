@@ -740,10 +740,10 @@ class Transformer(ReplicaAware, nn.Module):
         dev = input_spectrum.device if self.__dict__.get("_dp_origin") is not None and input_spectrum.is_cuda else None
         return self.engine(dev).forward(input_spectrum, text, prior_seq, sampled_emotion_feature, slot=slot)
 
-    def forward_draws(self, input_spectrum, prior_seq, sampled_emotion_features):
+    def forward_draws(self, input_spectrum, prior_seq, sampled_emotion_features, *, slot=0):
         """Diversity sampling (BASELINE config 5): sampled [B,R,frames,d_model] -> pose [B,R,frames,pose_dim]."""
         _eval_only(self)
-        return self.engine().forward_draws(input_spectrum, prior_seq, sampled_emotion_features)
+        return self.engine().forward_draws(input_spectrum, prior_seq, sampled_emotion_features, slot=slot)
 
 
 class TransformerMemory(Transformer):
