@@ -920,7 +920,7 @@ def main():
 
 
 GEMM_NAMES = {2: "gemm_glds_kernel (fp32 X via LDS-DMA)", 3: "gemm_presplit_kernel (pre-split X)", 4: "gemm_bf16_kernel (causal shift)",
-              5: "gemm_kernel (f32 MFMA)", 6: "attention_mfma_kernel"}
+              5: "gemm_kernel (f32 MFMA)", 6: "attention_mfma_kernel", 7: "ffn_slab_kernel (fused w_1 -> ReLU -> w_2 + residual, hidden in LDS)"}
 
 
 def kernel_name(tag):

@@ -5,10 +5,13 @@
 namespace {
 
 // ---- LayerNorm (Full_model/SubLayers.py:55-57,80-82): one wave per row, two-pass in registers ----------
-template <int NV>   // NV f4 per lane (D <= NV*256)
+// SUMP: the row is not read from x but folded from `nparts` partial-sum planes [nparts][rows][D] (x = plane 0) in order, + bias2 + resid: the epilogue
+// the fused FFN slab kernel (ffn.hip) leaves to its LayerNorm when the hidden is split over several workgroups.
+struct LnSum { int nparts = 0; const float* bias2 = nullptr; const float* resid = nullptr; int ldr = 0; };
+template <int NV, bool SUMP = false>   // NV f4 per lane (D <= NV*256)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, float* __restrict__ y, int rows, int D,
-                                                        float eps, unsigned short* __restrict__ img) {
+                                                        float eps, unsigned short* __restrict__ img, LnSum ps = LnSum()) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * D);
@@ -19,6 +22,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         const int q = lane + i * 64;
         v[i] = q < nq ? xr[q] : (f4){0.f, 0.f, 0.f, 0.f};
+        if (SUMP && q < nq) {
+            for (int p = 1; p < ps.nparts; ++p) v[i] += reinterpret_cast<const f4*>(x + ((size_t)p * rows + row) * D)[q];
+            v[i] = v[i] + reinterpret_cast<const f4*>(ps.bias2)[q] + reinterpret_cast<const f4*>(ps.resid + (size_t)row * ps.ldr)[q];
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)D;
@@ -439,6 +446,16 @@ int egi_layernorm(const float* x, const float* gamma, const float* beta, float* 
     else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
     else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
     return eg_check_launch("layernorm");
+}
+int egi_layernorm_sum(const float* parts, int nparts, const float* bias, const float* resid, int ldr, const float* gamma, const float* beta, float* y, void* img,
+                      int rows, int d, float eps, hipStream_t st) {
+    EG_REQUIRE(parts && bias && resid && gamma && beta && y && rows > 0 && nparts >= 1, EG_ERR_BAD_ARG, "egi_layernorm_sum: null pointer");
+    EG_REQUIRE(d > 0 && d <= 512 && (d & 63) == 0 && (ldr & 3) == 0, EG_ERR_UNSUPPORTED, "egi_layernorm_sum: D=%d ldr=%d", d, ldr);
+    LnSum ps;
+    ps.nparts = nparts; ps.bias2 = bias; ps.resid = resid; ps.ldr = ldr;
+    hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(eg_cdiv(rows, 4)), dim3(256), 0, st, parts, gamma, beta, y, rows, d, eps,
+                       reinterpret_cast<unsigned short*>(img), ps);
+    return eg_check_launch("layernorm_sum");
 }
 extern "C" int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
                             float eps, void* stream) {
