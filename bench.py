@@ -352,7 +352,8 @@ def diversity_leg(precision, dev, steps, B=64, R=32):
                 step(i)
         torch.cuda.synchronize(dev)
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=st):
+        from emotiongestures_amd.pipeline import CAPTURE_MODE
+        with torch.cuda.graph(gr, stream=st, capture_error_mode=CAPTURE_MODE):
             out_i = step(i)
         graphs.append((gr, st, out_i))
 
@@ -546,6 +547,18 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
     return out
 
 
+def emit(line):
+    """The ONE JSON line, as the LAST line of stdout: RCCL writes its version banner through libc's stdout buffer, which would otherwise be flushed
+    behind Python's at exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def collective_facts(dist, backend, dev):
     """What the process group really is: backend, RCCL version, and the ranks an all_reduce / all_gather actually reached (every rank calls)."""
     if dist is None:
@@ -603,7 +616,7 @@ def train_worker(args, rank, world, dev, dist, backend):
         if parity is not None:
             parity.pop("trainable_parameters"); parity.pop("buckets")
             line["f32_eager"] = parity
-        print(json.dumps(line))
+        emit(line)
     return 0
 
 
@@ -915,7 +928,7 @@ def main():
         }
         if facts is not None:       # N > 1 (or EG_FORCE_COLLECTIVES): what the barrier / max-over-ranks really ran over
             line["collectives"] = facts
-        print(json.dumps(line))
+        emit(line)
     return 0
 
 

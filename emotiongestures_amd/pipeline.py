@@ -17,6 +17,13 @@ from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 import torch
 
 
+# Stream capture in `thread_local` error mode: with a torch.distributed process group alive (bench.py --gpus N, DataParallel's RCCL broadcast) the
+# RCCL watchdog thread polls its events (hipEventQuery) at any time; under the default `global` mode such a call from ANOTHER thread while this
+# thread captures is flagged as illegal and the watchdog aborts the process ("operation not permitted when stream is capturing" -- caught in
+# round 5 by the forced 1-rank RCCL run: 4 of 8 runs died).  Only calls made by the capturing thread itself can invalidate its capture.
+CAPTURE_MODE = "thread_local"
+
+
 class _Lane:
     __slots__ = ("slot", "stream", "graph", "inputs", "outputs", "done", "busy", "collected", "keep", "key")
 
@@ -74,7 +81,7 @@ class ClipPipeline:
         torch.cuda.current_stream(self.device).wait_stream(cap)
         torch.cuda.synchronize(self.device)
         ln.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ln.graph):
+        with torch.cuda.graph(ln.graph, capture_error_mode=CAPTURE_MODE):
             ln.outputs = self._step(ln)
         ln.graph.replay()                 # capture does not execute: run once so that the lane's outputs are defined from the start
         torch.cuda.synchronize(self.device)

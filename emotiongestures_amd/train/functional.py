@@ -481,6 +481,9 @@ def _pack_conv(w, flip=False):
     return img
 
 
+PAD_WGRAD = True            # False: ragged-width weight gradients on the fp32 implicit GEMM (A/B switch of the tests)
+
+
 class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(k=3, pad=1, stride s) on NHWC activations; weight OIHW as in the reference's state_dict."""
 
@@ -568,6 +571,18 @@ class _Conv3x3(torch.autograd.Function):
             ws = _scratch(dev, need, "wgrad")
             L.check(lib.eg_conv3x3_wgrad_mfma_oihw(_ptr(x), _ptr(dy2), _ptr(dw), B, H, W, Ci, Co, _ptr(ws), ws.numel(), _stream(dev)),
                     "eg_conv3x3_wgrad_mfma")
+        elif _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 4 == 0 and PAD_WGRAD:
+            # a ragged output width (final_conv1: 128 -> frames = 34 / 60 / 120): the same MFMA kernel on dy zero-padded to a multiple of 32 channels --
+            # the padded rows of dW come out zero and are dropped (one pad pass over dy and a small copy instead of the fp32 implicit GEMM:
+            # 274 -> ~60 us at 128 clips)
+            Cop = (Co + 31) // 32 * 32
+            dyp = _pad_cols(dy2, 32)
+            dwp = torch.empty(Cop, Ci, 3, 3, dtype=torch.float32, device=dev)
+            need = lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Cop)
+            ws = _scratch(dev, need, "wgrad")
+            L.check(lib.eg_conv3x3_wgrad_mfma_oihw(_ptr(x), _ptr(dyp), _ptr(dwp), B, H, W, Ci, Cop, _ptr(ws), ws.numel(), _stream(dev)),
+                    "eg_conv3x3_wgrad_mfma")
+            dw.copy_(dwp[:Co])                                              # data movement into the flat gradient slice
         elif Ci % 4 == 0:           # implicit GEMM over the output pixels (no im2col buffer)
             dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
             need = lib.eg_gemm_tn_workspace_floats(Co, 9 * Ci, B * Ho * Wo)

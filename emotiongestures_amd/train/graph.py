@@ -18,6 +18,7 @@ import torch
 from .. import _lib as L
 from . import functional as F
 from .optim import FlatAdam
+from ..pipeline import CAPTURE_MODE          # "thread_local": the RCCL watchdog thread may poll its events while this thread captures
 
 
 def _drop_stream_scratch(stream) -> None:
@@ -61,7 +62,7 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode=CAPTURE_MODE):
             self.loss = step_fn(inputs)
         if optimizer is not None:
             optimizer.t -= 1                        # the capture recorded a step without executing it
@@ -233,13 +234,13 @@ class SegmentedStep:
         pool = torch.cuda.graph_pool_handle()
         graphs, ready = [], []
         g0 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g0, pool=pool, stream=self._stream):
+        with torch.cuda.graph(g0, pool=pool, stream=self._stream, capture_error_mode=CAPTURE_MODE):
             ready.append(self._phase0())
         graphs.append(g0)
         n_cuts = len(self.ctx.cuts)
         for i in range(n_cuts):
             gi = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gi, pool=pool, stream=self._stream):
+            with torch.cuda.graph(gi, pool=pool, stream=self._stream, capture_error_mode=CAPTURE_MODE):
                 r = self._phase_cut(i)
                 if i == n_cuts - 1:
                     r = r + self._phase_last_collect()
@@ -248,7 +249,7 @@ class SegmentedStep:
         if n_cuts == 0:
             ready[-1] = ready[-1] + self._phase_last_collect_captured(pool, graphs)
         gt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gt, pool=pool, stream=self._stream):
+        with torch.cuda.graph(gt, pool=pool, stream=self._stream, capture_error_mode=CAPTURE_MODE):
             self._tail()
         graphs.append(gt)
         self.opt.t -= 1                                           # the capture recorded an optimiser step without executing it
@@ -258,7 +259,7 @@ class SegmentedStep:
 
     def _phase_last_collect_captured(self, pool, graphs):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool, stream=self._stream):
+        with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode=CAPTURE_MODE):
             r = self._phase_last_collect()
         graphs.append(g)
         return r
