@@ -46,8 +46,9 @@ _L = C.c_int64
 
 class EgLinearArgs(C.Structure):
     """include/emogest.h: the argument block of eg_linear_ex (field order = the header's)."""
-    _fields_ = [(n, _P) for n in ("x", "w", "bias", "res1", "res2", "y", "gate_src", "drop_epoch", "partial")] + [("drop_offset", C.c_uint64)] + \
-               [(n, _I) for n in ("lda", "ldw", "ldr", "ldc", "ldg", "m", "n", "k", "relu", "precision", "splits")] + \
+    _fields_ = [(n, _P) for n in ("x", "w", "bias", "res1", "res2", "y", "gate_src", "drop_epoch", "partial", "x_images", "y_images")] + \
+               [("drop_offset", C.c_uint64)] + \
+               [(n, _I) for n in ("lda", "ldw", "ldr", "ldc", "ldg", "m", "n", "k", "relu", "precision", "splits", "k_x", "y_k")] + \
                [("drop_seed", C.c_uint32), ("drop_p", C.c_float)]
 
 
@@ -172,7 +173,8 @@ SIGNATURES = {
     "eg_linear_wgrad_mfma": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
     "eg_linear_ex": (C.c_int, [C.POINTER(EgLinearArgs), _P]),
     "eg_layernorm_backward_ex_workspace_floats": (_L, [_I, _I]),
-    "eg_layernorm_backward_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_float, C.c_float, C.c_uint32, C.c_uint64, _P, _P, _P]),
+    "eg_layernorm_backward_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_float, C.c_float, C.c_uint32, C.c_uint64, _P, _P, _P, _P]),
+    "eg_layernorm_img": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "eg_f32_to_bf16": (C.c_int, [_P, _P, _L, _P]),
     "eg_bf16_to_f32": (C.c_int, [_P, _P, _L, C.c_float, _P]),
 }

@@ -473,7 +473,7 @@ int launch_glds(const GemmArgs& a, int splits, hipStream_t st) {
 // 4 -> 128 x 64 (two 64-row X image tiles; the wave grid stays 2 x 2, a wave owns 64 x 32).  The 64 x 64 tile streams 16 KB of operands
 // from L2 into LDS per 48 MFMAs; the 128 x 64 tile 24 KB per 96 (3/4 of the operand stream per MFMA, 6 instead of 4 LDS-DMA pieces and
 // 12 instead of 8 ds_read_b128 per wave for twice the MFMAs), at half the workgroups.
-template <int TERMS, int BK, int RING, int WM = 2>
+template <int TERMS, int BK, int RING, int WM = 2, bool TRAIN = false>
 __global__ __launch_bounds__(256, (WM == 2 || RING <= 3) ? 2 : 1) void gemm_presplit_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr int KG = BK / 32;                                           // MFMA k-groups per step
@@ -638,14 +638,14 @@ __global__ __launch_bounds__(256, (WM == 2 || RING <= 3) ? 2 : 1) void gemm_pres
         step(s, fa, fb);
         if (s + 1 < nsteps) step(s + 1, fb, fa);
     }
-    gemm_epilogue<WM, 2>(a, acc, m0 + ((TM == 1) ? wm : wmt * 64) + li, n0 + wn + kq * 4);
+    gemm_epilogue<WM, 2, TRAIN>(a, acc, m0 + ((TM == 1) ? wm : wmt * 64) + li, n0 + wn + kq * 4);
 }
 
-template <int TERMS, int BK, int RING, int WM = 2>
+template <int TERMS, int BK, int RING, int WM = 2, bool TRAIN = false>
 int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, dim3 grid, hipStream_t st) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr size_t LDS_BYTES = (size_t)RING * (WM / 2 + 1) * NIMG * (BK / 32) * 4 * 64 * 16;
-    auto kern = gemm_presplit_kernel<TERMS, BK, RING, WM>;
+    auto kern = gemm_presplit_kernel<TERMS, BK, RING, WM, TRAIN>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_presplit")) return rc;
     if (WM == 4) grid.x = (grid.x + 1) / 2;          // grid.x arrives as the number of 64-row tiles
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, xhi, xlo, xko);
@@ -659,7 +659,7 @@ int launch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, 
 // workgroup tile 128 x 128 = two 64-row image tiles of X and of W, 32 KB per 32-deep step, 3-slot ring (96 KB: one workgroup
 // = two waves per SIMD).  Schedule as in the convolution: one barrier per step between the two MFMA halves, counted vmcnt
 // (the copy of step s+2 stays in flight), fragments of step s+1 read after the barrier under the second half.
-template <int TERMS, int RING = 3>
+template <int TERMS, int RING = 3, bool TRAIN = false>
 __global__ __launch_bounds__(512, 1) void gemm_presplit128_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO,
                                                                   int m_tiles, int n_tiles) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
@@ -751,15 +751,15 @@ __global__ __launch_bounds__(512, 1) void gemm_presplit128_kernel(GemmArgs a, co
         step(s, fa, fb);
         if (s + 1 < nsteps) step(s + 1, fb, fa);
     }
-    gemm_epilogue<4, 2>(a, acc, m0 + wm * 64 + li, n0 + wn * 32 + kq * 4);
+    gemm_epilogue<4, 2, TRAIN>(a, acc, m0 + wm * 64 + li, n0 + wn * 32 + kq * 4);
 }
 
-template <int TERMS, int RING = 3>
+template <int TERMS, int RING = 3, bool TRAIN = false>
 int launch_presplit128(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, int m_tiles, int n_tiles, hipStream_t st) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr size_t LDS_BYTES = (size_t)RING * 2 * NIMG * 8 * 64 * 16;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    auto kern = gemm_presplit128_kernel<TERMS, RING>;
+    auto kern = gemm_presplit128_kernel<TERMS, RING, TRAIN>;
     if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "gemm_presplit128")) return rc;
     dim3 grid(eg_cdiv(m_tiles, 2), eg_cdiv(n_tiles, 2), 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, st, a, xhi, xlo, xko, m_tiles, n_tiles);
@@ -803,6 +803,11 @@ int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko
     }
     const bool x3 = precision == EG_PREC_BF16X3;
     dim3 grid(mt, nt, 1);
+    if (a.gate || a.drop.thr) {             // the training epilogue (ReLU-backward gate / Dropout): split-bf16 only, the two default tiles
+        if (!x3) { eg_set_error("pre-split product with a training epilogue: bf16x3 only"); return EG_ERR_UNSUPPORTED; }
+        if (tile == TILE_128) return launch_presplit128<3, 3, true>(a, xhi, xlo, xko, mt, nt, st);
+        return launch_presplit<3, 32, 4, 2, true>(a, xhi, xlo, xko, grid, st);
+    }
     switch (tile) {
         case TILE_128: return x3 ? launch_presplit128<3>(a, xhi, xlo, xko, mt, nt, st) : launch_presplit128<1>(a, xhi, xlo, xko, mt, nt, st);
         case TILE_128x64: return x3 ? launch_presplit<3, 32, 4, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4, 4>(a, xhi, xlo, xko, grid, st);
@@ -965,8 +970,10 @@ extern "C" int eg_linear_splitk(const float* x, int32_t lda, const float* w, int
 extern "C" int eg_linear_ex(const EgLinearArgs* p, void* stream) {
     EG_REQUIRE(p, EG_ERR_BAD_ARG, "eg_linear_ex: null argument block");
     GemmArgs a;
-    int rc = fill_common(a, p->x, p->lda, p->w, p->ldw, p->m, p->n, p->k, p->precision, "eg_linear_ex");
+    int rc = fill_common(a, p->x_images ? reinterpret_cast<const float*>(p->x_images) : p->x, p->x_images ? 4 : p->lda, p->w, p->ldw, p->m, p->n, p->k, p->precision,
+                         "eg_linear_ex");
     if (rc) return rc;
+    if (p->x_images) a.x = nullptr;
     EG_REQUIRE(p->y, EG_ERR_BAD_ARG, "eg_linear_ex: null output");
     EG_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, EG_ERR_BAD_ARG, "eg_linear_ex: drop_p=%f", (double)p->drop_p);
     a.bias = p->bias; a.res1 = p->res1; a.res2 = p->res2; a.ldr = p->ldr; a.y = p->y; a.ldc = p->ldc; a.relu = p->relu;
@@ -977,10 +984,25 @@ extern "C" int eg_linear_ex(const EgLinearArgs* p, void* stream) {
         a.drop.inv_keep = 1.0f / (1.0f - p->drop_p);
         a.drop.seed = p->drop_seed; a.drop.offset = p->drop_offset; a.drop.epoch = p->drop_epoch;
     }
+    if (p->y_images) {                  // second output: Y as bf16 (hi, lo) tile-planar images of width y_k for a downstream pre-split product
+        EG_REQUIRE(p->precision != EG_PREC_F32 && (p->n & 3) == 0 && (p->y_k & 63) == 0 && p->y_k >= p->n && p->splits < 2, EG_ERR_BAD_ARG,
+                   "eg_linear_ex: image output needs a bf16 mode, n %% 4 == 0, y_k %% 64 == 0 and no split-K");
+        a.yimg = reinterpret_cast<unsigned short*>(p->y_images); a.yKO = p->y_k >> 3; a.yoct0 = 0;
+    }
     if (p->splits >= 2) {
-        EG_REQUIRE(p->partial, EG_ERR_BAD_ARG, "eg_linear_ex: split-K needs a partial buffer of splits*M*N floats");
+        EG_REQUIRE(p->partial && !p->x_images, EG_ERR_BAD_ARG, "eg_linear_ex: split-K needs a partial buffer of splits*M*N floats (and fp32 X)");
         a.partial = p->partial;
         return launch_splitk(a, p->splits, p->precision, (hipStream_t)stream);
+    }
+    if (p->x_images) {                  // X arrives pre-split (the producing kernel's epilogue wrote the images): no in-kernel split, both operands by LDS-DMA
+        EG_REQUIRE(p->precision != EG_PREC_F32 && (p->k_x & 63) == 0 && (p->k & 31) == 0 && p->k <= p->k_x, EG_ERR_BAD_ARG,
+                   "eg_linear_ex: pre-split X needs a bf16 mode, k %% 32 == 0 and images of width k_x %% 64 == 0 >= k");
+        const int xko = p->k_x >> 3, mt = eg_cdiv(p->m, 64);
+        const bf8* xhi = reinterpret_cast<const bf8*>(p->x_images);
+        const bf8* xlo = xhi + (size_t)mt * xko * 64;
+        a.xoct0 = 0;
+        EgProfScope prof(3, 2.0 * p->m * (double)p->n * p->k, (hipStream_t)stream);
+        return dispatch_presplit(a, xhi, xlo, xko, p->precision, (hipStream_t)stream, &prof, 0);
     }
     EgProfScope prof(p->precision == EG_PREC_F32 ? 5 : 2, 2.0 * p->m * (double)p->n * p->k, (hipStream_t)stream);
     return launch_gemm(a, 1, p->precision, (hipStream_t)stream);

@@ -457,6 +457,10 @@ int egi_layernorm_sum(const float* parts, int nparts, const float* bias, const f
                        reinterpret_cast<unsigned short*>(img), ps);
     return eg_check_launch("layernorm_sum");
 }
+extern "C" int eg_layernorm_img(const float* x, const float* gamma, const float* beta, float* y, void* y_images, int32_t rows, int32_t d, float eps,
+                                void* stream) {
+    return egi_layernorm(x, gamma, beta, y, y_images, rows, d, eps, (hipStream_t)stream);
+}
 extern "C" int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
                             float eps, void* stream) {
     return egi_layernorm(x, gamma, beta, y, nullptr, rows, d, eps, (hipStream_t)stream);

@@ -972,75 +972,95 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// LayerNorm backward for the fused transformer blocks: a wave walks RW rows with the row held in registers (NC column slots per lane), keeps the two
-// affine-gradient column sums (sum dy, sum dy * xhat) in registers across its rows, and the workgroup's four waves are folded through LDS in a fixed
-// order into one partial per workgroup ([blk][2][D], the layout col_finalize_kernel folds).  Optional second output: dx with the Dropout mask of the
-// branch that precedes the residual add.
-template <int NC>
+// LayerNorm backward for the fused transformer blocks: a wave walks RW rows with the row held in registers (NV float4 per lane: the column quads
+// lane + 64 i), keeps the two affine-gradient column sums (sum dy, sum dy * xhat) in registers across its rows, and the workgroup's four waves are
+// folded through LDS in a fixed order into one partial per workgroup ([blk][2][D], the layout col_finalize_kernel folds).  Optional: a second output,
+// dx with the Dropout mask of the branch that precedes the residual add, and that branch gradient as bf16 (hi, lo) tile-planar images for a
+// pre-split input-gradient product.
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_ex_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                                                         float* __restrict__ dx, float* __restrict__ dxm, float* __restrict__ part, int rows, int D,
-                                                        int RW, float eps, EgDropout dr) {
+                                                        int RW, float eps, EgDropout dr, unsigned short* __restrict__ img) {
     extern __shared__ float lsum[];                      // [4 waves][2][D]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + wave) * RW;
+    const int row0 = (blockIdx.x * 4 + wave) * RW, nq = D >> 2;
     const unsigned int dseed = dr.thr ? dropout_seed(dr.seed, dr.epoch) : 0u;
     const float invD = 1.0f / (float)D;
-    float sb[NC], sg[NC], gm[NC];
+    const f4 z4 = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 sb[NV], sg[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        sb[i] = sg[i] = 0.f;
-        gm[i] = (i * 64 + lane < D) ? gamma[i * 64 + lane] : 0.f;
+    for (int i = 0; i < NV; ++i) {
+        sb[i] = sg[i] = z4;
+        gm[i] = (lane + i * 64 < nq) ? reinterpret_cast<const f4*>(gamma)[lane + i * 64] : z4;
     }
     for (int j = 0; j < RW; ++j) {
         const int row = row0 + j;
         if (row >= rows) break;
-        const float* xr = x + (size_t)row * D;
-        const float* dr_ = dy + (size_t)row * D;
-        float xv[NC], dv[NC];
+        const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * D);
+        const f4* dr_ = reinterpret_cast<const f4*>(dy + (size_t)row * D);
+        f4 xv[NV], dv[NV];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const bool ok = i * 64 + lane < D;
-            xv[i] = ok ? xr[i * 64 + lane] : 0.f;
-            dv[i] = ok ? dr_[i * 64 + lane] : 0.f;
-            s += xv[i];
+        for (int i = 0; i < NV; ++i) {
+            const bool ok = lane + i * 64 < nq;
+            xv[i] = ok ? xr[lane + i * 64] : z4;
+            dv[i] = ok ? dr_[lane + i * 64] : z4;
+            s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
         }
         const float mean = wave_sum(s) * invD;
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const float d = (i * 64 + lane < D) ? xv[i] - mean : 0.f;
-            ss += d * d;
-        }
+        for (int i = 0; i < NV; ++i)
+            if (lane + i * 64 < nq) {
+                const f4 d = xv[i] - mean;
+                ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
         const float rstd = 1.0f / sqrtf(wave_sum(ss) * invD + eps);
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const float xh = (xv[i] - mean) * rstd, gd = gm[i] * dv[i];      // columns >= D: gm = dv = 0
+        for (int i = 0; i < NV; ++i) {
+            const f4 xh = (xv[i] - mean) * rstd, gd = gm[i] * dv[i];      // quads past D: gm = dv = 0
             xv[i] = xh;
-            a += gd;
-            b += gd * xh;
+            a += (gd[0] + gd[1]) + (gd[2] + gd[3]);
+            b += (gd[0] * xh[0] + gd[1] * xh[1]) + (gd[2] * xh[2] + gd[3] * xh[3]);
         }
         a = wave_sum(a) * invD;
         b = wave_sum(b) * invD;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) {
-                const float g = rstd * (gm[i] * dv[i] - a - xv[i] * b);
-                dx[(size_t)row * D + c] = g;
-                if (dxm) dxm[(size_t)row * D + c] = dropout_keep(dseed, dr.offset + (unsigned long long)row * D + c, dr.thr) ? g * dr.inv_keep : 0.f;
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + i * 64;
+            if (q < nq) {
+                const f4 g = (gm[i] * dv[i] - a - xv[i] * b) * rstd;
+                reinterpret_cast<f4*>(dx + (size_t)row * D)[q] = g;
+                f4 br = g;
+                if (dxm) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        br[r] = dropout_keep(dseed, dr.offset + (unsigned long long)row * D + 4 * q + r, dr.thr) ? g[r] * dr.inv_keep : 0.f;
+                    reinterpret_cast<f4*>(dxm + (size_t)row * D)[q] = br;
+                }
+                if (img) {
+                    bf8 h8, l8;
+                    split_octet<true>(br, z4, h8, l8);
+                    const int KO = D >> 3;
+                    const size_t slot = (((size_t)(row >> 6) * KO + (q >> 1)) * 64 + (row & 63)) * 8 + (q & 1) * 4;
+                    const size_t lo_off = (size_t)((rows + 63) >> 6) * KO * 512;
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x4_t hh = __builtin_bit_cast(u32x4_t, h8), ll = __builtin_bit_cast(u32x4_t, l8);
+                    *reinterpret_cast<u32x2*>(img + slot) = (u32x2){hh[0], hh[1]};
+                    *reinterpret_cast<u32x2*>(img + lo_off + slot) = (u32x2){ll[0], ll[1]};
+                }
                 sb[i] += dv[i];
                 sg[i] += dv[i] * xv[i];
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = i * 64 + lane;
-        if (c < D) {
-            lsum[(wave * 2) * D + c] = sb[i];
-            lsum[(wave * 2 + 1) * D + c] = sg[i];
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nq) {
+            reinterpret_cast<f4*>(lsum + (wave * 2) * D)[q] = sb[i];
+            reinterpret_cast<f4*>(lsum + (wave * 2 + 1) * D)[q] = sg[i];
         }
     }
     __syncthreads();
@@ -1744,7 +1764,7 @@ extern "C" int64_t eg_layernorm_backward_ex_workspace_floats(int32_t rows, int32
 }
 extern "C" int eg_layernorm_backward_ex(const float* x, const float* dy, const float* gamma, float* dx, float* dx_dropped, float* dgamma, float* dbeta,
                                         int32_t rows, int32_t d, float eps, float drop_p, uint32_t drop_seed, uint64_t drop_offset,
-                                        const int32_t* epoch_dev, float* workspace, void* stream) {
+                                        const int32_t* epoch_dev, float* workspace, void* branch_images, void* stream) {
     EG_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && workspace && rows > 0, EG_ERR_BAD_ARG, "eg_layernorm_backward_ex: bad argument");
     EG_REQUIRE(d > 0 && (d & 63) == 0 && d <= 1024, EG_ERR_UNSUPPORTED, "eg_layernorm_backward_ex: d=%d (multiple of 64, <= 1024)", d);
     EG_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f) == (dx_dropped == nullptr), EG_ERR_BAD_ARG,
@@ -1757,8 +1777,9 @@ extern "C" int eg_layernorm_backward_ex(const float* x, const float* dy, const f
     }
     const int rw = ln_ex_rows_per_wave(rows), nblk = eg_cdiv(rows, 4 * rw);
     const size_t smem = (size_t)8 * d * sizeof(float);
-    if (d <= 512) hipLaunchKernelGGL((ln_bwd_ex_kernel<8>), dim3(nblk), dim3(256), smem, ST, x, dy, gamma, dx, dx_dropped, workspace, rows, d, rw, eps, dr);
-    else hipLaunchKernelGGL((ln_bwd_ex_kernel<16>), dim3(nblk), dim3(256), smem, ST, x, dy, gamma, dx, dx_dropped, workspace, rows, d, rw, eps, dr);
+    unsigned short* img = reinterpret_cast<unsigned short*>(branch_images);
+    if (d <= 512) hipLaunchKernelGGL((ln_bwd_ex_kernel<2>), dim3(nblk), dim3(256), smem, ST, x, dy, gamma, dx, dx_dropped, workspace, rows, d, rw, eps, dr, img);
+    else hipLaunchKernelGGL((ln_bwd_ex_kernel<4>), dim3(nblk), dim3(256), smem, ST, x, dy, gamma, dx, dx_dropped, workspace, rows, d, rw, eps, dr, img);
     if (int rc = eg_check_launch("layernorm_backward_ex")) return rc;
     hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(d, 4)), dim3(256), 0, ST, workspace, nblk, d, dbeta, dgamma, 1.0f);
     return eg_check_launch("layernorm_backward_ex_fold");

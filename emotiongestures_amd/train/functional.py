@@ -178,11 +178,16 @@ def _pack_linear(w, transpose=False):
     return img, (k + 63) // 64 * 64
 
 
-def _linear_ex(x, lda, w, ldw, bias, res, y, M, N, K, relu, prec, gate=None, drop=None, splits=0):
-    """One eg_linear_ex call (include/emogest.h: EgLinearArgs).  drop = (p, seed, offset, epoch tensor | None) of a Dropout site or None."""
+def _linear_ex(x, lda, w, ldw, bias, res, y, M, N, K, relu, prec, gate=None, drop=None, splits=0, x_img=None, y_img=None):
+    """One eg_linear_ex call (include/emogest.h: EgLinearArgs).  drop = (p, seed, offset, epoch tensor | None) of a Dropout site or None.
+    x_img: X as pre-split bf16 images of width K (then `x` is not read); y_img: receives Y as images of width N."""
     a = L.EgLinearArgs()
-    a.x, a.w, a.bias, a.res1, a.res2, a.y = x.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None), \
+    a.x, a.w, a.bias, a.res1, a.res2, a.y = (x.data_ptr() if x is not None else None), w.data_ptr(), (bias.data_ptr() if bias is not None else None), \
         (res.data_ptr() if res is not None else None), None, y.data_ptr()
+    if x_img is not None:
+        a.x_images, a.k_x = x_img.data_ptr(), K
+    if y_img is not None:
+        a.y_images, a.y_k = y_img.data_ptr(), N
     a.gate_src = gate.data_ptr() if gate is not None else None
     a.lda, a.ldw, a.ldr, a.ldc, a.ldg = lda, ldw, N, N, N
     a.m, a.n, a.k, a.relu, a.precision, a.splits = M, N, K, int(relu), prec, int(splits)
@@ -198,26 +203,54 @@ def _linear_ex(x, lda, w, ldw, bias, res, y, M, N, K, relu, prec, gate=None, dro
     return y
 
 
-def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False, gate=None, drop=None):
+# From this many rows up the fused blocks chain their products through pre-split images.  OFF by default (measured, round 5): at 128 clips per step
+# (4352 rows) the chained step takes 28.12 ms against 27.86 ms without -- stand-alone the pre-split product is only 4-17 us ahead of the fp32-input
+# kernel per launch at these shapes (tools/bench_ops.py gemm: 14.0 / 29.6 / 39.8 / 40.6 us against 18.4 / 35.4 / 46.0 / 57.7 us for 4352 x {512, 1536, 2048} x 512
+# and 4352 x 512 x 2048), and writing the images (LayerNorm outputs, the 2048-wide hidden and its gradient: ~36 MB per FFN each way) costs more than that.
+PRESPLIT_ROWS = int(__import__("os").environ.get("EG_TRAIN_PRESPLIT_ROWS", str(1 << 30)))
+
+
+def presplit_ok(rows: int, k: int) -> bool:
+    """Do the fused blocks hand activations of `rows` x `k` to their consumer as pre-split bf16 (hi, lo) images (the producing LayerNorm / GEMM epilogue
+    writes them, the consuming product reads both operands by LDS-DMA)?  Split-bf16 arithmetic only, `rows >= PRESPLIT_ROWS`."""
+    return _PREC["gemm"] != F32 and rows >= PRESPLIT_ROWS and k % 64 == 0 and k > 0
+
+
+def new_images(rows: int, k: int, dev) -> torch.Tensor:
+    """Storage of the bf16 (hi, lo) tile-planar images of a [rows, k] activation (eg_split_tiles layout): 4 bytes per element of the padded tile grid."""
+    return torch.empty(((rows + 63) // 64) * 64 * k, dtype=torch.float32, device=dev)
+
+
+def images_of(t):
+    """The images a producing block attached to its output tensor (None: the consumer reads fp32)."""
+    return getattr(t, "_eg_img", None)
+
+
+def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False, gate=None, drop=None, x_img=None, want_img=False):
     """y[M,N] = epi(x[M,K] w[N,K]^T) on the MFMA GEMM (eg_linear_ex): fp32, or split-bf16 under set_precision("bf16x3").
     epi: + bias; `gate` ([M,N]): ReLU backward (v = gate > 0 ? v : 0); `drop` = (p, seed, offset, epoch): nn.Dropout on the product from the
-    counter hash; + res; relu.  w_transposed: w is [K,N] and the product is x w (the input gradient of a Linear)."""
+    counter hash; + res; relu.  w_transposed: w is [K,N] and the product is x w (the input gradient of a Linear).
+    x_img: x as pre-split images (the pre-split product: split-bf16 only); want_img: also return y as images -> (y, y_img)."""
     if _PREC["gemm"] != F32:
-        x = _pad_cols(x)
+        if x_img is None:
+            x = _pad_cols(x)
         M, K = x.shape
         N = w.shape[1] if w_transposed else w.shape[0]
         wimg, ldw = _pack_linear(w, w_transposed)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        y_img = new_images(M, N, x.device) if want_img else None
         splits = 0
-        if M <= 128 and K >= 4096:
-            splits = min(64, K // 1024)
-        elif K >= 1024:
-            # few output tiles and a deep K (the FFN's second product and the first one's input gradient at 16 clips: 544 x 512 x 2048 = 72 tiles
-            # on 256 CUs, 64 serial K-steps, 29.7 us): split K until ~256 workgroups exist, fold with the epilogue pass
-            tiles = ((M + 63) // 64) * ((N + 63) // 64)
-            if tiles <= 96:
-                splits = min(K // 512, max(2, 256 // tiles))
-        return _linear_ex(x, K, wimg, ldw, bias, res, y, M, N, K, relu, _PREC["gemm"], gate, drop, splits)
+        if x_img is None and y_img is None:
+            if M <= 128 and K >= 4096:
+                splits = min(64, K // 1024)
+            elif K >= 1024:
+                # few output tiles and a deep K (the FFN's second product and the first one's input gradient at 16 clips: 544 x 512 x 2048 = 72 tiles
+                # on 256 CUs, 64 serial K-steps, 29.7 us): split K until ~256 workgroups exist, fold with the epilogue pass
+                tiles = ((M + 63) // 64) * ((N + 63) // 64)
+                if tiles <= 96:
+                    splits = min(K // 512, max(2, 256 // tiles))
+        _linear_ex(x, K, wimg, ldw, bias, res, y, M, N, K, relu, _PREC["gemm"], gate, drop, splits, x_img, y_img)
+        return (y, y_img) if want_img else y
     if w_transposed:
         w = raw_transpose(w)
     x, w = _pad_cols(x), _pad_cols(w)
@@ -225,7 +258,14 @@ def raw_linear(x, w, bias=None, relu=False, res=None, w_transposed=False, gate=N
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     splits = min(64, K // 1024) if (M <= 128 and K >= 4096) else 0      # short and deep (emotion_classifer_header.0: K = frames * d_model)
-    return _linear_ex(x, K, w, K, bias, res, y, M, N, K, relu, F32, gate, drop, splits)
+    _linear_ex(x, K, w, K, bias, res, y, M, N, K, relu, F32, gate, drop, splits)
+    return (y, None) if want_img else y
+
+
+def raw_linear_img(x, w, bias=None, relu=False, res=None, w_transposed=False, gate=None, drop=None, x_img=None, want_img=False):
+    """raw_linear that ALWAYS returns (y, images of y or None)."""
+    out = raw_linear(x, w, bias, relu, res, w_transposed, gate, drop, x_img, want_img)
+    return out if want_img else (out, None)
 
 
 def raw_transpose(x):
@@ -339,7 +379,11 @@ class _Fork(torch.autograd.Function):
 
 def fork(x):
     """Two uses of one tensor; the backward sums the two gradients on the HIP elementwise kernel (not torch's accumulate)."""
-    return _Fork.apply(x)
+    a, b = _Fork.apply(x)
+    img = images_of(x)
+    if img is not None:             # both uses may read the row through the producer's images
+        a._eg_img = b._eg_img = img
+    return a, b
 
 
 class _Add(torch.autograd.Function):
@@ -983,24 +1027,28 @@ def raw_wgrad(x, dy, dw, db=None):
     return dw, db
 
 
-def _ln_forward(x2, g, b, eps):
+def _ln_forward(x2, g, b, eps, want_img=False):
+    """-> (y, images of y or None).  The images feed the next block's first product (presplit_ok decides)."""
     y = torch.empty_like(x2)
-    L.check(_lib().eg_layernorm(_ptr(x2), _ptr(g), _ptr(b), _ptr(y), x2.shape[0], x2.shape[1], float(eps), _stream(x2.device)), "eg_layernorm")
-    return y
+    img = new_images(x2.shape[0], x2.shape[1], x2.device) if (want_img and presplit_ok(x2.shape[0], x2.shape[1])) else None
+    L.check(_lib().eg_layernorm_img(_ptr(x2), _ptr(g), _ptr(b), _ptr(y), _ptr(img), x2.shape[0], x2.shape[1], float(eps), _stream(x2.device)), "eg_layernorm")
+    return y, img
 
 
-def _ln_backward_ex(pre, dy2, g, eps, site, g_param, b_param):
-    """-> (d pre, d pre through the Dropout `site` (the same tensor when the site is off), dgamma, dbeta): eg_layernorm_backward_ex."""
+def _ln_backward_ex(pre, dy2, g, eps, site, g_param, b_param, want_img=False):
+    """-> (d pre, d pre through the Dropout `site` (the same tensor when the site is off), dgamma, dbeta, images of the branch gradient or None):
+    eg_layernorm_backward_ex."""
     lib = _lib()
     rows, D = pre.shape
     dpre = torch.empty_like(pre)
     dbr = torch.empty_like(pre) if site is not None else None
     dg, db = grad_out(g_param), grad_out(b_param)
     ws = _scratch(pre.device, int(lib.eg_layernorm_backward_ex_workspace_floats(rows, D)), "lnx")
+    img = new_images(rows, D, pre.device) if (want_img and presplit_ok(rows, D)) else None
     p, seed, off, ep = site if site is not None else (0.0, 0, 0, None)
     L.check(lib.eg_layernorm_backward_ex(_ptr(pre), _ptr(dy2), _ptr(g), _ptr(dpre), _ptr(dbr), _ptr(dg), _ptr(db), rows, D, float(eps), float(p), int(seed),
-                                         int(off), _ptr(ep), _ptr(ws), _stream(pre.device)), "eg_layernorm_backward_ex")
-    return dpre, (dbr if dbr is not None else dpre), dg, db
+                                         int(off), _ptr(ep), _ptr(ws), _ptr(img), _stream(pre.device)), "eg_layernorm_backward_ex")
+    return dpre, (dbr if dbr is not None else dpre), dg, db, img
 
 
 def blocks_fusable(d_model: int) -> bool:
@@ -1011,25 +1059,29 @@ class _MHABlock(torch.autograd.Function):
     """MultiHeadAttention.forward (SubLayers.py:30-59): LN(dropout(fc(attention(q Wq, k Wk, v Wv))) + q) as one node; xkv None = self attention."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, wq, wk, wv, wfc, g, b, heads, p_attn, p_fc, eps):
+    def forward(ctx, xq, xkv, wq, wk, wv, wfc, g, b, heads, p_attn, p_fc, eps, xq_img, xkv_img):
         lib = _lib()
         B, Lq, D = xq.shape
         xq2 = _chk(xq).reshape(B * Lq, D)
         selfa = xkv is None
+        if xq_img is not None and not presplit_ok(B * Lq, D):
+            xq_img = None
         wqd, wkd, wvd, wfd, gd, bd = _chk(wq), _chk(wk), _chk(wv), _chk(wfc), _chk(g), _chk(b)
         dev = xq2.device
         if selfa:
             Lk, xkv2 = Lq, None
             wcat, _ = fused_rows([wqd, wkd, wvd])
-            qkv = raw_linear(xq2, wcat)                                   # [rows, 3D]
+            qkv = raw_linear(xq2, wcat, x_img=xq_img)                     # [rows, 3D]; X through the images the producing LayerNorm emitted
             q, k, v, ldq, ldk = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, 3 * D
             saved_proj = (qkv,)
         else:
             Lk = xkv.shape[1]
             xkv2 = _chk(xkv).reshape(B * Lk, D)
             wcat, _ = fused_rows([wkd, wvd])
-            qb = raw_linear(xq2, wqd)
-            kv = raw_linear(xkv2, wcat)                                   # [rows_k, 2D]
+            if xkv_img is not None and not presplit_ok(B * Lk, D):
+                xkv_img = None
+            qb = raw_linear(xq2, wqd, x_img=xq_img)
+            kv = raw_linear(xkv2, wcat, x_img=xkv_img)                    # [rows_k, 2D]
             q, k, v, ldq, ldk = qb, kv, kv[:, D:], D, 2 * D
             saved_proj = (qb, kv)
         o = torch.empty(B * Lq, D, device=dev)
@@ -1040,14 +1092,18 @@ class _MHABlock(torch.autograd.Function):
                                        float(pa), sa, oa, _ptr(ea), _stream(dev)), "eg_attention_train")
         site_f = drop_site(p_fc, B * Lq * D, xq2)
         pre = raw_linear(o, wfd, res=xq2, drop=site_f)                    # dropout(fc(.)) + residual in the product's epilogue (SubLayers.py:54)
-        y = _ln_forward(pre, gd, bd, eps)
+        y, yimg = _ln_forward(pre, gd, bd, eps, want_img=True)
         ctx.save_for_backward(xq2, xkv2, attn, o, pre, wqd, wkd, wvd, wfd, gd, *saved_proj)
         ctx.cfg = (B, Lq, Lk, D, heads, selfa, site_a, site_f, float(eps), xq.requires_grad, (xkv is not None and xkv.requires_grad))
         ctx.params = (wq, wk, wv, wfc, g, b)
-        return y.view(B, Lq, D)
+        ctx.set_materialize_grads(False)
+        if yimg is None:
+            return y.view(B, Lq, D), None
+        ctx.mark_non_differentiable(yimg)
+        return y.view(B, Lq, D), yimg
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dimg=None):
         lib = _lib()
         xq2, xkv2, attn, o, pre, wq, wk, wv, wfc, g = ctx.saved_tensors[:10]
         proj = ctx.saved_tensors[10:]
@@ -1055,8 +1111,8 @@ class _MHABlock(torch.autograd.Function):
         pq, pk, pv, pfc, pg, pb = ctx.params
         dev = pre.device
         dy2 = _chk(dy).reshape(B * Lq, D)
-        dpre, dfc, dg, db = _ln_backward_ex(pre, dy2, g, eps, site_f, pg, pb)
-        do = raw_linear(dfc, wfc, w_transposed=True)
+        dpre, dfc, dg, db, dfc_img = _ln_backward_ex(pre, dy2, g, eps, site_f, pg, pb, want_img=True)
+        do = raw_linear(dfc, wfc, w_transposed=True, x_img=dfc_img)
         dwfc, _ = raw_wgrad(o, dfc, grad_out(pfc))
         pa, sa, oa, ea = site_a if site_a is not None else (0.0, 0, 0, None)
         if selfa:
@@ -1069,7 +1125,7 @@ class _MHABlock(torch.autograd.Function):
             dx = raw_linear(dqkv, wcat, w_transposed=True, res=dpre) if need_dxq else None      # the residual's gradient rides in the epilogue
             dwm, dws = fused_grad_out((pq, pk, pv), D)
             raw_wgrad(xq2, dqkv, dwm)
-            return (dx.view(B, Lq, D) if dx is not None else None), None, dws[0], dws[1], dws[2], dwfc, dg, db, None, None, None, None
+            return (dx.view(B, Lq, D) if dx is not None else None), None, dws[0], dws[1], dws[2], dwfc, dg, db, None, None, None, None, None, None
         qb, kv = proj
         dq, dkv = torch.empty_like(qb), torch.empty_like(kv)
         L.check(lib.eg_attention_backward_train(_ptr(qb), D, kv.data_ptr(), 2 * D, kv[:, D:].data_ptr(), 2 * D, _ptr(attn), _ptr(do), D, _ptr(dq), D,
@@ -1082,49 +1138,66 @@ class _MHABlock(torch.autograd.Function):
         dwm, dws = fused_grad_out((pk, pv), D)
         raw_wgrad(xkv2, dkv, dwm)
         return ((dxq.view(B, Lq, D) if dxq is not None else None), (dxkv.view(B, Lk, D) if dxkv is not None else None), dwq, dws[0], dws[1], dwfc, dg, db,
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def mha_block(m, xq, xkv=None, p_attn=0.0, p_fc=0.0):
     """m: a MultiHeadAttention parameter holder.  xkv None: self attention (k = v = q = xq); else k = v = xkv."""
-    return _MHABlock.apply(xq, xkv, m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.fc.weight, m.layer_norm.weight, m.layer_norm.bias, m.n_head,
-                           float(p_attn), float(p_fc), m.layer_norm.eps)
+    y, yimg = _MHABlock.apply(xq, xkv, m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.fc.weight, m.layer_norm.weight, m.layer_norm.bias, m.n_head,
+                              float(p_attn), float(p_fc), m.layer_norm.eps, images_of(xq), images_of(xkv) if xkv is not None else None)
+    if yimg is not None:
+        y._eg_img = yimg            # the consumer's first product reads the row through these images (large batches, split-bf16)
+    return y
 
 
 class _FFNBlock(torch.autograd.Function):
     """PositionwiseFeedForward.forward (SubLayers.py:74-84): LN(dropout(w_2(relu(w_1 x))) + x) as one node: 3 launches forward, 6 backward."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, g, b, p_drop, eps):
+    def forward(ctx, x, w1, b1, w2, b2, g, b, p_drop, eps, x_img):
         xs = x.shape
         D = xs[-1]
         x2 = _chk(x).reshape(-1, D)
         w1d, b1d, w2d, b2d, gd, bd = _chk(w1), _chk(b1), _chk(w2), _chk(b2), _chk(g), _chk(b)
-        h = raw_linear(x2, w1d, b1d, relu=True)
+        chain = x_img is not None and presplit_ok(x2.shape[0], D) and presplit_ok(x2.shape[0], w1d.shape[0])
+        # large batches, split-bf16: x arrives as images (from the producing LayerNorm), the hidden leaves its product as fp32 (the backward's gate and
+        # weight gradient read it) AND as images for w_2
+        h, h_img = raw_linear_img(x2, w1d, b1d, relu=True, x_img=x_img if chain else None, want_img=chain)
         site = drop_site(p_drop, x2.numel(), x2)
-        pre = raw_linear(h, w2d, b2d, res=x2, drop=site)                  # x = self.dropout(x); x += residual (SubLayers.py:79)
-        y = _ln_forward(pre, gd, bd, eps)
+        pre = raw_linear(h, w2d, b2d, res=x2, drop=site, x_img=h_img)     # x = self.dropout(x); x += residual (SubLayers.py:79)
+        y, yimg = _ln_forward(pre, gd, bd, eps, want_img=True)
         ctx.save_for_backward(x2, h, pre, w1d, w2d, gd)
         ctx.cfg = (xs, site, float(eps), x.requires_grad)
         ctx.params = (w1, b1, w2, b2, g, b)
-        return y.view(xs)
+        ctx.set_materialize_grads(False)
+        if yimg is None:
+            return y.view(xs), None
+        ctx.mark_non_differentiable(yimg)
+        return y.view(xs), yimg
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dimg=None):
         x2, h, pre, w1, w2, g = ctx.saved_tensors
         xs, site, eps, need_dx = ctx.cfg
         p1, pb1, p2, pb2, pg, pb = ctx.params
         dy2 = _chk(dy).reshape(-1, xs[-1])
-        dpre, dff, dg, db = _ln_backward_ex(pre, dy2, g, eps, site, pg, pb)
-        dh = raw_linear(dff, w2, w_transposed=True, gate=h)               # ReLU backward as the epilogue gate
+        rows = x2.shape[0]
+        chain = presplit_ok(rows, xs[-1]) and presplit_ok(rows, h.shape[1])
+        dpre, dff, dg, db, dff_img = _ln_backward_ex(pre, dy2, g, eps, site, pg, pb, want_img=chain)
+        # ReLU backward as the epilogue gate; the gated gradient as fp32 (for dW_1) and as images (for the next input-gradient product)
+        dh, dh_img = raw_linear_img(dff, w2, w_transposed=True, gate=h, x_img=dff_img, want_img=chain and need_dx)
         dw2, db2 = raw_wgrad(h, dff, grad_out(p2), grad_out(pb2))
-        dx = raw_linear(dh, w1, w_transposed=True, res=dpre) if need_dx else None     # + the residual's gradient
+        dx = raw_linear(dh, w1, w_transposed=True, res=dpre, x_img=dh_img) if need_dx else None     # + the residual's gradient
         dw1, db1 = raw_wgrad(x2, dh, grad_out(p1), grad_out(pb1))
-        return (dx.view(xs) if dx is not None else None), dw1, db1, dw2, db2, dg, db, None, None
+        return (dx.view(xs) if dx is not None else None), dw1, db1, dw2, db2, dg, db, None, None, None
 
 
 def ffn_block(f, x, p_drop=0.0):
-    return _FFNBlock.apply(x, f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias, f.layer_norm.weight, f.layer_norm.bias, float(p_drop), f.layer_norm.eps)
+    y, yimg = _FFNBlock.apply(x, f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias, f.layer_norm.weight, f.layer_norm.bias, float(p_drop), f.layer_norm.eps,
+                              images_of(x))
+    if yimg is not None:
+        y._eg_img = yimg
+    return y
 
 
 class _LinearChain(torch.autograd.Function):
@@ -1133,18 +1206,22 @@ class _LinearChain(torch.autograd.Function):
     backward -- no elementwise launch either way."""
 
     @staticmethod
-    def forward(ctx, x, relu_between, drop_p, n_layers, *wb):
+    def forward(ctx, x, relu_between, drop_p, n_layers, x_img, *wb):
         xs = x.shape
         h = _chk(x).reshape(-1, xs[-1])
         ws = [_chk(wb[2 * i]) for i in range(n_layers)]
         bs = [(_chk(wb[2 * i + 1]) if wb[2 * i + 1] is not None else None) for i in range(n_layers)]
         ins, sites = [], []
+        rows = h.shape[0]
+        img = x_img if (x_img is not None and presplit_ok(rows, h.shape[1])) else None
         for i in range(n_layers):
             last = i + 1 == n_layers
             ins.append(h)
             site = drop_site(drop_p, h.shape[0] * ws[i].shape[0], h) if (drop_p > 0.0 and not last) else None
             sites.append(site)
-            h = raw_linear(h, ws[i], bs[i], relu=relu_between and not last, drop=site)
+            # large batches, split-bf16: a layer whose output width suits (a multiple of 64) hands it to the next one as images
+            want = (not last) and presplit_ok(rows, ws[i].shape[0]) and ws[i].shape[0] == ws[i + 1].shape[1]
+            h, img = raw_linear_img(h, ws[i], bs[i], relu=relu_between and not last, drop=site, x_img=img, want_img=want)
         ctx.save_for_backward(*ins, *ws)
         ctx.cfg = (xs, n_layers, bool(relu_between), sites, x.requires_grad)
         ctx.params = wb
@@ -1156,6 +1233,7 @@ class _LinearChain(torch.autograd.Function):
         ins, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         g = _chk(dy).reshape(-1, ws[-1].shape[0])
         grads = [None] * (2 * n)
+        rows, gimg = g.shape[0], None
         for i in range(n - 1, -1, -1):
             pw, pbias = ctx.params[2 * i], ctx.params[2 * i + 1]
             same = ins[i].shape[1] == ws[i].shape[1]
@@ -1166,11 +1244,16 @@ class _LinearChain(torch.autograd.Function):
             if i > 0 or need_dx:
                 # the masks of the boundary in FRONT of layer i (ReLU by its saved output = this layer's input; Dropout from that site's scalars)
                 gate = ins[i] if (relu_between and i > 0) else None
-                g = raw_linear(g, ws[i], w_transposed=True, gate=gate, drop=sites[i - 1] if i > 0 else None)
+                # the gradient continues as images when the next input-gradient product (layer i-1's) can take them
+                want = i > 0 and (i > 1 or need_dx) and presplit_ok(rows, ws[i].shape[1]) and presplit_ok(rows, ws[i - 1].shape[0]) and \
+                    ws[i].shape[1] == ws[i - 1].shape[0]
+                use = gimg if (gimg is not None and presplit_ok(rows, g.shape[1])) else None
+                g, gimg = raw_linear_img(g, ws[i], w_transposed=True, gate=gate, drop=sites[i - 1] if i > 0 else None, x_img=use, want_img=want)
                 if g.shape[1] != (ins[i].shape[1]):
                     g = g[:, :ins[i].shape[1]]
+                    gimg = None
         dx = g.reshape(xs) if need_dx else None
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
 def linear_chain(x, layers, relu_between=False, drop_p=0.0):
@@ -1178,7 +1261,7 @@ def linear_chain(x, layers, relu_between=False, drop_p=0.0):
     wb = []
     for lin in layers:
         wb += [lin.weight, lin.bias]
-    return _LinearChain.apply(x, bool(relu_between), float(drop_p), len(layers), *wb)
+    return _LinearChain.apply(x, bool(relu_between), float(drop_p), len(layers), images_of(x), *wb)
 
 
 class _Conv1dCL(torch.autograd.Function):

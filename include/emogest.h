@@ -316,9 +316,13 @@ typedef struct EgLinearArgs {
     const float* gate_src;          /* [M, ldg] or NULL */
     const int32_t* drop_epoch;      /* device-resident step counter or NULL (eg_dropout_dev) */
     float* partial;                 /* split-K scratch or NULL */
+    const void* x_images;           /* NULL, or X as bf16 (hi, lo) tile-planar images of width k_x (eg_split_tiles layout; then x is ignored): the
+                                       pre-split product of eg_linear_presplit with this epilogue */
+    void* y_images;                 /* NULL, or a second output: Y as images of width y_k for the next product (written beside y) */
     uint64_t drop_offset;
     int32_t lda, ldw, ldr, ldc, ldg;
     int32_t m, n, k, relu, precision, splits;
+    int32_t k_x, y_k;
     uint32_t drop_seed;
     float drop_p;
 } EgLinearArgs;
@@ -327,6 +331,10 @@ int eg_linear_ex(const EgLinearArgs* args, void* stream);
 /* nn.LayerNorm(D, eps) over the last axis (Full_model/SubLayers.py:55-57,80-82).  rows x D, D%4==0, D<=2048. */
 int eg_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t d,
                  float eps, void* stream);
+/* The same with a second output: y as bf16 (hi, lo) tile-planar images [ceil(rows/64)][d/8][64][8] (eg_split_tiles layout, d % 64 == 0) for the
+ * pre-split product that consumes the row next (y_images may be NULL). */
+int eg_layernorm_img(const float* x, const float* gamma, const float* beta, float* y, void* y_images, int32_t rows, int32_t d, float eps,
+                     void* stream);
 
 /* ScaledDotProductAttention (Full_model/Modules.py:13-23) for all heads, mask=None, eval mode:
  * out[b,i,h*dv:(h+1)*dv] = softmax_j((q[b,i,h]/sqrt(dk)) . k[b,j,h]) v[b,j,h].
@@ -540,7 +548,8 @@ int eg_layernorm_backward(const float* x, const float* dy, const float* gamma, f
 int64_t eg_layernorm_backward_ex_workspace_floats(int32_t rows, int32_t d);
 int eg_layernorm_backward_ex(const float* x, const float* dy, const float* gamma, float* dx, float* dx_dropped, float* dgamma, float* dbeta,
                              int32_t rows, int32_t d, float eps, float drop_p, uint32_t drop_seed, uint64_t drop_offset, const int32_t* epoch_dev,
-                             float* workspace, void* stream);
+                             float* workspace, void* branch_images, void* stream);      /* branch_images (may be NULL): the gradient that enters the
+                             Dropout'ed branch (dx_dropped, or dx when drop_p == 0) also as bf16 (hi, lo) images for a pre-split input-gradient product */
 /* ScaledDotProductAttention backward (Modules.py:13-23) from the forward's probabilities; Lq, Lk <= 64-ish (LDS-resident) */
 int eg_attention_backward(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* attn,
                           const float* dout, int32_t ldo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
