@@ -1160,6 +1160,7 @@ int conv3x3_dispatch(const float* x, const float* w, const float* bias, const fl
     if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2, 2, 2>(a, batch, precision, st);
     if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 64 && coutp == 128 && stride == 2) return launch_conv<64, 8, 2, 2, 2, 2>(a, batch, precision, st);
+    if (cin == 64 && coutp == 128 && stride == 1) return launch_conv<64, 8, 1, 4, 2, 2>(a, batch, precision, st);      // training: input gradient of final_conv1 (dy padded to 64 channels)
     if (cin == 128 && coutp == 128 && stride == 1) return launch_conv<128, 8, 1, 4, 2, 2>(a, batch, precision, st);
     // 256-channel stage of the audio emotion classifier (model/audio_emotion_classifer.py:20-22): 2-row tiles, waves split the channels
     if (cin == 128 && coutp == 256 && stride == 2) return launch_conv<128, 16, 2, 2, 1, 4>(a, batch, precision, st);

@@ -650,6 +650,18 @@ class _Conv3x3(torch.autograd.Function):
             L.check(lib.eg_conv3x3_se(_ptr(dyd), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"],
                                       _stream(dev)), "eg_conv3x3 (dgrad)")
             dres = None
+        elif ctx.need_dx and _PREC["conv"] != F32 and ctx.stride == 1 and Ci == 128 and Co <= 64 and Co % 4 == 0 and PAD_WGRAD:
+            # final_conv1 (128 -> frames): the same rotated-filter convolution on dy and the filter zero-padded to 64 output channels, instead of
+            # the [pixels, 9 * 128] column product + col2im (585 MB written and re-read per 128-clip step)
+            dyp = _pad_cols(dy2, 64).view(B, Ho, Wo, 64)
+            wpad = torch.zeros(64, Ci, 3, 3, dtype=torch.float32, device=dev)
+            wpad[:Co].copy_(w)
+            wp = _pack_conv(wpad, flip=True)
+            dx = torch.empty_like(x)
+            res = _chk(dres) if dres is not None else None
+            L.check(lib.eg_conv3x3_se(_ptr(dyp), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, 64, Ci, 1, 0, 0, _PREC["conv"],
+                                      _stream(dev)), "eg_conv3x3 (dgrad, padded)")
+            dres = None
         elif ctx.need_dx:
             wmat_t = w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()   # [(kh,kw,ci), co] = Wmat^T
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
