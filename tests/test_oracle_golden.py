@@ -211,3 +211,32 @@ def test_attention_mask_oracle_matches_reference_golden():
         assert rel_l2(y.numpy()[:, :, ::4], z[f"{name}/out"]) < 2e-6
         np.testing.assert_allclose(attn.numpy()[:, ::4], z[f"{name}/attn"], atol=2e-7)
     assert abs(float(z["pad/attn"][2].max()) - 1.0 / 40) < 1e-7          # every key masked: uniform over all 40
+
+
+def test_mel_oracle_filterbank_and_db_cross_checked_against_transformers_audio_utils():
+    """The other half of the mel front-end's pin (the Slaney filterbank and power_to_db were single-sourced).  librosa is not in
+    the image, but `transformers.audio_utils` carries an independent implementation written to reproduce librosa: `mel_filter_bank(norm="slaney",
+    mel_scale="slaney")` and `spectrogram(center=True, pad_mode="constant", power=2) -> power_to_db(reference=max, db_range=80)`.  The oracle's
+    filterbank equals it to 1e-8, and the whole pipeline (STFT framing, window, power, mel, dB, fp16) gives the same fp16 image on random audio,
+    silence-padded audio and a loud / quiet pair."""
+    A = pytest.importorskip("transformers.audio_utils")
+    from oracle import emogest_oracle as O
+    fb = A.mel_filter_bank(num_frequency_bins=513, num_mel_filters=128, min_frequency=0.0, max_frequency=8000.0, sampling_rate=16000,
+                           norm="slaney", mel_scale="slaney")
+    mine = O.mel_filterbank(16000, 1024, 128)
+    assert fb.T.shape == mine.shape and float(np.abs(fb.T - mine).max()) < 1e-8 and float(np.abs(mine).max()) > 0.01
+    rng = np.random.RandomState(3)
+    audio = (rng.randn(3, 64000) * 0.1).astype(np.float32)
+    audio[1, 30000:] = 0.0                      # trailing silence: the top_db floor decides most bins
+    audio[2] *= 1e-3                            # a quiet clip: ref = its own maximum
+    win = A.window_function(1024, "hann", periodic=True)
+    want = []
+    for a in audio:
+        s = A.spectrogram(a.astype(np.float64), win, frame_length=1024, hop_length=512, fft_length=1024, power=2.0, center=True, pad_mode="constant",
+                          mel_filters=fb, mel_floor=0.0, dtype=np.float64)
+        want.append(A.power_to_db(s, reference=float(s.max()), min_value=1e-10, db_range=80.0))
+    want = np.stack(want).astype(np.float16).astype(np.float32)
+    got = O.melspectrogram(audio)
+    assert got.shape == want.shape == (3, 128, 126)
+    diff = got != want
+    assert diff.mean() < 1e-3 and float(np.abs(got - want).max()) <= 0.0625          # at most a stray fp16 ulp near 64 dB (measured: identical)
