@@ -819,6 +819,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         cap = 400 * max(args.steps, 1)
         gen.concurrent = False                  # per-launch durations are only meaningful without overlapping side streams
+        gen.shared_chip = lanes > 1             # the tile policy of the TIMED configuration (other legs' pipelines reset the hint on the shared model)
         eager_step = make_step(gen, vae, mel, None)
         for _ in range(3):                      # warm: clocks up, kernels / weights resident, before per-launch events are taken
             eager_step()
@@ -856,7 +857,7 @@ def main():
                 # the step as it is run -- four batches in flight, the rest of the chip busy with other lanes' kernels -- and its rate per occupied CU share
                 "kernel_cu_ms_per_step": round(cu_ms / args.steps, 4), "mean_workgroups_per_launch": round(float(wgs[seld].mean()), 1),
                 "achieved_per_occupied_share": round(float(fl[seld].sum()) / (cu_ms * 1e-3) / 1e12, 2) if cu_ms > 0 else None,
-                "tile_policy": os.environ.get("EG_GEMM_TILE", "auto (128 x 128 from 64 workgroups up, else 64 x 64)"),
+                "tile_policy": os.environ.get("EG_GEMM_TILE", "auto: the caller's shared-chip hint (several batches in flight) -> 128 x 128 from 64 workgroups up; stand-alone 64 x 64"),
                 "flop_per_launch": flop,
                 "by_kernel_ms_per_step": {kernel_name(k): round(v[0] / args.steps, 4) for k, v in sorted(groups.items())},
                 "by_kernel_tflops": {kernel_name(k): round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in sorted(contraction.items())}}

@@ -29,6 +29,9 @@ struct ConvArgs {
     // fused SE tail (SEBasicBlock.forward, ResNetBlocks.py:28-36, identity shortcut): v = relu(v * gate[b, co] + res[pixel, co])
     // applied after the BatchNorm affine; gate comes from se_gate_pre_kernel (computed BEFORE this convolution runs)
     const float* gate = nullptr; const float* res = nullptr; int relu2 = 0;
+    // training: a per-INPUT-channel affine applied while the halo tile is staged (the BatchNorm in front of this convolution folded into its operand
+    // staging: x' = x * in_scale[ci] + in_shift[ci] for pixels inside the image, zero padding stays zero) -- split-bf16 kernels only
+    const float* in_scale = nullptr; const float* in_shift = nullptr;
     unsigned int* dbg = nullptr;        // diagnostic build only (EG_CONV32_STAMP=1): per-wave phase cycle sums of the persistent 32->32 kernel
 };
 
@@ -309,10 +312,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
             }
         }
     };
-    auto store_tile = [&]() {
+    const int oc8s = ((tid >> 3) & 3) * 8;          // this thread's channel octet inside a 32-channel chunk (the same for all its iterations)
+    auto store_tile = [&](int chunk) {
+        f4 s0 = (f4){1.f, 1.f, 1.f, 1.f}, s1 = s0, h0 = (f4){0.f, 0.f, 0.f, 0.f}, h1 = h0;
+        if (a.in_scale) {
+            s0 = *reinterpret_cast<const f4*>(a.in_scale + chunk * 32 + oc8s); s1 = *reinterpret_cast<const f4*>(a.in_scale + chunk * 32 + oc8s + 4);
+            h0 = *reinterpret_cast<const f4*>(a.in_shift + chunk * 32 + oc8s); h1 = *reinterpret_cast<const f4*>(a.in_shift + chunk * 32 + oc8s + 4);
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (lslot[it] >= 0) {
+                if (a.in_scale && goff[it] >= 0) {          // inside the image only: the zero padding of the normalised map stays zero
+                    pv[it][0] = pv[it][0] * s0 + h0;
+                    pv[it][1] = pv[it][1] * s1 + h1;
+                }
                 bf8 hi, lo;
                 split_octet<TERMS == 3>(pv[it][0], pv[it][1], hi, lo);
                 tile[lslot[it]] = hi;
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     Frags fr[2];
 #pragma unroll 1
     for (int chunk = 0; chunk < CIN / 32; ++chunk) {
-        store_tile();                           // the tile is free: its last reads completed before the barrier of the previous tap 8
+        store_tile(chunk);                      // the tile is free: its last reads completed before the barrier of the previous tap 8
         if (COUNTED && chunk > 0) {              // W of this chunk's tap 0 landed at that barrier too; only W of tap 1 is in flight
             wait_vmcnt_imm<GW>();
             wait_lgkmcnt0();                    // tile writes visible
@@ -549,6 +562,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
         lslot[it] = p < NPIX ? oc * PL + p : -1;
     }
     const int oc8 = ((tid >> 3) & 3) * 8;
+    f4 isc[2] = {(f4){1.f, 1.f, 1.f, 1.f}, (f4){1.f, 1.f, 1.f, 1.f}}, ish[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+    if (a.in_scale) {
+        isc[0] = *reinterpret_cast<const f4*>(a.in_scale + oc8); isc[1] = *reinterpret_cast<const f4*>(a.in_scale + oc8 + 4);
+        ish[0] = *reinterpret_cast<const f4*>(a.in_shift + oc8); ish[1] = *reinterpret_cast<const f4*>(a.in_shift + oc8 + 4);
+    }
     f4 pv[NIT][2];
     // tile coordinates advance incrementally along the walk (an integer division per use costs ~30 VALU instructions; this kernel
     // issues 4 non-MFMA VALU instructions per MFMA as it is: profiles/r02k_pmc_conv32_persistent.txt)
@@ -574,6 +592,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
                 const float* src = xb + (gy * a.W + gx) * CIN + oc8;
                 pv[it][0] = *reinterpret_cast<const f4*>(src);
                 pv[it][1] = *reinterpret_cast<const f4*>(src + 4);
+                if (a.in_scale) {                   // the BatchNorm in front of this convolution, folded into the staging (in-image pixels only)
+                    pv[it][0] = pv[it][0] * isc[0] + ish[0];
+                    pv[it][1] = pv[it][1] * isc[1] + ish[1];
+                }
             }
         }
     };
@@ -1343,8 +1365,8 @@ int launch_conv32_persistent(const ConvArgs& a, int batch, int precision, int th
     {   // A/B switch, read per call (a captured graph keeps what it was captured with): teams of 4 waves sharing one weight copy
         const char* e = getenv("EG_CONV32_TEAMS");
         const int teams = (e && e[0]) ? atoi(e) : 0;
-        if (th == 4 && precision == EG_PREC_BF16X3 && teams == 2) return launch_conv32_teams_t<3, 2>(a, batch, whi, wlo, st);
-        if (th == 4 && precision == EG_PREC_BF16X3 && teams == 3) return launch_conv32_teams_t<3, 3>(a, batch, whi, wlo, st);
+        if (th == 4 && precision == EG_PREC_BF16X3 && teams == 2 && !a.in_scale) return launch_conv32_teams_t<3, 2>(a, batch, whi, wlo, st);
+        if (th == 4 && precision == EG_PREC_BF16X3 && teams == 3 && !a.in_scale) return launch_conv32_teams_t<3, 3>(a, batch, whi, wlo, st);
     }
     static const bool stamp = [] { const char* e = getenv("EG_CONV32_STAMP"); return e && e[0] == '1'; }();
     if (stamp && precision == EG_PREC_BF16X3 && th == 4) {
@@ -1417,7 +1439,7 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
 namespace {
 int conv3x3_dispatch(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate, const float* residual,
                      float* y, float* gap_partial, float* gap_sq, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
-                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
+                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream, const float* in_scale = nullptr, const float* in_shift = nullptr);
 }
 extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate,
                              const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin,
@@ -1435,11 +1457,23 @@ extern "C" int eg_conv3x3_sq(const float* x, const float* w, const float* bias, 
     return conv3x3_dispatch(x, w, bias, nullptr, nullptr, nullptr, nullptr, y, gap_partial, gap_sq_partial, batch, h, wdt, cin, cout, stride, relu, 0, precision,
                             stream);
 }
+// eg_conv3x3_sq on x' = x * in_scale[ci] + in_shift[ci] (per INPUT channel, in-image pixels; the zero padding stays zero): the train-mode BatchNorm in
+// front of the convolution folded into its operand staging, so that the normalised map is never written (ResNetBlocks.py:26-27: bn1 -> conv2).
+extern "C" int eg_conv3x3_sq_in_affine(const float* x, const float* in_scale, const float* in_shift, const float* w, const float* bias, float* y,
+                                       float* gap_partial, float* gap_sq_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
+                                       int32_t stride, int32_t relu, int32_t precision, void* stream) {
+    EG_REQUIRE(in_scale && in_shift, EG_ERR_BAD_ARG, "eg_conv3x3_sq_in_affine: both affine vectors are required");
+    EG_REQUIRE(!gap_partial == !gap_sq_partial, EG_ERR_BAD_ARG, "eg_conv3x3_sq_in_affine: both partial buffers or none");
+    return conv3x3_dispatch(x, w, bias, nullptr, nullptr, nullptr, nullptr, y, gap_partial, gap_sq_partial, batch, h, wdt, cin, cout, stride, relu, 0, precision,
+                            stream, in_scale, in_shift);
+}
 namespace {
 int conv3x3_dispatch(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate, const float* residual,
                      float* y, float* gap_partial, float* gap_sq, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
-                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
+                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream, const float* in_scale, const float* in_shift) {
     EG_REQUIRE(x && w && y && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3: null pointer or empty shape");
+    EG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!in_scale || (precision != EG_PREC_F32 && cin % 32 == 0 && eg_aligned16(in_scale) &&
+               eg_aligned16(in_shift))), EG_ERR_BAD_ARG, "eg_conv3x3: the input affine needs both vectors, a split-bf16 mode and cin %% 32 == 0");
     // gate + residual: relu(v * gate + residual) (the fused SE tail); residual alone: v + residual, no ReLU (the training path's fused fan-in add:
     // an input gradient that lands on a tensor with a second consumer, train/functional.py conv3x3(passthrough=True))
     EG_REQUIRE(!gate || residual, EG_ERR_BAD_ARG, "eg_conv3x3_se: a gate needs a residual");
@@ -1452,6 +1486,7 @@ int conv3x3_dispatch(const float* x, const float* w, const float* bias, const fl
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.gap = gap_partial; a.gap2 = gap_sq;
     a.gate = gate; a.res = residual; a.relu2 = gate ? 1 : 0;
+    a.in_scale = in_scale; a.in_shift = in_shift;
     a.H = h; a.W = wdt; a.Ho = (h + 2 - 3) / stride + 1; a.Wo = (wdt + 2 - 3) / stride + 1;
     a.cout = cout; a.relu = relu; a.nchw = nchw_out;
     const int th = conv_tile_rows(cin, cout, stride);

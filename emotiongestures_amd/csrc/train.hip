@@ -596,7 +596,9 @@ __global__ __launch_bounds__(256) void clip_sums_sq_kernel(const float* __restri
 }
 __global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __restrict__ clip_d, int B, int C, long rows, float eps, float momentum,
                                                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                                             float* __restrict__ run_var) {
+                                                             float* __restrict__ run_var, const float* __restrict__ gamma = nullptr,
+                                                             const float* __restrict__ beta = nullptr, float* __restrict__ aff_scale = nullptr,
+                                                             float* __restrict__ aff_shift = nullptr) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
@@ -609,6 +611,10 @@ __global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __res
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (aff_scale) {            // the apply y = (x - mean) * rstd * gamma + beta as one multiply-add per element, exactly as bn_apply rounds it: see below
+        aff_scale[c] = rstd[c] * gamma[c];
+        aff_shift[c] = beta[c] - mean[c] * (rstd[c] * gamma[c]);
+    }
     if (run_mean) {
         const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
@@ -1582,6 +1588,25 @@ extern "C" int eg_bn_train_forward_sq(const float* x, const float* gap_partial, 
     if (int rc = eg_check_launch("bn_finalize_sq")) return rc;
     if (!y) return EG_OK;
     return launch_bn_apply(x, save_mean, save_rstd, gamma, beta, y, rows, c, ST);
+}
+
+// Train-mode BatchNorm statistics only, from the producing convolution's partials, plus the apply folded to one affine per channel
+// (aff_scale = gamma * rstd, aff_shift = beta - mean * aff_scale) for the consumer that applies it while staging its operand (eg_conv3x3_sq_in_affine,
+// eg_conv3x3_wgrad_mfma_oihw_in_affine): the normalised map is never written.  Running statistics updated as eg_bn_train_forward_sq does.
+extern "C" int eg_bn_train_stats_sq(const float* gap_partial, const float* gap_sq_partial, int32_t tiles, int32_t batch, const float* gamma, const float* beta,
+                                    float* save_mean, float* save_rstd, float* running_mean, float* running_var, float* aff_scale, float* aff_shift,
+                                    int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream) {
+    EG_REQUIRE(gap_partial && gap_sq_partial && gamma && beta && save_mean && save_rstd && aff_scale && aff_shift && workspace && rows > 0 && batch > 0 && tiles > 0,
+               EG_ERR_BAD_ARG, "eg_bn_train_stats_sq: bad argument");
+    EG_REQUIRE(c > 0 && c <= 256 && 256 % c == 0, EG_ERR_UNSUPPORTED, "eg_bn_train_stats_sq: C=%d (a divisor of 256)", c);
+    EG_REQUIRE((int64_t)4 * batch * c <= eg_colreduce_workspace_floats(c) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EG_ERR_WORKSPACE,
+               "eg_bn_train_stats_sq: batch %d does not fit the reduction workspace", batch);
+    double* clip_d = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(clip_sums_sq_kernel, dim3(batch), dim3(256), 0, ST, gap_partial, gap_sq_partial, tiles, c, (float*)nullptr, clip_d);
+    if (int rc = eg_check_launch("clip_sums_sq")) return rc;
+    hipLaunchKernelGGL(bn_finalize_sq_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, clip_d, batch, c, (long)rows, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var, gamma, beta, aff_scale, aff_shift);
+    return eg_check_launch("bn_finalize_sq");
 }
 
 #define SE_TAIL_SHAPE(who) EG_REQUIRE(batch > 0 && hw > 0 && c >= 8 && c <= 256 && c % 8 == 0, EG_ERR_UNSUPPORTED, who ": C=%d (multiple of 8, <= 256)", c)

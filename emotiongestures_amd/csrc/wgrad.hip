@@ -33,6 +33,7 @@ struct WgradArgs {
     int strips, chunks, R;  // units = B * strips * chunks; chunk = R rows
     int units, upw;         // units per workgroup (consecutive)
     int n_cit, nct;         // channel tiles: nct = (Ci / CI_T) * (Co / CO_T), input tile fastest
+    const float* in_scale = nullptr; const float* in_shift = nullptr;      // x' = x * in_scale[ci] + in_shift[ci] (in-image pixels) while staging: the folded BatchNorm
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -84,6 +85,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(WgradArgs a)
     const int sdw = so * (is_x ? XS : DS) * 4 + (is_x ? sq + 4 : sq);
     const int sjstride = NO * (is_x ? XS : DS) * 4;
 
+    f4 isc0 = (f4){1.f, 1.f, 1.f, 1.f}, isc1 = isc0, ish0 = (f4){0.f, 0.f, 0.f, 0.f}, ish1 = ish0;
+    const bool affine = a.in_scale != nullptr && is_x;
+    if (affine) {
+        isc0 = *reinterpret_cast<const f4*>(a.in_scale + sch); isc1 = *reinterpret_cast<const f4*>(a.in_scale + sch + 4);
+        ish0 = *reinterpret_cast<const f4*>(a.in_shift + sch); ish1 = *reinterpret_cast<const f4*>(a.in_shift + sch + 4);
+    }
     f4 acc[9][NCI][NCO];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -112,6 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(WgradArgs a)
                 const float* p = sp + (size_t)row * a.W * sC;
                 if (v0) { dst[0] = *reinterpret_cast<const f4*>(p); dst[1] = *reinterpret_cast<const f4*>(p + 4); }
                 if (v1) { dst[2] = *reinterpret_cast<const f4*>(p + sC); dst[3] = *reinterpret_cast<const f4*>(p + sC + 4); }
+                if (affine) {               // in-image pixels only: what lies outside stays the zero padding of the normalised map
+                    if (v0) { dst[0] = dst[0] * isc0 + ish0; dst[1] = dst[1] * isc1 + ish1; }
+                    if (v1) { dst[2] = dst[2] * isc0 + ish0; dst[3] = dst[3] * isc1 + ish1; }
+                }
             }
         };
         auto write_stage = [&](const f4 (&src)[4], int j) {
@@ -262,7 +273,7 @@ extern "C" int64_t eg_conv3x3_wgrad_mfma_workspace_floats(int32_t batch, int32_t
 }
 
 namespace { int wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, float* workspace,
-                           int64_t workspace_floats, int oihw, void* stream); }
+                           int64_t workspace_floats, int oihw, void* stream, const float* in_scale = nullptr, const float* in_shift = nullptr); }
 
 // dw_mat [cout][9*cin] ((kh, kw, ci) fastest to slowest as eg_conv3x3_wgrad writes it); stride 1 only, cin % 32 == 0, cout % 32 == 0.
 extern "C" int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
@@ -274,10 +285,16 @@ extern "C" int eg_conv3x3_wgrad_mfma_oihw(const float* x, const float* dy, float
                                           float* workspace, int64_t workspace_floats, void* stream) {
     return wgrad_mfma(x, dy, dw, batch, h, w, cin, cout, workspace, workspace_floats, 1, stream);
 }
+// the same for a convolution whose input was x' = x * in_scale[ci] + in_shift[ci] (eg_conv3x3_sq_in_affine): the affine is re-applied while x is staged
+extern "C" int eg_conv3x3_wgrad_mfma_oihw_in_affine(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dw, int32_t batch,
+                                                    int32_t h, int32_t w, int32_t cin, int32_t cout, float* workspace, int64_t workspace_floats, void* stream) {
+    EG_REQUIRE(in_scale && in_shift && eg_aligned16(in_scale) && eg_aligned16(in_shift), EG_ERR_BAD_ARG, "eg_conv3x3_wgrad_mfma_oihw_in_affine: affine vectors");
+    return wgrad_mfma(x, dy, dw, batch, h, w, cin, cout, workspace, workspace_floats, 1, stream, in_scale, in_shift);
+}
 
 namespace {
 int wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, float* workspace,
-               int64_t workspace_floats, int oihw, void* stream) {
+               int64_t workspace_floats, int oihw, void* stream, const float* in_scale, const float* in_shift) {
     EG_REQUIRE(x && dy && dw_mat && workspace && batch > 0 && h > 0 && w > 0, EG_ERR_BAD_ARG, "eg_conv3x3_wgrad_mfma: null pointer or empty shape");
     EG_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0, EG_ERR_UNSUPPORTED, "eg_conv3x3_wgrad_mfma: channels %d -> %d (multiples of 32)", cin, cout);
     EG_REQUIRE(eg_aligned16(x) && eg_aligned16(dy), EG_ERR_ALIGN, "eg_conv3x3_wgrad_mfma: activations must be 16-byte aligned");
@@ -288,6 +305,7 @@ int wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, in
     WgradArgs a;
     a.x = x; a.dy = dy; a.part = workspace; a.B = batch; a.H = h; a.W = w; a.Ci = cin; a.Co = cout;
     a.strips = p.strips; a.chunks = p.chunks; a.R = p.R; a.units = p.units; a.upw = p.upw; a.n_cit = p.n_cit; a.nct = p.nct;
+    a.in_scale = in_scale; a.in_shift = in_shift;
     EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + 7, 2.0 * 9 * cin * cout * (double)h * w * batch, st);
     const dim3 grid(p.S * p.nct);
     if (p.ci_t == 64) {

@@ -532,10 +532,17 @@ class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(k=3, pad=1, stride s) on NHWC activations; weight OIHW as in the reference's state_dict."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False, passthrough=False):
+    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False, passthrough=False, in_scale=None, in_shift=None):
         lib = _lib()
         ctx.set_materialize_grads(False)            # no zero-filled "gradients" for the non-differentiable pooling partials / an unused alias
         xd, wd = _chk(x, "x"), _chk(w, "weight")
+        ctx.in_affine = None
+        if in_scale is not None:
+            # x is the PRE-normalisation map of a deferred BatchNorm (batch_norm(defer_apply=True)): its per-channel affine is applied while the
+            # convolution (and later its weight-gradient kernel) stages the operand -- the normalised map never exists in memory
+            if not (_PREC["conv"] != F32 and stride == 1 and xd.shape[-1] % 32 == 0 and wd.shape[0] % 32 == 0 and b is None and not relu):
+                raise L.EgError("conv3x3: a deferred BatchNorm in front needs a split-bf16, stride-1, bias-free convolution with channels % 32 == 0")
+            ctx.in_affine = (in_scale, in_shift)
         gap = None
         B, H, W, Ci = xd.shape
         Co = wd.shape[0]
@@ -552,7 +559,15 @@ class _Conv3x3(torch.autograd.Function):
             if Co % 4 == 0:
                 y = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=dev)
                 tiles = int(lib.eg_conv3x3_gap_tiles(H, W, Ci, Co, stride)) if want_gap else 0
-                if want_gap and prec != F32 and 256 % Co == 0:
+                if ctx.in_affine is not None:
+                    if want_gap:
+                        if 256 % Co:
+                            raise L.EgError("conv3x3: a deferred BatchNorm in front needs Cout to divide 256 for the pooling partials")
+                        gap = torch.empty(2, B, tiles, Co, dtype=torch.float32, device=dev)
+                    L.check(lib.eg_conv3x3_sq_in_affine(_ptr(xd), _ptr(in_scale), _ptr(in_shift), _ptr(wp), None, _ptr(y), _ptr(gap),
+                                                        _ptr(gap[1]) if gap is not None else None, B, H, W, Ci, Co, 1, 0, prec, _stream(dev)),
+                            "eg_conv3x3_sq_in_affine")
+                elif want_gap and prec != F32 and 256 % Co == 0:
                     # split-bf16 modes: the epilogue also emits the per-tile sums of squares -- gap is then [2, B, tiles, Co] (plane 0 = the sums every
                     # consumer reads through the base pointer, plane 1 = the squares): train-mode BatchNorm needs no pass over y for its variance
                     gap = torch.empty(2, B, tiles, Co, dtype=torch.float32, device=dev)
@@ -601,7 +616,7 @@ class _Conv3x3(torch.autograd.Function):
         B, H, W, Ci = x.shape
         Co = w.shape[0]
         if dy is None:              # only the alias was used downstream
-            return (_chk(dres) if dres is not None else None), None, None, None, None, None, None, None
+            return (_chk(dres) if dres is not None else None), None, None, None, None, None, None, None, None, None
         dyd = _chk(dy)
         if y is not None:
             dyd = raw_ew(EW_RELU_BWD, dyd, y)
@@ -610,7 +625,12 @@ class _Conv3x3(torch.autograd.Function):
         dy2 = dyd.view(B * Ho * Wo, Co)
         dw = grad_out(ctx.params[0], (Co, Ci, 3, 3))
         dwm = None
-        if _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 32 == 0:       # split-bf16 MFMA weight gradient, written OIHW
+        if ctx.in_affine is not None:   # the deferred BatchNorm's affine re-applied while x is staged (forward checked the shape constraints)
+            need = lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Co)
+            ws = _scratch(dev, need, "wgrad")
+            L.check(lib.eg_conv3x3_wgrad_mfma_oihw_in_affine(_ptr(x), _ptr(ctx.in_affine[0]), _ptr(ctx.in_affine[1]), _ptr(dy2), _ptr(dw), B, H, W, Ci, Co,
+                                                             _ptr(ws), ws.numel(), _stream(dev)), "eg_conv3x3_wgrad_mfma (in-affine)")
+        elif _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 32 == 0:       # split-bf16 MFMA weight gradient, written OIHW
             need = lib.eg_conv3x3_wgrad_mfma_workspace_floats(B, H, W, Ci, Co)                # straight into the flat gradient slice
             ws = _scratch(dev, need, "wgrad")
             L.check(lib.eg_conv3x3_wgrad_mfma_oihw(_ptr(x), _ptr(dy2), _ptr(dw), B, H, W, Ci, Co, _ptr(ws), ws.numel(), _stream(dev)),
@@ -669,13 +689,16 @@ class _Conv3x3(torch.autograd.Function):
             L.check(lib.eg_im2col3x3(_ptr(dcol), _ptr(dx), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_col2im3x3")
         if dres is not None:        # passthrough on a path without the fused epilogue (or no dx wanted): the plain add
             dx = raw_ew(EW_ADD, dx, _chk(dres)) if dx is not None else _chk(dres)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False, passthrough=False):
     """want_gap: also return the per-(clip, tile) channel sums of the output; defer_mask: the ReLU's backward is applied by the consumer;
     passthrough: also return an alias of the input for its second consumer (the residual branch) -- the two gradients are then summed in the
     input-gradient launch's epilogue instead of by a `fork`."""
+    aff = getattr(x_nhwc, "_eg_in_affine", None)        # a deferred BatchNorm produced x: (scale, shift) to apply while staging
+    if aff is not None:
+        return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough, aff[0], aff[1])
     return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough)
 
 
@@ -733,15 +756,27 @@ class _BatchNorm(torch.autograd.Function):
     """nn.BatchNorm{1,2}d in train() mode over the last (channel) axis; updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, gap=None, relu_input=False):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, gap=None, relu_input=False, defer=False):
         lib = _lib()
         xd, g, b = _chk(x), _chk(gamma), _chk(beta)
         Cc = xd.shape[-1]
         rows = xd.numel() // Cc
         dev = xd.device
-        y = torch.empty_like(xd)
         mean, rstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
+        if defer:
+            # statistics only; the apply is handed to the consuming convolution as one affine per channel (conv3x3 reads `_eg_in_affine` off the
+            # returned alias): the normalised map is neither written nor read -- one write + one read of the map less per block, forward
+            aff = torch.empty(2, Cc, device=dev)
+            L.check(lib.eg_bn_train_stats_sq(_ptr(gap), _ptr(gap[1]), gap.shape[2], gap.shape[1], _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(run_mean),
+                                             _ptr(run_var), _ptr(aff[0]), _ptr(aff[1]), rows, Cc, float(momentum), float(eps), _ptr(ws), _stream(dev)),
+                    "eg_bn_train_stats_sq")
+            ctx.save_for_backward(xd, g, mean, rstd)
+            ctx.relu_input = bool(relu_input)
+            ctx.params = (gamma, beta)
+            ctx.mark_non_differentiable(aff)
+            return x.view_as(x), aff
+        y = torch.empty_like(xd)
         if gap is not None and gap.dim() == 4:     # sums and sums of squares from the producing convolution: statistics without touching the map
             L.check(lib.eg_bn_train_forward_sq(_ptr(xd), _ptr(gap), _ptr(gap[1]), gap.shape[2], gap.shape[1], _ptr(g), _ptr(b), _ptr(y), _ptr(mean),
                                                _ptr(rstd), None, _ptr(run_mean), _ptr(run_var), rows, Cc, float(momentum), float(eps), _ptr(ws),
@@ -759,7 +794,7 @@ class _BatchNorm(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _daff=None):
         lib = _lib()
         x, g, mean, rstd = ctx.saved_tensors
         Cc = x.shape[-1]
@@ -770,12 +805,28 @@ class _BatchNorm(torch.autograd.Function):
         ws = _scratch(dev, lib.eg_colreduce_workspace_floats(Cc), "col")
         L.check(lib.eg_bn_train_backward(_ptr(x), _ptr(dyd), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, Cc, int(ctx.relu_input),
                                          _ptr(ws), _stream(dev)), "eg_bn_train_backward")
-        return dx, dg, db, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
-def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5, gap=None, relu_input=False):
+DEFER_BN_APPLY = __import__("os").environ.get("EG_DEFER_BN", "1") != "0"       # False: every BatchNorm writes its output map (A/B switch)
+# Deferral pays only on large maps: at 128 clips per step 27.36 vs 27.48 ms (13 launches and 2.9 GB less), at 16 clips 8.12 vs 8.07 ms (the affine in
+# the convolution's and the weight-gradient kernel's staging costs more than the 6 us apply launch it replaces).  Threshold in elements of the map.
+DEFER_BN_MIN_NUMEL = int(__import__("os").environ.get("EG_DEFER_BN_MIN_NUMEL", str(12 << 20)))
+
+
+def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5, gap=None, relu_input=False, defer_apply=False):
     """`bn` = a BatchNorm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked).  gap: pooling partials of the
-    convolution that produced x (conv3x3(want_gap=True)); relu_input: x = relu(.) whose mask this backward applies (conv3x3(defer_mask=True))."""
+    convolution that produced x (conv3x3(want_gap=True)); relu_input: x = relu(.) whose mask this backward applies (conv3x3(defer_mask=True)).
+    defer_apply: the ONLY consumer is a stride-1, bias-free conv3x3 (a block's conv2): in the split-bf16 modes the normalisation is then not
+    applied here but handed to that convolution as a per-channel affine (returned tensor = an alias of x carrying `_eg_in_affine`; conv3x3 and its
+    weight-gradient kernel apply it while staging): nobody else may read the returned tensor's values."""
+    Cc = x_channels_last.shape[-1]
+    if (defer_apply and DEFER_BN_APPLY and _PREC["conv"] != F32 and gap is not None and gap.dim() == 4 and Cc % 32 == 0 and 256 % Cc == 0
+            and x_channels_last.dim() == 4 and x_channels_last.numel() >= DEFER_BN_MIN_NUMEL):
+        y, aff = _BatchNorm.apply(x_channels_last, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, eps, gap, relu_input, True)
+        y._eg_in_affine = (aff[0], aff[1])
+        _running_stats_written(bn)
+        return y
     y = _BatchNorm.apply(x_channels_last, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, eps, gap, relu_input)
     _running_stats_written(bn)
     return y
@@ -1080,11 +1131,12 @@ class _MHABlock(torch.autograd.Function):
             xq_img = None
         wqd, wkd, wvd, wfd, gd, bd = _chk(wq), _chk(wk), _chk(wv), _chk(wfc), _chk(g), _chk(b)
         dev = xq2.device
+        Dq = wqd.shape[0]               # heads x d_k: the projection width (Motion_Discriminator: 8 x 64 = 512 over a 128-wide model)
         if selfa:
             Lk, xkv2 = Lq, None
             wcat, _ = fused_rows([wqd, wkd, wvd])
             qkv = raw_linear(xq2, wcat, x_img=xq_img)                     # [rows, 3D]; X through the images the producing LayerNorm emitted
-            q, k, v, ldq, ldk = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, 3 * D
+            q, k, v, ldq, ldk = qkv, qkv[:, Dq:], qkv[:, 2 * Dq:], 3 * Dq, 3 * Dq
             saved_proj = (qkv,)
         else:
             Lk = xkv.shape[1]
@@ -1094,19 +1146,19 @@ class _MHABlock(torch.autograd.Function):
                 xkv_img = None
             qb = raw_linear(xq2, wqd, x_img=xq_img)
             kv = raw_linear(xkv2, wcat, x_img=xkv_img)                    # [rows_k, 2D]
-            q, k, v, ldq, ldk = qb, kv, kv[:, D:], D, 2 * D
+            q, k, v, ldq, ldk = qb, kv, kv[:, Dq:], Dq, 2 * Dq
             saved_proj = (qb, kv)
-        o = torch.empty(B * Lq, D, device=dev)
+        o = torch.empty(B * Lq, Dq, device=dev)
         attn = torch.empty(B, heads, Lq, Lk, device=dev)
         site_a = drop_site(p_attn, B * heads * Lq * Lk, xq2)
         pa, sa, oa, ea = site_a if site_a is not None else (0.0, 0, 0, None)
-        L.check(lib.eg_attention_train(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldk, _ptr(o), D, _ptr(attn), B, heads, Lq, Lk, D // heads,
+        L.check(lib.eg_attention_train(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldk, _ptr(o), Dq, _ptr(attn), B, heads, Lq, Lk, Dq // heads,
                                        float(pa), sa, oa, _ptr(ea), _stream(dev)), "eg_attention_train")
         site_f = drop_site(p_fc, B * Lq * D, xq2)
         pre = raw_linear(o, wfd, res=xq2, drop=site_f)                    # dropout(fc(.)) + residual in the product's epilogue (SubLayers.py:54)
         y, yimg = _ln_forward(pre, gd, bd, eps, want_img=True)
         ctx.save_for_backward(xq2, xkv2, attn, o, pre, wqd, wkd, wvd, wfd, gd, *saved_proj)
-        ctx.cfg = (B, Lq, Lk, D, heads, selfa, site_a, site_f, float(eps), xq.requires_grad, (xkv is not None and xkv.requires_grad))
+        ctx.cfg = (B, Lq, Lk, D, Dq, heads, selfa, site_a, site_f, float(eps), xq.requires_grad, (xkv is not None and xkv.requires_grad))
         ctx.params = (wq, wk, wv, wfc, g, b)
         ctx.set_materialize_grads(False)
         if yimg is None:
@@ -1119,7 +1171,7 @@ class _MHABlock(torch.autograd.Function):
         lib = _lib()
         xq2, xkv2, attn, o, pre, wq, wk, wv, wfc, g = ctx.saved_tensors[:10]
         proj = ctx.saved_tensors[10:]
-        B, Lq, Lk, D, heads, selfa, site_a, site_f, eps, need_dxq, need_dxkv = ctx.cfg
+        B, Lq, Lk, D, Dq, heads, selfa, site_a, site_f, eps, need_dxq, need_dxkv = ctx.cfg
         pq, pk, pv, pfc, pg, pb = ctx.params
         dev = pre.device
         dy2 = _chk(dy).reshape(B * Lq, D)
@@ -1130,9 +1182,9 @@ class _MHABlock(torch.autograd.Function):
         if selfa:
             (qkv,) = proj
             dqkv = torch.empty_like(qkv)
-            L.check(lib.eg_attention_backward_train(qkv.data_ptr(), 3 * D, qkv[:, D:].data_ptr(), 3 * D, qkv[:, 2 * D:].data_ptr(), 3 * D, _ptr(attn), _ptr(do), D,
-                                                    dqkv.data_ptr(), 3 * D, dqkv[:, D:].data_ptr(), 3 * D, dqkv[:, 2 * D:].data_ptr(), 3 * D, B, heads, Lq, Lk,
-                                                    D // heads, float(pa), sa, oa, _ptr(ea), _stream(dev)), "eg_attention_backward_train")
+            L.check(lib.eg_attention_backward_train(qkv.data_ptr(), 3 * Dq, qkv[:, Dq:].data_ptr(), 3 * Dq, qkv[:, 2 * Dq:].data_ptr(), 3 * Dq, _ptr(attn), _ptr(do), Dq,
+                                                    dqkv.data_ptr(), 3 * Dq, dqkv[:, Dq:].data_ptr(), 3 * Dq, dqkv[:, 2 * Dq:].data_ptr(), 3 * Dq, B, heads, Lq, Lk,
+                                                    Dq // heads, float(pa), sa, oa, _ptr(ea), _stream(dev)), "eg_attention_backward_train")
             wcat, _ = fused_rows([wq, wk, wv])
             dx = raw_linear(dqkv, wcat, w_transposed=True, res=dpre) if need_dxq else None      # the residual's gradient rides in the epilogue
             dwm, dws = fused_grad_out((pq, pk, pv), D)
@@ -1140,8 +1192,8 @@ class _MHABlock(torch.autograd.Function):
             return (dx.view(B, Lq, D) if dx is not None else None), None, dws[0], dws[1], dws[2], dwfc, dg, db, None, None, None, None, None, None
         qb, kv = proj
         dq, dkv = torch.empty_like(qb), torch.empty_like(kv)
-        L.check(lib.eg_attention_backward_train(_ptr(qb), D, kv.data_ptr(), 2 * D, kv[:, D:].data_ptr(), 2 * D, _ptr(attn), _ptr(do), D, _ptr(dq), D,
-                                                dkv.data_ptr(), 2 * D, dkv[:, D:].data_ptr(), 2 * D, B, heads, Lq, Lk, D // heads, float(pa), sa, oa, _ptr(ea),
+        L.check(lib.eg_attention_backward_train(_ptr(qb), Dq, kv.data_ptr(), 2 * Dq, kv[:, Dq:].data_ptr(), 2 * Dq, _ptr(attn), _ptr(do), Dq, _ptr(dq), Dq,
+                                                dkv.data_ptr(), 2 * Dq, dkv[:, Dq:].data_ptr(), 2 * Dq, B, heads, Lq, Lk, Dq // heads, float(pa), sa, oa, _ptr(ea),
                                                 _stream(dev)), "eg_attention_backward_train")
         wcat, _ = fused_rows([wk, wv])
         dxq = raw_linear(dq, wq, w_transposed=True, res=dpre) if need_dxq else None

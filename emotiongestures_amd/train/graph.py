@@ -216,9 +216,17 @@ class SegmentedStep:
         if exposed is not None and self.side is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        # The last phase's buckets are reduced on the SIDE stream as well, never on the caller's: with async_op=False torch.distributed enqueues the
+        # collective on the current stream and its watchdog thread later queries the work's end event -- an event last recorded on the stream this
+        # class captures its graphs on makes that query fail while a capture is open ("operation not permitted on an event last recorded in a
+        # capturing stream": 3 of 10 forced 1-rank RCCL runs aborted in round 5 before this).
         if self.side is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self._reduce(bucket_ids)
             cur.wait_stream(self.side)
-        self._reduce(bucket_ids)
+        else:
+            self._reduce(bucket_ids)
         if ev is not None:
             ev[1].record()
             exposed.append(ev)

@@ -252,6 +252,12 @@ int eg_conv3x3_se(const float* x, const float* w_packed, const float* bias, cons
  * BatchNorm that follows takes mean and variance from them (eg_bn_train_forward_sq) without reading y again. */
 int eg_conv3x3_sq(const float* x, const float* w_packed, const float* bias, float* y, float* gap_partial, float* gap_sq_partial, int32_t batch,
                   int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride, int32_t relu, int32_t precision, void* stream);
+/* The same convolution on x' = x * in_scale[ci] + in_shift[ci] (per INPUT channel; in-image pixels only, the zero padding stays zero): the train-mode
+ * BatchNorm in front of the convolution (ResNetBlocks.py:26-27, bn1 -> conv2) folded into the operand staging -- the normalised map is never written.
+ * in_scale / in_shift come from eg_bn_train_stats_sq.  Split-bf16 modes, cin % 32 == 0.  gap_partial / gap_sq_partial: both or neither. */
+int eg_conv3x3_sq_in_affine(const float* x, const float* in_scale, const float* in_shift, const float* w_packed, const float* bias, float* y,
+                            float* gap_partial, float* gap_sq_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
+                            int32_t relu, int32_t precision, void* stream);
 /* SELayer gate of a block computed BEFORE its conv2 runs: the spatial mean of BN2(conv2(t1)) is linear in window sums of t1
  * (total from conv1's gap partials, border lines / corners read from t1), so gate = sigmoid(W2 relu(W1 mean + b1) + b2) needs
  * only t1 and conv2's fp32 weight image (the head of its EG_PACK_CONV3X3 entry).  t1 NHWC [B,H,W,C], conv2: C -> C, stride 1. */
@@ -470,6 +476,11 @@ int eg_bn_train_forward_gap(const float* x, const float* gap_partial, int32_t ti
 int eg_bn_train_forward_sq(const float* x, const float* gap_partial, const float* gap_sq_partial, int32_t tiles, int32_t batch, const float* gamma,
                            const float* beta, float* y, float* save_mean, float* save_rstd, float* clip_sum, float* running_mean, float* running_var,
                            int64_t rows, int32_t c, float momentum, float eps, float* workspace, void* stream);
+/* Statistics only (no apply), plus the apply folded to one affine per channel: aff_scale = gamma * rstd, aff_shift = beta - mean * aff_scale -- for
+ * eg_conv3x3_sq_in_affine / eg_conv3x3_wgrad_mfma_oihw_in_affine, which apply it while staging their operand. */
+int eg_bn_train_stats_sq(const float* gap_partial, const float* gap_sq_partial, int32_t tiles, int32_t batch, const float* gamma, const float* beta,
+                         float* save_mean, float* save_rstd, float* running_mean, float* running_var, float* aff_scale, float* aff_shift, int64_t rows,
+                         int32_t c, float momentum, float eps, float* workspace, void* stream);
 /* SEBasicBlock tail under autograd (ResNetBlocks.py:28-36,92-96), maps [batch, hw, c] channels-last, c % 8 == 0, c <= 256:
  *   forward:  pooled = mean_hw(bn2(c2)) from clip_sum; h = relu(W1 pooled + b1); gate = sigmoid(W2 h + b2)      (eg_se_gate_train_forward)
  *             out = relu(bn2(c2) * gate + res) in one pass, bn2's output never stored                            (eg_se_tail_forward)
@@ -503,6 +514,9 @@ int eg_conv3x3_wgrad_mfma(const float* x, const float* dy, float* dw_mat, int32_
 /* The same gradient written in nn.Conv2d's weight layout dw[cout][cin][3][3] by the final fixed-order reduction (no permute pass behind it). */
 int eg_conv3x3_wgrad_mfma_oihw(const float* x, const float* dy, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                float* workspace, int64_t workspace_floats, void* stream);
+/* ... of a convolution whose input was x' = x * in_scale[ci] + in_shift[ci] (eg_conv3x3_sq_in_affine): the affine is re-applied while x is staged. */
+int eg_conv3x3_wgrad_mfma_oihw_in_affine(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dw, int32_t batch, int32_t h,
+                                         int32_t w, int32_t cin, int32_t cout, float* workspace, int64_t workspace_floats, void* stream);
 /* Weight and bias gradient of nn.Linear on the split-bf16 matrix pipe (3 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate):
  *   dw[n][k] = sum_r dy[r][n] * x[r][k]   (dy [rows, n] at pitch ldy, x [rows, k] at pitch ldx, dw at pitch lddw);  db[n] = sum_r dy[r][n] (db may be NULL).
  * F.linear's parameter gradients under autograd (every nn.Linear of Full_model/Models_spatial_memory.py, SubLayers.py:30-84).  Deterministic: rows

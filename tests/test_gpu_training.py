@@ -1530,3 +1530,54 @@ def test_fused_blocks_step_equals_the_operator_by_operator_step(precision, flat,
     assert errs[0][0] < tol, errs[:5]
     assert float(g1["0.audio_encoder.final_conv1.bias"].abs().max()) < 1e-4
     assert n1 <= n0 - (100 if dropout else 60), (n0, n1)            # the point of the exercise: fewer launches per step (measured: 888 -> 778 / 840 -> 776)
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(1, 32, 32), (2, 32, 64), (1, 128, 128), (1, 64, 64)])
+def test_deferred_batchnorm_apply_matches_the_materialised_block(stride, cin, cout):
+    """batch_norm(defer_apply=True) in the split-bf16 modes: bn1 is not applied as a pass over the map; conv2's staging (eg_conv3x3_sq_in_affine) and conv2's
+    weight-gradient staging (eg_conv3x3_wgrad_mfma_oihw_in_affine) apply it as one affine per input channel, zero padding untouched.  Against the same block
+    with the normalised map materialised: output, input gradient, every parameter gradient and the running statistics agree at the split-bf16 noise level
+    (the two formulations round x' differently by an ulp, which re-rolls the (hi, lo) split: 2e-5 on the output, 2e-4 on gradients)."""
+    from emotiongestures_amd.modules import ResNetSE, SEBasicBlock
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train import nets
+    import copy
+    torch.manual_seed(12)
+    if (stride, cin, cout) == (2, 32, 64):
+        blk = ResNetSE(SEBasicBlock, [1, 1, 1], [32, 64, 128]).layer2[0]
+    else:
+        blk = SEBasicBlock(cin, cout)
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.1)
+    for n, p in blk.named_parameters():
+        if n.endswith("bn1.weight") or n.endswith("bn2.weight") or n.endswith("downsample.1.weight"):
+            p.data.add_(1.0)
+        if n.endswith("bn1.bias"):
+            p.data.add_(0.3)                # a shift that the zero padding must NOT receive
+    blk = blk.to(DEV)
+    blk2 = copy.deepcopy(blk)
+    x = torch.randn(3, 21, 38, cin, device=DEV)
+    dy, res = None, []
+    old = (F.DEFER_BN_APPLY, F.DEFER_BN_MIN_NUMEL)
+    try:
+        with F.precision("bf16x3"):
+            for b, defer in ((blk, True), (blk2, False)):
+                F.DEFER_BN_APPLY, F.DEFER_BN_MIN_NUMEL = defer, 0
+                n0 = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count())
+                xi = x.clone().requires_grad_(True)
+                out = nets.se_basic_block(b, xi)
+                if dy is None:
+                    dy = torch.randn_like(out)
+                out.backward(dy)
+                torch.cuda.synchronize()
+                res.append((out.detach(), xi.grad, {n: p.grad for n, p in b.named_parameters()}, {n: v.clone() for n, v in b.named_buffers()},
+                            int(__import__("emotiongestures_amd")._lib.load().eg_launch_count()) - n0))
+    finally:
+        F.DEFER_BN_APPLY, F.DEFER_BN_MIN_NUMEL = old
+    (o1, g1, p1, b1, n1), (o2, g2, p2, b2, n2) = res
+    assert n1 == n2 - 1                      # the apply launch is gone
+    assert rel(o1, o2) < 2e-5 and rel(g1, g2) < 2e-4
+    for n in p2:
+        assert p1[n] is not None and rel(p1[n], p2[n]) < 3e-4, (n, rel(p1[n], p2[n]))
+    for n in b2:
+        assert rel(b1[n].float(), b2[n].float()) < 1e-5, n
