@@ -115,7 +115,7 @@ def measured_traffic(tag, precision):
         return None
     kern = json.load(open(os.path.join(pdir, cands[-1])))["kernels"]      # newest round's file
     if tag in (2, 3, 4):
-        prefix = {2: "gemm_glds_kernel<3>", 3: "gemm_presplit", 4: "gemm_bf16_kernel<3>"}[tag]
+        prefix = {2: "gemm_glds_kernel<3", 3: "gemm_presplit", 4: "gemm_bf16_kernel<3"}[tag]
     elif tag >= 1000:
         cin, cout, s = tag // 1000000, (tag // 1000) % 1000, (tag // 100) % 10
         prefix = f"conv3x3_bf16_kernel<{cin}, {(cout + 15) // 16}, {s},"
@@ -690,6 +690,9 @@ def main():
     def make_runner(gen_, lanes_):
         """(step callable, pipeline or None) for a generator: hipGraph lanes unless --no-graph."""
         if args.no_graph:
+            # eager (profiling passes): EG_BENCH_SHARED_CHIP=1 keeps the tile policy of the timed 4-lane configuration, so that the per-kernel PMC
+            # numbers describe the kernels the headline runs
+            gen_.shared_chip = os.environ.get("EG_BENCH_SHARED_CHIP") == "1"
             side = torch.cuda.Stream(dev) if gen_.concurrent else None
             return make_step(gen_, vae, mel, side), None
         # One lane = one captured step (all launches + the fork/join of its side streams) replayed on its own stream.

@@ -8,6 +8,7 @@ cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 INF="python3 bench.py --no-cpu-baseline --no-extra-legs --no-train-legs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_ks -- $INF > $O/${TAG}_ks.log 2>&1
 python3 tools/rocprof_summary.py $O/${TAG}_ks $O/${TAG}_kernel_stats_default_cmd.md
+export EG_BENCH_SHARED_CHIP=1       # the eager profiling passes use the GEMM tile policy of the timed 4-lane configuration
 EAGER="python3 bench.py --no-graph --no-concurrent --in-flight 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --no-train-legs --no-roofline"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -- $EAGER > $O/${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -- $EAGER > $O/${TAG}_write.log 2>&1
