@@ -635,7 +635,7 @@ class _Conv3x3(torch.autograd.Function):
             ws = _scratch(dev, need, "wgrad")
             L.check(lib.eg_conv3x3_wgrad_mfma_oihw(_ptr(x), _ptr(dy2), _ptr(dw), B, H, W, Ci, Co, _ptr(ws), ws.numel(), _stream(dev)),
                     "eg_conv3x3_wgrad_mfma")
-        elif _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and Co % 4 == 0 and PAD_WGRAD:
+        elif _PREC["conv"] != F32 and ctx.stride == 1 and Ci % 32 == 0 and PAD_WGRAD:
             # a ragged output width (final_conv1: 128 -> frames = 34 / 60 / 120): the same MFMA kernel on dy zero-padded to a multiple of 32 channels --
             # the padded rows of dW come out zero and are dropped (one pad pass over dy and a small copy instead of the fp32 implicit GEMM:
             # 274 -> ~60 us at 128 clips)
@@ -670,7 +670,7 @@ class _Conv3x3(torch.autograd.Function):
             L.check(lib.eg_conv3x3_se(_ptr(dyd), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"],
                                       _stream(dev)), "eg_conv3x3 (dgrad)")
             dres = None
-        elif ctx.need_dx and _PREC["conv"] != F32 and ctx.stride == 1 and Ci == 128 and Co <= 64 and Co % 4 == 0 and PAD_WGRAD:
+        elif ctx.need_dx and _PREC["conv"] != F32 and ctx.stride == 1 and Ci == 128 and Co <= 64 and PAD_WGRAD:
             # final_conv1 (128 -> frames): the same rotated-filter convolution on dy and the filter zero-padded to 64 output channels, instead of
             # the [pixels, 9 * 128] column product + col2im (585 MB written and re-read per 128-clip step)
             dyp = _pad_cols(dy2, 64).view(B, Ho, Wo, 64)
