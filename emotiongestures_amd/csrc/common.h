@@ -177,4 +177,5 @@ struct EgiLinear {
     void* yimg = nullptr; int yK = 0, yk0 = 0;                      // optional pre-split output images of width yK at column offset yk0
     int m = 0, n = 0, k = 0, relu = 0, a_shift = 0, a_seq = 1, precision = 0;
     int shared_chip = 0;                                            // the caller keeps other work resident (several batches in flight): tile for CU time, not latency
+    int splits = 0; float* partial = nullptr;                       // pre-split input only: split K over `splits` workgroup slices (partial >= splits*m*n floats), fixed-order fold
 };

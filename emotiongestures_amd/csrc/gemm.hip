@@ -931,6 +931,20 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
+        if (p.splits > 1) {
+            // a single clip (one or two row tiles) and a deep K: 64 serial K steps on a handful of workgroups.  Split K over workgroup slices (64 x 64
+            // tile, blockIdx.z) and fold the partials in a fixed order with the whole epilogue (bias, residual, ReLU): shorter wall time for one more launch.
+            EG_REQUIRE(p.partial && !p.yimg && p.y, EG_ERR_BAD_ARG, "egi_linear: split-K needs a partial buffer and an fp32 output (no image output)");
+            a.partial = p.partial;
+            a.k_per_split = (int)eg_round_up(eg_cdiv(a.K, p.splits), 64);
+            const int nsplit = eg_cdiv(a.K, a.k_per_split);
+            prof.workgroups(mt * eg_cdiv(a.N, 64) * nsplit);
+            dim3 grid(mt, eg_cdiv(a.N, 64), nsplit);
+            const int rc = (p.precision == EG_PREC_BF16X3) ? launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(eg_cdiv(a.M * a.N, 256)), dim3(256), 0, st, a, nsplit);
+            return eg_check_launch("splitk_reduce");
+        }
         return dispatch_presplit(a, xhi, xlo, xko, p.precision, st, &prof, p.shared_chip);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");

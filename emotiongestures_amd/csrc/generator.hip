@@ -387,7 +387,7 @@ inline Act act(float* f, int ld, void* img = nullptr, int kimg = 0) { Act a; a.f
 // through them (no in-kernel split), and an output with an image slot is emitted split for the next product;
 // want_f32 = false then skips the fp32 copy.  In f32 mode images are ignored and everything flows through fp32 buffers.
 int lin(const EgGenerator* g, const float* arena, const LinW& w, const Act& x, int xk0, const Act& y, bool want_f32, int m, int relu,
-        const float* res1, int ldr, hipStream_t st, int n_override = 0) {
+        const float* res1, int ldr, hipStream_t st, int n_override = 0, int splits = 0, float* partial = nullptr) {
     const bool img_ok = g->cfg.precision != EG_PREC_F32;
     EgiLinear p;
     p.w = arena + w.w; p.ldw = w.kpad; p.bias = w.b >= 0 ? arena + w.b : nullptr;
@@ -401,6 +401,7 @@ int lin(const EgGenerator* g, const float* arena, const LinW& w, const Act& x, i
     const bool yimg = img_ok && y.img;
     if (yimg) { p.yimg = y.img; p.yK = y.kimg; }
     if (want_f32 || !yimg) { p.y = y.f; p.ldc = y.ld; }
+    if (splits > 1 && img_ok && x.img && !yimg) { p.splits = splits; p.partial = partial; }
     return egi_linear(p, st);
 }
 
@@ -443,7 +444,10 @@ int run_ffn(const EgGenerator* g, const float* arena, const FfnW& f, const Act& 
     } else {
         const Act hid = act(h, DI, P(ws, w.im_h), DI);
         EG_TRY(lin(g, arena, f.w1, x, 0, hid, false, rows, 1, nullptr, 0, st));
-        EG_TRY(lin(g, arena, f.w2, hid, 0, act(pr, D), true, rows, 0, x.f, D, st));
+        // one or two clips (<= 128 rows) in a bf16 mode: w_2's 2048-deep product is 64 serial K steps on 8 - 16 workgroups; split K four ways (the fp32
+        // hidden buffer is free in these modes and takes the partials)
+        const int sp = (g->cfg.precision != EG_PREC_F32 && rows <= 128 && DI >= 2048 && 4 * D <= DI) ? 4 : 0;
+        EG_TRY(lin(g, arena, f.w2, hid, 0, act(pr, D), true, rows, 0, x.f, D, st, 0, sp, h));
     }
     return egi_layernorm(pr, arena + f.ln_g, arena + f.ln_b, out.f, g->cfg.precision != EG_PREC_F32 ? out.img : nullptr, rows, D, 1e-6f, st);
 }
