@@ -24,6 +24,22 @@ import torch
 CAPTURE_MODE = "thread_local"
 
 
+def cu_masked_stream(device, cu_ids):
+    """A HIP stream whose kernels run only on the given compute units (hipExtStreamCreateWithCUMask; 256 CUs = 8 mask words), wrapped for torch.
+    Experiment hook of ClipPipeline (`EG_LANE_CU_MASK`): lanes as SPATIAL partitions of the chip instead of time-slicing all of it."""
+    import ctypes
+    hip = ctypes.CDLL(torch.__file__.rsplit("/", 1)[0] + "/lib/libamdhip64.so")
+    words = (ctypes.c_uint32 * 8)()
+    for cu in cu_ids:
+        words[cu >> 5] |= 1 << (cu & 31)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class _Lane:
     __slots__ = ("slot", "stream", "graph", "inputs", "outputs", "done", "busy", "collected", "keep", "key")
 
@@ -50,13 +66,24 @@ class ClipPipeline:
         for i in range(lanes):
             ln = _Lane()
             ln.slot = i
-            ln.stream = torch.cuda.Stream(self.device)
+            ln.stream = self._lane_stream(i, lanes)
             ln.inputs = {k: v.to(self.device).clone() for k, v in example_inputs.items()}
             ln.done = torch.cuda.Event()
             ln.collected = None
             ln.busy = False
             self._capture(ln)
             self.lanes.append(ln)
+
+    def _lane_stream(self, i, lanes):
+        """The stream lane i replays on.  EG_LANE_CU_MASK (experiment): "contig" = lane i gets CUs [i * 256 / lanes, ...), "interleave" = CUs i, i + lanes, ...
+        (default: an ordinary stream; every lane may use the whole chip)."""
+        import os
+        mode = os.environ.get("EG_LANE_CU_MASK", "")
+        if mode not in ("contig", "interleave") or lanes < 2:
+            return torch.cuda.Stream(self.device)
+        per = 256 // lanes
+        cus = range(i * per, (i + 1) * per) if mode == "contig" else range(i, 256, lanes)
+        return cu_masked_stream(self.device, list(cus))
 
     # one step on the current stream, reading the lane's static buffers
     def _step(self, ln: _Lane):
