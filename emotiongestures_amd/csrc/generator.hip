@@ -444,9 +444,10 @@ int run_ffn(const EgGenerator* g, const float* arena, const FfnW& f, const Act& 
     } else {
         const Act hid = act(h, DI, P(ws, w.im_h), DI);
         EG_TRY(lin(g, arena, f.w1, x, 0, hid, false, rows, 1, nullptr, 0, st));
-        // one or two clips (<= 128 rows) in a bf16 mode: w_2's 2048-deep product is 64 serial K steps on 8 - 16 workgroups; split K four ways (the fp32
-        // hidden buffer is free in these modes and takes the partials)
-        const int sp = (g->cfg.precision != EG_PREC_F32 && rows <= 128 && DI >= 2048 && 4 * D <= DI) ? 4 : 0;
+        // ONE clip (<= 64 rows: a single row tile) in a bf16 mode: w_2's 2048-deep product is 64 serial K steps on 8 workgroups; split K four ways (the
+        // fp32 hidden buffer is free in these modes and takes the partials).  Only there: from two clips up every product accumulates K in one order
+        // whatever the batch size, so a clip's pose does not depend on how a batch is chunked (nn.DataParallel's scatter, ClipPipeline's batches).
+        const int sp = (g->cfg.precision != EG_PREC_F32 && rows <= 64 && DI >= 2048 && 4 * D <= DI) ? 4 : 0;
         EG_TRY(lin(g, arena, f.w2, hid, 0, act(pr, D), true, rows, 0, x.f, D, st, 0, sp, h));
     }
     return egi_layernorm(pr, arena + f.ln_g, arena + f.ln_b, out.f, g->cfg.precision != EG_PREC_F32 ? out.img : nullptr, rows, D, 1e-6f, st);
