@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 // OIHW fp32 -> the image eg_conv3x3 reads (conv.hip: launch_conv): fp32 [tap][ci/4][coutp][4], then bf16 hi and lo images
 // [tap][ci/8][coutp][8].  flip != 0 packs the filter of the input-gradient convolution instead: w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
 // (the result then convolves `cout` input channels into `cin` output channels).  One thread per (tap, channel octet, output channel).
-__device__ __forceinline__ void pack_conv3x3_item(const float* __restrict__ w, int cout, int cin, int flip, float* __restrict__ image, int idx) {
+__device__ __forceinline__ void pack_conv3x3_item(const float* __restrict__ w, int cout, int cin, int flip, float* __restrict__ image, int idx, bool skip_f32 = false) {
     const int CI = flip ? cout : cin, CO = flip ? cin : cout, coutp = (CO + 15) / 16 * 16;
     const int total = 9 * (CI / 8) * coutp;
     if (idx >= total) return;
@@ -831,9 +831,11 @@ __device__ __forceinline__ void pack_conv3x3_item(const float* __restrict__ w, i
             if (j < 4) v0[j] = x; else v1[j - 4] = x;
         }
     }
-    f4* f32img = reinterpret_cast<f4*>(image);
-    f32img[((size_t)tap * (CI / 4) + oc * 2) * coutp + co] = v0;
-    f32img[((size_t)tap * (CI / 4) + oc * 2 + 1) * coutp + co] = v1;
+    if (!skip_f32) {            // the fp32 head of the image: read by the fp32 kernels (and by eg_se_gate_pre), never by the split-bf16 ones
+        f4* f32img = reinterpret_cast<f4*>(image);
+        f32img[((size_t)tap * (CI / 4) + oc * 2) * coutp + co] = v0;
+        f32img[((size_t)tap * (CI / 4) + oc * 2 + 1) * coutp + co] = v1;
+    }
     bf8 hi, lo;
     split_octet<true>(v0, v1, hi, lo);
     bf8* himg = reinterpret_cast<bf8*>(image + (size_t)9 * CI * coutp);
@@ -849,7 +851,8 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
 // [n][k] fp32 (row stride ld) -> the image eg_linear's split-bf16 modes read (gemm.hip: fill_common): fp32 [rows][kpad], then tile-planar bf16
 // hi and lo images [rows/64][kpad/8][64][8]; rows = n rounded up to 64, kpad = k rounded up to 64, zero padded.  transpose != 0 packs
 // the transposed matrix (the `weight` of dX = dY W is W^T): image row r, column q = w[q][r].  One thread per (row tile, k octet, row).
-__device__ __forceinline__ void pack_linear_item(const float* __restrict__ w, int ld, int n, int k, int transpose, float* __restrict__ image, int idx) {
+__device__ __forceinline__ void pack_linear_item(const float* __restrict__ w, int ld, int n, int k, int transpose, float* __restrict__ image, int idx,
+                                                 bool skip_f32 = false) {
     const int rows = (n + 63) / 64 * 64, kpad = (k + 63) / 64 * 64, KO = kpad / 8;
     if (idx >= rows * KO) return;
     const int r = idx & 63, ko = (idx >> 6) % KO, rt = idx / (64 * KO);
@@ -863,9 +866,11 @@ __device__ __forceinline__ void pack_linear_item(const float* __restrict__ w, in
             if (j < 4) v0[j] = x; else v1[j - 4] = x;
         }
     }
-    f4* f32img = reinterpret_cast<f4*>(image + (size_t)row * kpad + ko * 8);
-    f32img[0] = v0;
-    f32img[1] = v1;
+    if (!skip_f32) {
+        f4* f32img = reinterpret_cast<f4*>(image + (size_t)row * kpad + ko * 8);
+        f32img[0] = v0;
+        f32img[1] = v1;
+    }
     bf8 hi, lo;
     split_octet<true>(v0, v1, hi, lo);
     bf8* himg = reinterpret_cast<bf8*>(image + (size_t)rows * kpad);
@@ -890,8 +895,10 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackEntry* __rest
     }
     const PackEntry e = table[lo];
     const int idx = (blk - e.first_block) * 256 + threadIdx.x;
-    if (e.kind == 0) pack_linear_item(e.src, e.c, e.a, e.b, e.flag, e.image, idx);
-    else pack_conv3x3_item(e.src, e.a, e.b, e.flag, e.image, idx);
+    // flag bit 0: transpose / flip; bit 1: leave the fp32 head of the image unwritten (a training step in the split-bf16 modes never reads it: half the
+    // bytes of the step's image refresh)
+    if (e.kind == 0) pack_linear_item(e.src, e.c, e.a, e.b, e.flag & 1, e.image, idx, (e.flag & 2) != 0);
+    else pack_conv3x3_item(e.src, e.a, e.b, e.flag & 1, e.image, idx, (e.flag & 2) != 0);
 }
 
 // ---- dropout: counter-based mask, nothing stored -- keep(i) = hash(seed, offset + i) >= p; y = keep ? x / (1 - p) : 0.  The backward pass
@@ -1726,7 +1733,7 @@ extern "C" int eg_pack_linear_device(const float* w, int32_t ld, int32_t n, int3
 // with first_block the running sum of eg_pack_table_blocks(...) of the entries before it; total_blocks = that sum over all entries.
 extern "C" int32_t eg_pack_table_blocks(int32_t kind, int32_t a, int32_t b, int32_t flag) {
     if (kind == 0) return (int32_t)((eg_round_up(a, 64) * (eg_round_up(b, 64) / 8) + 255) / 256);
-    const int ci = flag ? a : b, co = flag ? b : a;
+    const int ci = (flag & 1) ? a : b, co = (flag & 1) ? b : a;
     return (int32_t)((9 * (ci / 8) * (int)eg_round_up(co, 16) + 255) / 256);
 }
 extern "C" int eg_pack_table(const void* table, int32_t count, int32_t total_blocks, void* stream) {

@@ -138,7 +138,10 @@ class _ImageRegistry:
         self.sets = sets
 
     def lookup(self, w, kind, flag):
+        f32_now = _PREC["gemm" if kind == 0 else "conv"] == F32
         for reg in self.sets:
+            if f32_now and getattr(reg, "bf16_only", False):
+                continue                # images refreshed without their fp32 head (WeightImages built in a split-bf16 mode): the fp32 kernels pack per use
             hit = reg.lookup(w, kind, flag)
             if hit is not None:
                 return hit

@@ -123,6 +123,10 @@ class WeightImages:
         dev = fp.flat.device
         if dev.type != "cuda":
             raise L.EgError("WeightImages: needs a GPU")
+        from . import functional as F
+        # built while the step computes in a split-bf16 mode: the refresh leaves the fp32 head of each image unwritten (flag bit 1 of the table entry,
+        # csrc/train.hip pack_table_kernel) -- half the bytes of the launch -- and an fp32 lookup later misses (functional._ImageRegistry.lookup)
+        self.bf16_only = F.get_precision() != "f32"
         entries, self.images, self.params = [], {}, []
         first = 0
         skip_ids = {id(p) for p in skip}
@@ -132,7 +136,7 @@ class WeightImages:
             for kind, a, b, c, flag, floats, rows in kinds:
                 img = torch.empty(floats, dtype=torch.float32, device=dev)
                 self.images[(ptr, kind, flag, rows)] = (img, owners)
-                entries.append((ptr, img.data_ptr(), kind, a, b, c, flag, first))
+                entries.append((ptr, img.data_ptr(), kind, a, b, c, flag | (2 if self.bf16_only else 0), first))
                 first += int(lib.eg_pack_table_blocks(kind, a, b, flag))
 
         for p in fp.params:

@@ -535,7 +535,8 @@ int64_t eg_linear_packed_floats(int32_t n, int32_t k);
 int eg_pack_linear_device(const float* w, int32_t ld, int32_t n, int32_t k, int32_t transpose, float* image, void* stream);
 /* Every weight image of a training step in one launch.  `table`: device array of `count` 40-byte entries
  *   { const float* src; float* image; int32_t kind, a, b, c, flag, first_block; }
- * kind 0 = eg_pack_linear_device(src, ld = c, n = a, k = b, transpose = flag, image); kind 1 = eg_pack_conv3x3_device(src, cout = a, cin = b, flip = flag, image);
+ * kind 0 = eg_pack_linear_device(src, ld = c, n = a, k = b, transpose = flag & 1, image); kind 1 = eg_pack_conv3x3_device(src, cout = a, cin = b, flip = flag & 1, image);
+ * flag bit 1 set: the fp32 head of that image is left unwritten (only the split-bf16 kernels may read it);
  * first_block = sum of eg_pack_table_blocks(kind, a, b, flag) over the preceding entries, total_blocks = the sum over all. */
 int32_t eg_pack_table_blocks(int32_t kind, int32_t a, int32_t b, int32_t flag);
 int eg_pack_table(const void* table, int32_t count, int32_t total_blocks, void* stream);

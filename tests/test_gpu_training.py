@@ -1358,6 +1358,10 @@ def test_resident_weight_images_match_per_use_packing():
                 assert images.count > 100
                 w = model.post_projector[0].weight
                 assert images.lookup(w.detach(), 0, 0) is not None and images.lookup(w.detach(), 0, 1) is not None
+                # built in a split-bf16 mode the refresh skips each image's fp32 head: the fp32 kernels must not be handed one
+                assert images.bf16_only and F._image_registry().lookup(w.detach(), 0, 0) is not None
+                with F.precision("f32"):
+                    assert F._image_registry().lookup(w.detach(), 0, 0) is None
                 with torch.no_grad():
                     w.mul_(1.0)                                         # in-place torch op: version bump the registry has not seen
                 assert images.lookup(w.detach(), 0, 0) is None
