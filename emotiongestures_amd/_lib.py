@@ -57,6 +57,7 @@ class EgLinearArgs(C.Structure):
 SIGNATURES = {
     "eg_last_error": (C.c_char_p, []),
     "eg_launch_count": (_L, []),
+    "eg_launch_histogram": (_L, [C.c_char_p, _L, C.c_int32]),
     "eg_version": (C.c_char_p, []),
     "eg_set_default_precision": (C.c_int, [C.c_int]),
     "eg_get_default_precision": (C.c_int, []),

@@ -32,8 +32,11 @@ void eg_set_error(const char* fmt, ...);
 // Launch check without synchronising (Guideline 9: nothing blocking in a launch function).  Every kernel launch of the library passes
 // through here: the counter behind eg_launch_count() (launches per step of a training / inference pass, reported by bench.py).
 extern std::atomic<long long> g_eg_launches;
+extern bool g_eg_launch_hist;                   // EG_LAUNCH_HIST=1: also count launches by label (eg_launch_histogram: a diagnostic, off by default)
+void egi_count_launch(const char* what);
 static inline int eg_check_launch(const char* what) {
     g_eg_launches.fetch_add(1, std::memory_order_relaxed);
+    if (g_eg_launch_hist) egi_count_launch(what);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         eg_set_error("%s: %s", what, hipGetErrorString(e));

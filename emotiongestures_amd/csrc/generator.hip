@@ -22,6 +22,28 @@ void eg_set_error(const char* fmt, ...) {
 extern "C" const char* eg_last_error(void) { return g_err; }
 std::atomic<long long> g_eg_launches{0};
 extern "C" int64_t eg_launch_count(void) { return (int64_t)g_eg_launches.load(std::memory_order_relaxed); }
+// launches by label since the last reset (only counted under EG_LAUNCH_HIST=1): "label count\n" lines into buf, returns the bytes needed
+bool g_eg_launch_hist = [] { const char* e = getenv("EG_LAUNCH_HIST"); return e && e[0] == '1'; }();
+namespace {
+std::mutex g_hist_mu;
+std::map<std::string, long long> g_hist;
+}  // namespace
+void egi_count_launch(const char* what) {
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    ++g_hist[what];
+}
+extern "C" int64_t eg_launch_histogram(char* buf, int64_t cap, int32_t reset) {
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    std::string out;
+    for (const auto& kv : g_hist) out += kv.first + " " + std::to_string(kv.second) + "\n";
+    if (buf && cap > 0) {
+        const size_t n = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    if (reset) g_hist.clear();
+    return (int64_t)out.size() + 1;
+}
 extern "C" const char* eg_version(void) { return "emogest-hip 0.1 (gfx950)"; }
 static int g_default_precision = EG_PREC_F32;
 extern "C" int eg_set_default_precision(int p) {

@@ -59,6 +59,9 @@ int eg_get_default_precision(void);
 /* Number of kernel launches the library has issued in this process (every launch function counts; captured launches count when they are
  * recorded, not when a hipGraph replays them).  bench.py reports launches per step from differences of this counter. */
 int64_t eg_launch_count(void);
+/* Diagnostic (process started with EG_LAUNCH_HIST=1, else empty): launches by launch-site label since the last reset, as "label count\n" lines
+ * written NUL-terminated into buf (truncated to cap); returns the bytes the full text needs.  reset != 0 clears the counts. */
+int64_t eg_launch_histogram(char* buf, int64_t cap, int32_t reset);
 /* Optional per-launch timing of the contraction kernels (bench.py's roofline leg; a debugging facility, process
  * global, not thread safe).  While enabled, every eg_conv3x3 / eg_linear launch is bracketed by a hipEvent pair on its
  * own stream (no synchronisation).  eg_profile_read synchronises those events and returns, per record, a tag
