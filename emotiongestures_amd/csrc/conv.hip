@@ -32,6 +32,7 @@ struct ConvArgs {
     // training: a per-INPUT-channel affine applied while the halo tile is staged (the BatchNorm in front of this convolution folded into its operand
     // staging: x' = x * in_scale[ci] + in_shift[ci] for pixels inside the image, zero padding stays zero) -- split-bf16 kernels only
     const float* in_scale = nullptr; const float* in_shift = nullptr;
+    int wrow = 0;                       // channel-split launches: row length of the weight images (the convolution's padded output channels)
     unsigned int* dbg = nullptr;        // diagnostic build only (EG_CONV32_STAMP=1): per-wave phase cycle sums of the persistent 32->32 kernel
 };
 
@@ -199,7 +200,11 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 // Without the LDS weight ring every wave re-read all weights from L1/L2 (170 B/clk/CU demanded at C=128 vs 64 B/clk
 // of L1): the r01a profile's 115 us per 128->128 launch.
 
-template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS, int RING>
+// SPLIT: the workgroup computes the NTT * 16 output channels starting at blockIdx.z * NTT * 16 of a convolution with a.cout channels in all (its
+// weight images' row length `a.wrow`): small batches of the 64- and 128-channel stages have fewer pixel tiles than the chip has CUs (one clip: 8 tiles of
+// 128 -> 128), so the channels are spread over workgroups too.  Same pixel -> (wave, tile, lane) map (WM, MT) and the same K order as the unsplit
+// instantiation: every output element and every pooling partial is bitwise the same, whichever the launch function picks.
+template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS, int RING, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
                                                            const bf8* __restrict__ wlo) {
     using G = ConvGeom<S, TH>;
@@ -220,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles
     // (whole clips at B >= 8); halo rows / columns shared by neighbouring tiles then hit in that XCD's L2.
     int tile_id = blockIdx.x, b = blockIdx.y;
-    {
+    const int c0 = SPLIT ? (int)blockIdx.z * COUTP : 0;        // first output channel of this workgroup
+    if (!SPLIT) {
         const int total = gridDim.x * gridDim.y;
         if ((total & 7) == 0) {
             const int lin = blockIdx.y * gridDim.x + blockIdx.x;
@@ -256,6 +262,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     constexpr int GW = GTOT / 4;
     auto issue_weights = [&](int step, int buf) {
         const int chunk = step / 9, tap = step - chunk * 9;
+        if constexpr (SPLIT) {
+            // the slice's 4 octet rows of COUTP slots are not contiguous in the image (row length a.wrow): per-lane source addresses, the LDS side
+            // stays one contiguous KiB per wave-instruction
+            static_assert(COUNTED, "split instantiations deal whole pieces to the four waves");
+            const size_t rbase = ((size_t)tap * (CIN / 8) + chunk * 4) * a.wrow + c0;
+#pragma unroll
+            for (int p = 0; p < GW; ++p) {
+                const int flat = p * 4 + wave_u;
+                const int img = flat / PIECES, piece = flat - img * PIECES;
+                const int slot = piece * 64 + lane, oct = slot / COUTP, co = slot - oct * COUTP;
+                const bf8* src = (img ? wlo : whi) + rbase + (size_t)oct * a.wrow + co;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(wring + buf * WBUF + img * WIMG + piece * 64), 16, 0, 0);
+            }
+            return;
+        }
         const size_t gbase = ((size_t)tap * (CIN / 8) + chunk * 4) * COUTP;
         if constexpr (PIECES % 4 == 0) {        // every wave copies PIECES / 4 pieces of each image (image known at compile time)
 #pragma unroll
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     for (int n = 0; n < NT; ++n) {
         gsum[n] = (f4){0.f, 0.f, 0.f, 0.f};
         gsq[n] = gsum[n];
-        const int co = (wn * NT + n) * 16 + kq * 4;
+        const int co = c0 + (wn * NT + n) * 16 + kq * 4;
         const f4 bi = a.bias ? *reinterpret_cast<const f4*>(a.bias + co) : (f4){0.f, 0.f, 0.f, 0.f};
         const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
         const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
@@ -484,16 +506,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
             }
         }
         __syncthreads();
-        if (tid < a.cout) {
+        if (tid < (SPLIT ? COUTP : a.cout)) {
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) s += sred[m * COUTP + tid];
-            a.gap[((size_t)b * a.tiles + tile_id) * a.cout + tid] = s;
+            a.gap[((size_t)b * a.tiles + tile_id) * a.cout + c0 + tid] = s;
             if (a.gap2) {
                 float q = 0.f;
 #pragma unroll
                 for (int m = 0; m < WM; ++m) q += sred[(WM + m) * COUTP + tid];
-                a.gap2[((size_t)b * a.tiles + tile_id) * a.cout + tid] = q;
+                a.gap2[((size_t)b * a.tiles + tile_id) * a.cout + c0 + tid] = q;
             }
         }
     }
@@ -1304,6 +1326,29 @@ int launch_conv_bf16(const ConvArgs& a, const bf8* whi, const bf8* wlo, dim3 gri
     return eg_check_launch("conv3x3");
 }
 
+// Channel-split launch of a stride-1 body convolution: NTS * 16 output channels per workgroup, grid.z = cout / (NTS * 16) (conv3x3_bf16_kernel, SPLIT).
+template <int CIN, int NTS, int TH, int WM, int WN, int TERMS>
+int launch_conv_split_t(ConvArgs a, int batch, const bf8* whi, const bf8* wlo, hipStream_t st) {
+    constexpr int RING = 3;
+    using G = ConvGeom<1, TH>;
+    constexpr int NIMG = (TERMS == 3) ? 2 : 1;
+    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(NIMG * 4 * G::PL + RING * NIMG * 4 * NTS * 16);
+    auto kern = conv3x3_bf16_kernel<CIN, NTS, 1, TH, WM, WN, TERMS, RING, true>;
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (channel split)")) return rc;
+    a.wrow = a.cout;
+    hipLaunchKernelGGL(kern, dim3(a.tiles, batch, a.cout / (NTS * 16)), dim3(256), LDS_BYTES, st, a, whi, wlo);
+    return eg_check_launch("conv3x3 (channel split)");
+}
+// how many ways to split the channels of a C -> C body convolution with `wgs` pixel-tile workgroups: keep the launch near one workgroup per CU
+int conv_channel_split(int wgs, int max_split) {
+    const char* e = getenv("EG_CONV_SPLIT");            // A/B switch, read per call: 1 = never, 2, 4 (a captured graph keeps what it was captured with)
+    const int forced = (e && e[0]) ? atoi(e) : -1;
+    if (forced >= 0) return (forced == 2 || forced == 4) && forced <= max_split ? forced : 1;
+    int split = 1;
+    while (split < max_split && wgs * split * 2 <= 256) split *= 2;
+    return split;
+}
+
 template <int CIN, int NT, int S, int TH, int WM, int WN>
 int launch_conv(const ConvArgs& a, int batch, int precision, hipStream_t st) {
     dim3 grid(a.tiles, batch), block(256);
@@ -1501,6 +1546,16 @@ int conv3x3_dispatch(const float* x, const float* w, const float* bias, const fl
     if (cin == 32 && coutp == 32 && stride == 1 && th == 4) return launch_conv<32, 2, 1, 4, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 32 && stride == 1) return launch_conv<32, 2, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 32 && coutp == 64 && stride == 2) return launch_conv<32, 4, 2, 2, 2, 2>(a, batch, precision, st);
+    if ((cin == 64 || cin == 128) && cout == cin && stride == 1 && precision == EG_PREC_BF16X3 && !nchw_out) {
+        // few pixel tiles (small batches): spread the output channels over workgroups as well -- bitwise the unsplit kernels below
+        const int split = conv_channel_split(a.tiles * batch, cin == 128 ? 4 : 2);
+        const size_t f32_floats = (size_t)9 * cin * cout;
+        const bf8* whi = reinterpret_cast<const bf8*>(a.w + f32_floats);
+        const bf8* wlo = whi + (size_t)9 * (cin / 8) * cout;
+        if (cin == 64 && split == 2) return launch_conv_split_t<64, 2, 8, 4, 1, 3>(a, batch, whi, wlo, st);
+        if (cin == 128 && split == 2) return launch_conv_split_t<128, 4, 4, 2, 2, 3>(a, batch, whi, wlo, st);
+        if (cin == 128 && split == 4) return launch_conv_split_t<128, 2, 4, 2, 2, 3>(a, batch, whi, wlo, st);
+    }
     if (cin == 64 && coutp == 64 && stride == 1) return launch_conv<64, 4, 1, 8, 4, 1>(a, batch, precision, st);
     if (cin == 64 && coutp == 128 && stride == 2) return launch_conv<64, 8, 2, 2, 2, 2>(a, batch, precision, st);
     if (cin == 64 && coutp == 128 && stride == 1) return launch_conv<64, 8, 1, 4, 2, 2>(a, batch, precision, st);      // training: input gradient of final_conv1 (dy padded to 64 channels)

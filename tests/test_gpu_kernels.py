@@ -395,3 +395,37 @@ def test_conv32_teams_kernel_is_bitwise_the_persistent_kernel(monkeypatch):
         with torch.no_grad():
             poses[teams] = model(inp["spec"], inp["text"], inp["pre_pose"], inp["sampled"])[0].clone()
     assert torch.equal(poses["3"], poses[None])
+
+
+def test_channel_split_convolutions_are_bitwise_the_unsplit_kernels(monkeypatch):
+    """csrc/conv.hip conv3x3_bf16_kernel<..., SPLIT>: at small batches the 64 -> 64 and 128 -> 128 convolutions have fewer pixel tiles than the chip has
+    CUs, so the launch function also spreads the output channels over workgroups (EG_CONV_SPLIT = 1 | 2 | 4 forces a split; default: by tile count).
+    Same pixel -> lane map and K order: output map and pooling partials are bit-identical whatever the split -- so the result of a clip does not
+    depend on the batch it travels in -- with the fused SE tail (gate + residual + ReLU) as well."""
+    from emotiongestures_amd import _lib as L, ops
+    from emotiongestures_amd.engine import _ptr, _stream
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    for (c, B, H, W, splits) in ((128, 1, 32, 31, ("2", "4")), (128, 3, 17, 40, ("2", "4")), (64, 1, 64, 62, ("2",)), (64, 2, 21, 33, ("2",)), (128, 16, 32, 31, ("2", "4"))):
+        x = torch.randn(B, H, W, c, generator=g).to(dev)
+        w = (torch.randn(c, c, 3, 3, generator=g) * 0.05)
+        res = torch.randn(B, H, W, c, generator=g).to(dev)
+        gate = torch.rand(B, c, generator=g).to(dev)
+        sc, sh = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+        wp = ops.pack_conv3x3_weight(w, dev)[0]
+        tiles = int(lib.eg_conv3x3_gap_tiles(H, W, c, c, 1))
+        outs = {}
+        for split in ("1",) + splits + (None,):
+            if split is None:
+                monkeypatch.delenv("EG_CONV_SPLIT", raising=False)
+            else:
+                monkeypatch.setenv("EG_CONV_SPLIT", split)
+            y, gap = ops.conv3x3(x, w, relu=True, want_gap=True, precision="bf16x3", packed=(wp, None, None, None))
+            y2, gap2 = torch.empty_like(x), torch.empty(B, tiles, c, device=dev)
+            L.check(lib.eg_conv3x3_se(_ptr(x), _ptr(wp), None, _ptr(sc), _ptr(sh), _ptr(gate), _ptr(res), _ptr(y2), _ptr(gap2), B, H, W, c, c, 1, 0, 0, 2,
+                                      _stream(dev)), "eg_conv3x3_se")
+            outs[split] = (y.clone(), gap.clone(), y2, gap2)
+        for split in splits + (None,):
+            for a, b in zip(outs[split], outs["1"]):
+                assert torch.equal(a, b), (c, B, H, W, split)
