@@ -823,6 +823,100 @@ int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko
     return x3 ? launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
 }
 
+// ---- products of ONE clip (M <= 64 rows) ------------------------------------------------------------------------------------------------------
+// A single clip's rows fill one tile: the tiled kernels above then run 16-64 barriered K steps on a handful of workgroups (a 512 -> 512 product of 34
+// rows: 16 workgroups, ~10 us, almost all of it LDS-DMA latency and barriers).  Here a workgroup owns 16 output columns for ALL rows; its four waves
+// take the K steps round robin (wave w: steps w, w + 4, ...), every operand goes global -> registers as 16-byte loads (the X rows are L2 resident,
+// a weight element is used once per row tile: nothing to share through LDS), four steps of loads are in flight before the first MFMA, and the four
+// partial accumulators are folded through LDS in a fixed order (wave 0 .. 3) by the wave that then runs the row tile's epilogue.  N / 16 workgroups,
+// no barrier in the K loop, no LDS-DMA.  XF32: X is fp32 rows (split in registers; a_shift honoured) instead of pre-split images.
+template <int RT, bool XF32>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
+    constexpr int B = 4;                                   // K steps per batch of loads
+    __shared__ f4 red[4][RT][64];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16, KO = a.ldw >> 3;
+    const int nsteps = (a.K + 31) >> 5;
+    const bf8* __restrict__ wh = reinterpret_cast<const bf8*>(a.whi) + ((size_t)(n0 >> 6) * KO) * 64 + (n0 & 63) + li;
+    const bf8* __restrict__ wl = reinterpret_cast<const bf8*>(a.wlo) + ((size_t)(n0 >> 6) * KO) * 64 + (n0 & 63) + li;
+    struct Frag { bf8 wh, wl, xh[RT], xl[RT]; };
+    auto load = [&](Frag& f, int step) {                   // step < nsteps
+        const int ko = step * 4 + kq;
+        f.wh = wh[(size_t)ko * 64];
+        f.wl = wl[(size_t)ko * 64];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            if constexpr (XF32) {
+                const int m = t * 16 + li, k = ko * 8;
+                split_octet<true>(load_x_quad(a, m, k, a.K), load_x_quad(a, m, k + 4, a.K), f.xh[t], f.xl[t]);
+            } else {
+                const size_t gx = (size_t)(a.xoct0 + ko) * 64 + t * 16 + li;
+                f.xh[t] = xhi[gx];
+                f.xl[t] = xlo[gx];
+            }
+        }
+    };
+    f4 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+    auto mfma = [&](const Frag& f) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl, f.xh[t], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh, f.xl[t], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh, f.xh[t], acc[t], 0, 0, 0);
+        }
+    };
+    // this wave's steps: wave, wave + 4, ...; batches of B with the next batch's loads issued before the current batch's MFMAs
+    const int mine = (nsteps - wave + 3) >> 2;
+    Frag fa[B], fb[B];
+    auto load_batch = [&](Frag (&f)[B], int first) {       // steps first .. first + B - 1 of this wave's list
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+            if (first + j < mine) load(f[j], wave + 4 * (first + j));
+    };
+    auto mfma_batch = [&](const Frag (&f)[B], int first) {
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+            if (first + j < mine) mfma(f[j]);
+    };
+    load_batch(fa, 0);
+#pragma unroll 1
+    for (int s = 0; s < mine; s += 2 * B) {
+        if (s + B < mine) load_batch(fb, s + B);
+        mfma_batch(fa, s);
+        if (s + 2 * B < mine) load_batch(fa, s + 2 * B);
+        mfma_batch(fb, s + B);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) red[wave][t][lane] = acc[t];
+    __syncthreads();
+    // row tile t is finished by wave t % 4 (RT <= 4: one tile per wave)
+    if (wave < RT) {
+        f4 v[1][1];
+        v[0][0] = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+        gemm_epilogue<1, 1>(a, v, wave * 16 + li, n0 + kq * 4);
+    }
+}
+template <bool XF32>
+int launch_skinny(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, hipStream_t st) {
+    const dim3 grid(eg_cdiv(a.N, 16)), block(256);
+    switch (eg_cdiv(a.M, 16)) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
+    }
+    return eg_check_launch("gemm (one clip)");
+}
+// one clip's rows, split-bf16, no training masks, no split-K request: the skinny kernel.  EG_GEMM_SKINNY=0 keeps the tiled kernels (A/B switch, read per call).
+bool skinny_ok(const GemmArgs& a, int precision) {
+    if (a.M > 64 || precision != EG_PREC_BF16X3 || a.gate || a.drop.thr || a.partial) return false;
+    const char* e = getenv("EG_GEMM_SKINNY");
+    return !(e && e[0] == '0');
+}
+
 // fp32 [M, K] (row stride lda) -> bf16 (hi, lo) tile-planar images [ceil(M/64)][Kpad/8][64][8]; rows >= M and k >= K are zero.
 __global__ __launch_bounds__(256) void split_tile_kernel(const float* __restrict__ x, int lda, int M, int K, int KO,
                                                          bf8* __restrict__ hi, bf8* __restrict__ lo) {
@@ -931,6 +1025,10 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xhi = reinterpret_cast<const bf8*>(p.ximg);
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
+        if (skinny_ok(a, p.precision)) {        // one clip: 16 columns per workgroup, K over the waves, no LDS staging (replaces the split-K request too)
+            prof.workgroups(eg_cdiv(a.N, 16));
+            return launch_skinny<false>(a, xhi, xlo, xko, st);
+        }
         if (p.splits > 1) {
             // a single clip (one or two row tiles) and a deep K: 64 serial K steps on a handful of workgroups.  Split K over workgroup slices (64 x 64
             // tile, blockIdx.z) and fold the partials in a fixed order with the whole epilogue (bias, residual, ReLU): shorter wall time for one more launch.
@@ -948,6 +1046,10 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         return dispatch_presplit(a, xhi, xlo, xko, p.precision, st, &prof, p.shared_chip);
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
+    if (skinny_ok(a, p.precision)) {
+        prof.workgroups(eg_cdiv(a.N, 16));
+        return launch_skinny<true>(a, nullptr, nullptr, 0, st);
+    }
     prof.workgroups(eg_cdiv(p.m, 64) * eg_cdiv(p.n, 64));
     return launch_gemm(a, 1, p.precision, st);
 }
@@ -965,6 +1067,7 @@ extern "C" int eg_linear(const float* x, int32_t lda, const float* w, int32_t ld
     a.bias = bias; a.res1 = res1; a.res2 = res2; a.ldr = ldr; a.y = y; a.ldc = ldc; a.relu = relu;
     a.a_shift = a_shift; a.a_seq = a_seq > 0 ? a_seq : 1; a.k_per_split = (int)eg_round_up(k, 64); a.partial = nullptr;
     EgProfScope prof(precision == EG_PREC_F32 ? 5 : (a_shift ? 4 : 2), 2.0 * m * (double)n * k, (hipStream_t)stream);
+    if (skinny_ok(a, precision)) return launch_skinny<true>(a, nullptr, nullptr, 0, (hipStream_t)stream);      // one clip's rows
     return launch_gemm(a, 1, precision, (hipStream_t)stream);
 }
 

@@ -429,3 +429,46 @@ def test_channel_split_convolutions_are_bitwise_the_unsplit_kernels(monkeypatch)
         for split in splits + (None,):
             for a, b in zip(outs[split], outs["1"]):
                 assert torch.equal(a, b), (c, B, H, W, split)
+
+
+def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatch):
+    """csrc/gemm.hip gemm_skinny_kernel (M <= 64 rows, bf16x3: 16 output columns per workgroup, K steps dealt to the four waves, operands straight from
+    global memory, fixed-order fold): against a float64 reference within the split-bf16 bound, and against the tiled kernels (EG_GEMM_SKINNY=0) at
+    summation-order noise -- ragged M / N / K, bias, ReLU, both residual forms and the causal row shift (a_shift) included."""
+    from emotiongestures_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    for (M, K, N, kw) in ((34, 512, 512, {}), (1, 512, 1536, dict(bias=True)), (64, 2048, 512, dict(bias=True, res1=True)), (16, 300, 126, dict(bias=True, relu=True)),
+                          (60, 128, 512, dict(bias=True, res1=True, relu=True, res2=True)), (34, 124, 512, dict(bias=True)), (47, 512, 2048, dict(bias=True, relu=True)),
+                          (34, 512, 512, dict(bias=True, a_shift=4, a_seq=34)), (68, 512, 512, dict(bias=True))):
+        x = torch.randn(M, K, generator=g).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+        b = torch.randn(N, generator=g).to(dev) if kw.get("bias") else None
+        r1 = torch.randn(M, N, generator=g).to(dev) if kw.get("res1") else None
+        r2 = torch.randn(M, N, generator=g).to(dev) if kw.get("res2") else None
+        sh, sq = kw.get("a_shift", 0), kw.get("a_seq", 0)
+        outs = {}
+        for sk in ("0", "1"):
+            monkeypatch.setenv("EG_GEMM_SKINNY", sk)
+            outs[sk] = ops.linear(x, w, b, r1, r2, relu=bool(kw.get("relu")), a_shift=sh, a_seq=sq, precision="bf16x3")
+        xs = x.double()
+        if sh:
+            xs = torch.zeros_like(xs)
+            for m in range(M):
+                if m % sq >= sh:
+                    xs[m] = x[m - sh].double()
+        ref = xs @ w.double().T
+        if b is not None:
+            ref = ref + b.double()
+        if r1 is not None:
+            ref = ref + r1.double()
+        if kw.get("relu"):
+            ref = ref.clamp_min(0)
+        if r2 is not None:
+            ref = (ref + r2.double()).clamp_min(0)
+        refn = ref.cpu().numpy()
+        for sk in ("0", "1"):
+            e = rel_l2(outs[sk].double().cpu().numpy(), refn)
+            assert e < 2e-5, (M, K, N, kw, sk, e)
+        e = rel_l2(outs["1"].cpu().numpy(), outs["0"].cpu().numpy())
+        assert e < 2e-6, (M, K, N, kw, e)

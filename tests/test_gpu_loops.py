@@ -154,8 +154,26 @@ def test_k_fold_loop_two_gloo_ranks_share_this_gpu(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_ROOT=ROOT)
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=900)[0] for p in procs]
+        log = open(tmp_path / f"rank{r}.log", "w+")         # files, not pipes: a rank that waits for a dead peer still leaves the peer's last words readable
+        procs.append((subprocess.Popen([sys.executable, str(script)], env=env, stdout=log, stderr=subprocess.STDOUT, text=True), log))
+    import time
+    deadline = time.time() + 600
+    while time.time() < deadline and any(p.poll() is None for p, _ in procs):
+        if any(p.poll() not in (None, 0) for p, _ in procs):       # one rank died: do not sit out the other's collective timeout
+            break
+        time.sleep(0.5)
+    hung = [r for r, (p, _) in enumerate(procs) if p.poll() is None]
+    for p, _ in procs:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+    outs = []
+    for _, log in procs:
+        log.seek(0)
+        outs.append(log.read())
+        log.close()
+    procs = [p for p, _ in procs]
+    assert not hung, "rank(s) %s still running at the deadline\n" % hung + "\n".join(f"--- rank {r}:\n{o[-3000:]}" for r, o in enumerate(outs))
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}:\\n{o[-3000:]}"
     # the two ranks saw different batches: their per-iteration losses differ, their parameters (checked in the workers) do not
