@@ -1344,8 +1344,10 @@ int conv_channel_split(int wgs, int max_split) {
     const char* e = getenv("EG_CONV_SPLIT");            // A/B switch, read per call: 1 = never, 2, 4 (a captured graph keeps what it was captured with)
     const int forced = (e && e[0]) ? atoi(e) : -1;
     if (forced >= 0) return (forced == 2 || forced == 4) && forced <= max_split ? forced : 1;
+    // measured (tools/conv_b1_probe.py, us per launch, unsplit / 2 / 4): 128 ch. 64 tiles 26.9 / 18.9 / 15.3, 128 tiles 28.6 / 20.7 / 20.8, 256 tiles
+    // 31.1 / 30.7 / 37.0; 64 ch. 128 tiles 18.4 / 13.9, 256 tiles 20.1 / 19.6, 512 tiles 29.7 / 37.6 -- split while the launch stays within two workgroups per CU
     int split = 1;
-    while (split < max_split && wgs * split * 2 <= 256) split *= 2;
+    while (split < max_split && wgs * split * 2 <= 512) split *= 2;
     return split;
 }
 

@@ -7,7 +7,7 @@ from emotiongestures_amd import ops
 
 dev = torch.device("cuda:0")
 for (c, h, w) in ((128, 32, 31), (64, 64, 62), (32, 128, 124)):
-    for B in (1, 2, 4, 16, 64):
+    for B in (1, 4, 8, 16, 32, 64):
         x = torch.randn(B, h, w, c, device=dev)
         ws = [torch.randn(c, c, 3, 3, device=dev) * 0.05 for _ in range(40)]
         packs = [ops.conv3x3_pack(wt, None, None, None, dev) for wt in ws]
