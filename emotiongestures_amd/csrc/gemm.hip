@@ -823,23 +823,26 @@ int dispatch_presplit(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko
     return x3 ? launch_presplit<3, 32, 4>(a, xhi, xlo, xko, grid, st) : launch_presplit<1, 32, 4>(a, xhi, xlo, xko, grid, st);
 }
 
-// ---- products of ONE clip (M <= 64 rows) ------------------------------------------------------------------------------------------------------
-// A single clip's rows fill one tile: the tiled kernels above then run 16-64 barriered K steps on a handful of workgroups (a 512 -> 512 product of 34
-// rows: 16 workgroups, ~10 us, almost all of it LDS-DMA latency and barriers).  Here a workgroup owns 16 output columns for ALL rows; its four waves
-// take the K steps round robin (wave w: steps w, w + 4, ...), every operand goes global -> registers as 16-byte loads (the X rows are L2 resident,
-// a weight element is used once per row tile: nothing to share through LDS), four steps of loads are in flight before the first MFMA, and the four
-// partial accumulators are folded through LDS in a fixed order (wave 0 .. 3) by the wave that then runs the row tile's epilogue.  N / 16 workgroups,
-// no barrier in the K loop, no LDS-DMA.  XF32: X is fp32 rows (split in registers; a_shift honoured) instead of pre-split images.
-template <int RT, bool XF32>
+// ---- products of few rows (one clip: M <= 64 by default) ------------------------------------------------------------------
+// With few row tiles the tiled kernels above run 16-64 barriered K steps on a handful of workgroups (a 512 -> 512 product of 34 rows: 16 workgroups,
+// ~10 us; of 544 rows: 72 workgroups, ~11 us -- almost all of it LDS-DMA latency and barriers).  Here a workgroup owns 16 output columns of a 64-row
+// block; its four waves take the K steps round robin (wave w: steps w, w + 4, ...), every operand goes global -> registers as 16-byte loads (the X rows
+// are L2 resident and L2 feeds the 32 column workgroups that re-read them; a weight element is used once per row tile: nothing to share through LDS),
+// four steps of loads are in flight before the first MFMA, and the four partial accumulators are folded through LDS in a fixed order (wave 0 .. 3) by
+// the wave that then runs the row tile's epilogue.  (N / 16) x (M / 64) workgroups, no barrier in the K loop, no LDS-DMA.  A row's result depends on
+// K only (not on M): bitwise the same whatever batch the row travels in, as long as the batch stays in this kernel's range.
+// XF32: X is fp32 rows (split in registers; a_shift honoured) instead of pre-split images.  TRAIN: the training epilogue's masks compiled in.
+template <int RT, bool XF32, bool TRAIN>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a, const bf8* __restrict__ xhi, const bf8* __restrict__ xlo, int xKO) {
     constexpr int B = 4;                                   // K steps per batch of loads
     __shared__ f4 red[4][RT][64];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * 16, KO = a.ldw >> 3;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64, KO = a.ldw >> 3;
     const int nsteps = (a.K + 31) >> 5;
     const bf8* __restrict__ wh = reinterpret_cast<const bf8*>(a.whi) + ((size_t)(n0 >> 6) * KO) * 64 + (n0 & 63) + li;
     const bf8* __restrict__ wl = reinterpret_cast<const bf8*>(a.wlo) + ((size_t)(n0 >> 6) * KO) * 64 + (n0 & 63) + li;
+    const size_t xtile = (size_t)blockIdx.y * xKO * 64;    // this row block's X image tile
     struct Frag { bf8 wh, wl, xh[RT], xl[RT]; };
     auto load = [&](Frag& f, int step) {                   // step < nsteps
         const int ko = step * 4 + kq;
@@ -848,10 +851,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a, const bf8*
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             if constexpr (XF32) {
-                const int m = t * 16 + li, k = ko * 8;
+                const int m = m0 + t * 16 + li, k = ko * 8;
                 split_octet<true>(load_x_quad(a, m, k, a.K), load_x_quad(a, m, k + 4, a.K), f.xh[t], f.xl[t]);
             } else {
-                const size_t gx = (size_t)(a.xoct0 + ko) * 64 + t * 16 + li;
+                const size_t gx = xtile + (size_t)(a.xoct0 + ko) * 64 + t * 16 + li;
                 f.xh[t] = xhi[gx];
                 f.xl[t] = xlo[gx];
             }
@@ -892,29 +895,40 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a, const bf8*
 #pragma unroll
     for (int t = 0; t < RT; ++t) red[wave][t][lane] = acc[t];
     __syncthreads();
-    // row tile t is finished by wave t % 4 (RT <= 4: one tile per wave)
+    // row tile t is finished by wave t (RT <= 4: one tile per wave)
     if (wave < RT) {
         f4 v[1][1];
         v[0][0] = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
-        gemm_epilogue<1, 1>(a, v, wave * 16 + li, n0 + kq * 4);
+        gemm_epilogue<1, 1, TRAIN>(a, v, m0 + wave * 16 + li, n0 + kq * 4);
     }
+}
+template <bool XF32, bool TRAIN>
+int launch_skinny_t(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, hipStream_t st) {
+    const dim3 grid(eg_cdiv(a.N, 16), eg_cdiv(a.M, 64)), block(256);
+    switch (a.M > 64 ? 4 : eg_cdiv(a.M, 16)) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, XF32, TRAIN>), grid, block, 0, st, a, xhi, xlo, xko); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, XF32, TRAIN>), grid, block, 0, st, a, xhi, xlo, xko); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, XF32, TRAIN>), grid, block, 0, st, a, xhi, xlo, xko); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, XF32, TRAIN>), grid, block, 0, st, a, xhi, xlo, xko); break;
+    }
+    return eg_check_launch("gemm (few rows)");
 }
 template <bool XF32>
 int launch_skinny(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, hipStream_t st) {
-    const dim3 grid(eg_cdiv(a.N, 16)), block(256);
-    switch (eg_cdiv(a.M, 16)) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, XF32>), grid, block, 0, st, a, xhi, xlo, xko); break;
-    }
-    return eg_check_launch("gemm (one clip)");
+    if (a.gate || a.drop.thr) return launch_skinny_t<XF32, true>(a, xhi, xlo, xko, st);
+    return launch_skinny_t<XF32, false>(a, xhi, xlo, xko, st);
 }
-// one clip's rows, split-bf16, no training masks, no split-K request: the skinny kernel.  EG_GEMM_SKINNY=0 keeps the tiled kernels (A/B switch, read per call).
+// few rows, split-bf16, no split-K request: the skinny kernel.  Row limit: EG_GEMM_SKINNY_ROWS (read per call; 0 keeps the tiled kernels; default below).
+// One clip (<= 64 rows) is where it wins (1.26 -> 1.10 ms per clip end to end).  With more row blocks every one of the N / 16 column workgroups re-reads
+// and re-splits the block's X rows: at the 16-clip training step's 544 rows the step went 7.69 -> 8.42 ms, at 1088 rows 10.4 -> 12.9 ms (same box,
+// bench.py --train, twice each) -- the LDS-tiled kernels keep everything above one row block.
+constexpr int SKINNY_ROWS_DEFAULT = 64;
 bool skinny_ok(const GemmArgs& a, int precision) {
-    if (a.M > 64 || precision != EG_PREC_BF16X3 || a.gate || a.drop.thr || a.partial) return false;
-    const char* e = getenv("EG_GEMM_SKINNY");
-    return !(e && e[0] == '0');
+    if (precision != EG_PREC_BF16X3 || a.partial) return false;
+    int limit = SKINNY_ROWS_DEFAULT;
+    if (const char* e = getenv("EG_GEMM_SKINNY_ROWS")) limit = atoi(e);
+    if (const char* e = getenv("EG_GEMM_SKINNY")) { if (e[0] == '0') limit = 0; }
+    return a.M <= limit;
 }
 
 // fp32 [M, K] (row stride lda) -> bf16 (hi, lo) tile-planar images [ceil(M/64)][Kpad/8][64][8]; rows >= M and k >= K are zero.
@@ -1026,7 +1040,7 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = p.xk0 >> 3;
         if (skinny_ok(a, p.precision)) {        // one clip: 16 columns per workgroup, K over the waves, no LDS staging (replaces the split-K request too)
-            prof.workgroups(eg_cdiv(a.N, 16));
+            prof.workgroups(eg_cdiv(a.N, 16) * eg_cdiv(a.M, 64));
             return launch_skinny<false>(a, xhi, xlo, xko, st);
         }
         if (p.splits > 1) {
@@ -1047,7 +1061,7 @@ int egi_linear(const EgiLinear& p, hipStream_t st) {
     }
     EG_REQUIRE(p.x && (p.lda & 3) == 0, EG_ERR_BAD_ARG, "egi_linear: fp32 input missing");
     if (skinny_ok(a, p.precision)) {
-        prof.workgroups(eg_cdiv(a.N, 16));
+        prof.workgroups(eg_cdiv(a.N, 16) * eg_cdiv(a.M, 64));
         return launch_skinny<true>(a, nullptr, nullptr, 0, st);
     }
     prof.workgroups(eg_cdiv(p.m, 64) * eg_cdiv(p.n, 64));
@@ -1119,9 +1133,11 @@ extern "C" int eg_linear_ex(const EgLinearArgs* p, void* stream) {
         const bf8* xlo = xhi + (size_t)mt * xko * 64;
         a.xoct0 = 0;
         EgProfScope prof(3, 2.0 * p->m * (double)p->n * p->k, (hipStream_t)stream);
+        if (skinny_ok(a, p->precision)) return launch_skinny<false>(a, xhi, xlo, xko, (hipStream_t)stream);
         return dispatch_presplit(a, xhi, xlo, xko, p->precision, (hipStream_t)stream, &prof, 0);
     }
     EgProfScope prof(p->precision == EG_PREC_F32 ? 5 : 2, 2.0 * p->m * (double)p->n * p->k, (hipStream_t)stream);
+    if (skinny_ok(a, p->precision)) return launch_skinny<true>(a, nullptr, nullptr, 0, (hipStream_t)stream);      // few rows (small training steps)
     return launch_gemm(a, 1, p->precision, (hipStream_t)stream);
 }
 

@@ -432,7 +432,7 @@ def test_channel_split_convolutions_are_bitwise_the_unsplit_kernels(monkeypatch)
 
 
 def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatch):
-    """csrc/gemm.hip gemm_skinny_kernel (M <= 64 rows, bf16x3: 16 output columns per workgroup, K steps dealt to the four waves, operands straight from
+    """csrc/gemm.hip gemm_skinny_kernel (default: M <= 64 rows; here forced on up to 1024 through EG_GEMM_SKINNY_ROWS; bf16x3: 16 output columns of a 64-row block per workgroup, K steps dealt to the four waves, operands straight from
     global memory, fixed-order fold): against a float64 reference within the split-bf16 bound, and against the tiled kernels (EG_GEMM_SKINNY=0) at
     summation-order noise -- ragged M / N / K, bias, ReLU, both residual forms and the causal row shift (a_shift) included."""
     from emotiongestures_amd import ops
@@ -440,7 +440,8 @@ def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatc
     g = torch.Generator().manual_seed(31)
     for (M, K, N, kw) in ((34, 512, 512, {}), (1, 512, 1536, dict(bias=True)), (64, 2048, 512, dict(bias=True, res1=True)), (16, 300, 126, dict(bias=True, relu=True)),
                           (60, 128, 512, dict(bias=True, res1=True, relu=True, res2=True)), (34, 124, 512, dict(bias=True)), (47, 512, 2048, dict(bias=True, relu=True)),
-                          (34, 512, 512, dict(bias=True, a_shift=4, a_seq=34)), (68, 512, 512, dict(bias=True))):
+                          (34, 512, 512, dict(bias=True, a_shift=4, a_seq=34)), (68, 512, 512, dict(bias=True)), (544, 512, 512, dict(bias=True, res1=True)),
+                          (544, 2048, 512, dict(bias=True, relu=True)), (300, 512, 2048, dict(bias=True)), (1000, 128, 126, dict(bias=True, a_shift=2, a_seq=50))):
         x = torch.randn(M, K, generator=g).to(dev)
         w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
         b = torch.randn(N, generator=g).to(dev) if kw.get("bias") else None
@@ -448,6 +449,7 @@ def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatc
         r2 = torch.randn(M, N, generator=g).to(dev) if kw.get("res2") else None
         sh, sq = kw.get("a_shift", 0), kw.get("a_seq", 0)
         outs = {}
+        monkeypatch.setenv("EG_GEMM_SKINNY_ROWS", "1024")
         for sk in ("0", "1"):
             monkeypatch.setenv("EG_GEMM_SKINNY", sk)
             outs[sk] = ops.linear(x, w, b, r1, r2, relu=bool(kw.get("relu")), a_shift=sh, a_seq=sq, precision="bf16x3")
