@@ -1,8 +1,11 @@
-python -m pytest tests/test_gpu_kernels.py -q -x -k "one_clip_products" > gpurun_out/_t0.txt 2>&1; tail -3 gpurun_out/_t0.txt | cut -c1-250; grep -n "^E " gpurun_out/_t0.txt | head -5
-run() { EG_GEMM_SKINNY_ROWS=$1 python bench.py --train --train-batch $2 --steps 30 --warmup 5 --no-extra-legs 2>gpurun_out/_ab_err.txt | tail -1 | python -c "
-import sys,json
-try:
-    d=json.loads(sys.stdin.read()); print('skinny_rows=$1','b',$2, d.get('ms_per_step'), d.get('library_launches_per_step'), d.get('final_loss'))
-except Exception as e: print('fail',$2,e)"; }
-for i in 1 2; do for f in 64 1024 4096; do run $f 16; run $f 32; done; done
-run 64 128; run 8192 128
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+bash tools/profile_round.sh r05u > gpurun_out/r05u_profile_round.log 2>&1
+rm -rf gpurun_out/prof_b1n; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1n -- python3 tools/profile_b1.py > gpurun_out/_b1prof.log 2>&1
+python3 tools/rocprof_summary.py gpurun_out/prof_b1n gpurun_out/r05u_kernel_stats_b1.md; rm -rf gpurun_out/prof_b1n
+python bench.py 2>gpurun_out/r05u_bench_err.txt | tail -1 > gpurun_out/r05u_bench_line.json
+python -c "
+import json
+d=json.load(open('gpurun_out/r05u_bench_line.json')); e=d.get('extra_legs',{}); t=d.get('train',{})
+print('headline', d['value'], d['ms_per_step'], 'frac', d['roofline']['frac'], 'b1', e.get('gpu_b1',{}).get('latency_ms_median'), 'beat_long', e.get('beat_long',{}).get('value'), 'div', e.get('diversity_32',{}).get('value'))
+print({k:(v.get('ms_per_step'), v.get('library_launches_per_step')) for k,v in t.items() if isinstance(v,dict)})"
+ls gpurun_out/r05u_* | head -30
