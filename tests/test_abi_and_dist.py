@@ -180,3 +180,16 @@ def test_pipeline_argument_validation_without_gpu():
         ClipPipeline((None, None, None), {}, "cuda:0", lanes=0)
     with pytest.raises(RuntimeError):
         ClipPipeline((None, None, None), {}, "cpu", lanes=2)
+
+
+def test_launch_histogram_is_empty_unless_enabled_and_reports_its_size():
+    """eg_launch_histogram (diagnostic): without EG_LAUNCH_HIST=1 nothing is counted -- the text is empty, the call returns the one byte of its NUL and
+    tolerates a null / too small buffer; host-only, no GPU call."""
+    import ctypes
+    from emotiongestures_amd import _lib as L
+    lib = L.load()
+    if os.environ.get("EG_LAUNCH_HIST") == "1":
+        pytest.skip("histogram enabled in this environment")
+    assert int(lib.eg_launch_histogram(None, 0, 0)) == 1
+    buf = ctypes.create_string_buffer(8)
+    assert int(lib.eg_launch_histogram(buf, len(buf), 1)) == 1 and buf.value == b""
