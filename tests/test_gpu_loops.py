@@ -130,10 +130,11 @@ _WORKER = textwrap.dedent('''
     from emotiongestures_amd.train import loops
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    print("rank", rank, "process group up", flush=True)
     dev = torch.device("cuda:0")
     ds = build_dataset()
     hist = loops.train_k_fold(ds, device=dev, n_splits=2, total_epoch=1, batch_size=2, lr=1e-4, val_every=100, seed=1, max_iters_per_fold=3, folds=[1],
-                              log=lambda s: None)
+                              log=lambda s: print("rank", rank, s, flush=True))
     flat = torch.cat([p.detach().reshape(-1) for p in hist[0]["model"].parameters()]).cpu()
     other = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(other, flat)
@@ -144,37 +145,50 @@ _WORKER = textwrap.dedent('''
 ''')
 
 
-def test_k_fold_loop_two_gloo_ranks_share_this_gpu(tmp_path):
+def _run_two_ranks(tmp_path, attempt):
+    """-> (return codes or None for a rank killed at the deadline, logs)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    import socket
+    import socket, time
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_ROOT=ROOT)
-        log = open(tmp_path / f"rank{r}.log", "w+")         # files, not pipes: a rank that waits for a dead peer still leaves the peer's last words readable
+        log = open(tmp_path / f"rank{r}_{attempt}.log", "w+")      # files, not pipes: a rank that waits for a dead peer still leaves the peer's last words readable
         procs.append((subprocess.Popen([sys.executable, str(script)], env=env, stdout=log, stderr=subprocess.STDOUT, text=True), log))
-    import time
-    deadline = time.time() + 600
+    deadline = time.time() + 420
     while time.time() < deadline and any(p.poll() is None for p, _ in procs):
         if any(p.poll() not in (None, 0) for p, _ in procs):       # one rank died: do not sit out the other's collective timeout
             break
         time.sleep(0.5)
-    hung = [r for r, (p, _) in enumerate(procs) if p.poll() is None]
+    codes = []
     for p, _ in procs:
         if p.poll() is None:
             p.kill()
             p.wait()
+            codes.append(None)
+        else:
+            codes.append(p.returncode)
     outs = []
     for _, log in procs:
         log.seek(0)
         outs.append(log.read())
         log.close()
-    procs = [p for p, _ in procs]
-    assert not hung, "rank(s) %s still running at the deadline\n" % hung + "\n".join(f"--- rank {r}:\n{o[-3000:]}" for r, o in enumerate(outs))
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r}:\\n{o[-3000:]}"
+    return codes, outs
+
+
+def test_k_fold_loop_two_gloo_ranks_share_this_gpu(tmp_path):
+    codes, outs = _run_two_ranks(tmp_path, 0)
+    if None in codes and not all("process group up" in o for o in outs):
+        # the ranks never met (the probed port was taken in between, a slow peer start): a rendezvous problem, not the loop's -- one more try on a new
+        # port; a rank that hangs AFTER the group is up fails the test below
+        import warnings
+        warnings.warn("two-rank rendezvous did not complete, retrying once:\n" + "\n".join(f"--- rank {r}:\n{o[-1500:]}" for r, o in enumerate(outs)))
+        codes, outs = _run_two_ranks(tmp_path, 1)
+    report = "\n".join(f"--- rank {r} (exit {c}):\n{o[-3000:]}" for r, (c, o) in enumerate(zip(codes, outs)))
+    assert None not in codes, "rank(s) still running at the deadline\n" + report
+    assert all(c == 0 for c in codes), report
     # the two ranks saw different batches: their per-iteration losses differ, their parameters (checked in the workers) do not
     assert outs[0].split("ok")[-1] != outs[1].split("ok")[-1]
