@@ -26,7 +26,7 @@ def install_aliases() -> None:
         sys.modules.setdefault(top, pkg)
     for name in ("Full_model.Models_spatial_memory", "Full_model.Models_memory", "Full_model.Layers", "Full_model.SubLayers",
                  "Full_model.Modules", "Full_model.tcn", "Full_model.ResNetSE34V2", "Full_model.ResNetBlocks", "CAVE.BEAT_CVAE",
-                 "model.FGD", "model.FHD_score", "model.audio_emotion_classifer", "model.motion_ae", "model.embedding_space_evaluator",
+                 "model.FGD", "model.FHD_score", "model.Beat_score_v2", "model.audio_emotion_classifer", "model.motion_ae", "model.embedding_space_evaluator",
                  "skeleton_classifer.Models", "data_loader.data_preprocessor_expressive", "data_loader.motion_preprocessor_expressive",
                  "data_loader.lmdb_loader_BEAT_full", "utils.train_utils_BEAT", "utils.data_utils_expressive"):
         sys.modules.setdefault(name, importlib.import_module(f"{__name__}.{name}"))

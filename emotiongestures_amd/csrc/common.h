@@ -162,14 +162,6 @@ struct EgProfScope {
     ~EgProfScope();
 };
 
-// ---- fused PositionwiseFeedForward slab kernel (ffn.hip): pre = w_2(relu(w_1 x + b_1)) + b_2 + x in one launch, split-bf16, d_model 512 ----------------
-int egi_ffn_fused_splits(int d_model, int d_inner, int precision, int rows);      // 0: not taken (two launches); else workgroups per 64-row slab
-int egi_ffn_fused(const void* x_images, const float* x, int ldx, const float* w1, const float* b1, const float* w2, const float* b2, float* pre, int ldp,
-                  int rows, int d_inner, int splits, hipStream_t st);
-// LayerNorm of  (((p_0 + p_1) + ...) + bias) + resid  (the fused FFN's partial sums [nparts][rows][d], folded in order): misc.hip
-int egi_layernorm_sum(const float* parts, int nparts, const float* bias, const float* resid, int ldr, const float* gamma, const float* beta, float* y, void* img,
-                      int rows, int d, float eps, hipStream_t st);
-
 // ---- internal (C++ linkage) product descriptor shared by gemm.hip and generator.hip --------------------------------
 struct EgiLinear {
     const float* x = nullptr; int lda = 0;                          // fp32 input, or ...

@@ -918,15 +918,14 @@ int launch_skinny(const GemmArgs& a, const bf8* xhi, const bf8* xlo, int xko, hi
     if (a.gate || a.drop.thr) return launch_skinny_t<XF32, true>(a, xhi, xlo, xko, st);
     return launch_skinny_t<XF32, false>(a, xhi, xlo, xko, st);
 }
-// few rows, split-bf16, no split-K request: the skinny kernel.  Row limit: EG_GEMM_SKINNY_ROWS (read per call; 0 keeps the tiled kernels; default below).
+// few rows, split-bf16, no split-K request: the skinny kernel (EG_GEMM_SKINNY=0, read per call, keeps the tiled kernels).
 // One clip (<= 64 rows) is where it wins (1.26 -> 1.10 ms per clip end to end).  With more row blocks every one of the N / 16 column workgroups re-reads
 // and re-splits the block's X rows: at the 16-clip training step's 544 rows the step went 7.69 -> 8.42 ms, at 1088 rows 10.4 -> 12.9 ms (same box,
 // bench.py --train, twice each) -- the LDS-tiled kernels keep everything above one row block.
-constexpr int SKINNY_ROWS_DEFAULT = 64;
+constexpr int SKINNY_ROWS = 64;
 bool skinny_ok(const GemmArgs& a, int precision) {
     if (precision != EG_PREC_BF16X3 || a.partial) return false;
-    int limit = SKINNY_ROWS_DEFAULT;
-    if (const char* e = getenv("EG_GEMM_SKINNY_ROWS")) limit = atoi(e);
+    int limit = SKINNY_ROWS;
     if (const char* e = getenv("EG_GEMM_SKINNY")) { if (e[0] == '0') limit = 0; }
     return a.M <= limit;
 }

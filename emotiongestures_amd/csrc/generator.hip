@@ -452,26 +452,13 @@ int run_ffn(const EgGenerator* g, const float* arena, const FfnW& f, const Act& 
             hipStream_t st) {
     const int D = g->cfg.d_model, DI = g->cfg.d_inner;
     float *h = P(ws, w.ffn_h), *pr = P(ws, w.proj);
-    const int splits = (x.img && x.kimg == D && x.f && f.w1.b >= 0 && f.w2.b >= 0 && f.w1.kpad == D && f.w2.kpad == DI)
-                           ? egi_ffn_fused_splits(D, DI, g->cfg.precision, rows) : 0;
-    if (splits > 0) {
-        // one slab kernel, the hidden never leaves the CU (ffn.hip: half the CU time of the two launches below).  splits > 1: the hidden is split over that
-        // many workgroups per slab; their partial sums land in the (otherwise unused) fp32 hidden buffer and the LayerNorm folds them with b_2 and x.
-        if (splits == 1) {
-            EG_TRY(egi_ffn_fused(x.img, x.f, x.ld, arena + f.w1.w, arena + f.w1.b, arena + f.w2.w, arena + f.w2.b, pr, D, rows, DI, 1, st));
-        } else {
-            EG_TRY(egi_ffn_fused(x.img, x.f, x.ld, arena + f.w1.w, arena + f.w1.b, arena + f.w2.w, arena + f.w2.b, h, D, rows, DI, splits, st));
-            return egi_layernorm_sum(h, splits, arena + f.w2.b, x.f, x.ld, arena + f.ln_g, arena + f.ln_b, out.f, out.img, rows, D, 1e-6f, st);
-        }
-    } else {
-        const Act hid = act(h, DI, P(ws, w.im_h), DI);
-        EG_TRY(lin(g, arena, f.w1, x, 0, hid, false, rows, 1, nullptr, 0, st));
-        // ONE clip (<= 64 rows: a single row tile) in a bf16 mode: w_2's 2048-deep product is 64 serial K steps on 8 workgroups; split K four ways (the
-        // fp32 hidden buffer is free in these modes and takes the partials).  Only there: from two clips up every product accumulates K in one order
-        // whatever the batch size, so a clip's pose does not depend on how a batch is chunked (nn.DataParallel's scatter, ClipPipeline's batches).
-        const int sp = (g->cfg.precision != EG_PREC_F32 && rows <= 64 && DI >= 2048 && 4 * D <= DI) ? 4 : 0;
-        EG_TRY(lin(g, arena, f.w2, hid, 0, act(pr, D), true, rows, 0, x.f, D, st, 0, sp, h));
-    }
+    const Act hid = act(h, DI, P(ws, w.im_h), DI);
+    EG_TRY(lin(g, arena, f.w1, x, 0, hid, false, rows, 1, nullptr, 0, st));
+    // ONE clip (<= 64 rows: a single row tile) in a bf16 mode: w_2's 2048-deep product is 64 serial K steps on 8 workgroups; split K four ways (the
+    // fp32 hidden buffer is free in these modes and takes the partials).  Only there: from two clips up every product accumulates K in one order
+    // whatever the batch size, so a clip's pose does not depend on how a batch is chunked (nn.DataParallel's scatter, ClipPipeline's batches).
+    const int sp = (g->cfg.precision != EG_PREC_F32 && rows <= 64 && DI >= 2048 && 4 * D <= DI) ? 4 : 0;
+    EG_TRY(lin(g, arena, f.w2, hid, 0, act(pr, D), true, rows, 0, x.f, D, st, 0, sp, h));
     return egi_layernorm(pr, arena + f.ln_g, arena + f.ln_b, out.f, g->cfg.precision != EG_PREC_F32 ? out.img : nullptr, rows, D, 1e-6f, st);
 }
 

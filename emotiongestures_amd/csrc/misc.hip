@@ -447,16 +447,6 @@ int egi_layernorm(const float* x, const float* gamma, const float* beta, float* 
     else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, im);
     return eg_check_launch("layernorm");
 }
-int egi_layernorm_sum(const float* parts, int nparts, const float* bias, const float* resid, int ldr, const float* gamma, const float* beta, float* y, void* img,
-                      int rows, int d, float eps, hipStream_t st) {
-    EG_REQUIRE(parts && bias && resid && gamma && beta && y && rows > 0 && nparts >= 1, EG_ERR_BAD_ARG, "egi_layernorm_sum: null pointer");
-    EG_REQUIRE(d > 0 && d <= 512 && (d & 63) == 0 && (ldr & 3) == 0, EG_ERR_UNSUPPORTED, "egi_layernorm_sum: D=%d ldr=%d", d, ldr);
-    LnSum ps;
-    ps.nparts = nparts; ps.bias2 = bias; ps.resid = resid; ps.ldr = ldr;
-    hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(eg_cdiv(rows, 4)), dim3(256), 0, st, parts, gamma, beta, y, rows, d, eps,
-                       reinterpret_cast<unsigned short*>(img), ps);
-    return eg_check_launch("layernorm_sum");
-}
 extern "C" int eg_layernorm_img(const float* x, const float* gamma, const float* beta, float* y, void* y_images, int32_t rows, int32_t d, float eps,
                                 void* stream) {
     return egi_layernorm(x, gamma, beta, y, y_images, rows, d, eps, (hipStream_t)stream);

@@ -306,26 +306,31 @@ def mpjre(target: torch.Tensor, pred: torch.Tensor) -> float:
 
 
 def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6, imaginary="return_100"):
-    """model/FHD_score.py:159-217: ||mu1-mu2||^2 + Tr(C1 + C2 - 2 sqrt(C1 C2)), float64, scipy sqrtm.  A square root with a non-negligible
-    imaginary part returns 100 as that file does (`imaginary="return_100"`); model/embedding_space_evaluator.py:156-209 carries the same
-    formula but raises ValueError there (`imaginary="raise"`) -- its one difference, so that copy delegates here."""
+    """model/FHD_score.py:159-217: ||mu1-mu2||^2 + Tr(C1 + C2 - 2 sqrt(C1 C2)), float64, scipy sqrtm.  Any ValueError raised
+    inside upstream's try block (a non-negligible imaginary part of the square root, or scipy rejecting the product, e.g. NaN / inf entries) returns
+    100 as that file does (`imaginary="return_100"`); model/embedding_space_evaluator.py:156-209 carries the same formula without the try, so
+    the ValueError propagates there (`imaginary="raise"`) -- its one difference, so that copy delegates here."""
     from scipy import linalg
 
     mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
     sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
     assert mu1.shape == mu2.shape and sigma1.shape == sigma2.shape
     diff = mu1 - mu2
-    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
-    if not np.isfinite(covmean).all():
-        offset = np.eye(sigma1.shape[0]) * eps
-        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
-    if np.iscomplexobj(covmean):
-        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
-            if imaginary == "raise":
+    try:        # upstream's try covers the square root, the singular-product retry and the trace: ANY ValueError in there returns 100 (:196-213)
+        covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+        if not np.isfinite(covmean).all():
+            offset = np.eye(sigma1.shape[0]) * eps
+            covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+        if np.iscomplexobj(covmean):
+            if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
                 raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
-            return 100
-        covmean = covmean.real
-    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+            covmean = covmean.real
+        tr_covmean = np.trace(covmean)
+    except ValueError:
+        if imaginary == "raise":
+            raise
+        return 100
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * tr_covmean
 
 
 class FrechetAccumulator:

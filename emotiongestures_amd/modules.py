@@ -701,15 +701,29 @@ class Transformer(ReplicaAware, nn.Module):
     def _weights_version(self):
         return _weights_version_of(self._origin())
 
+    @staticmethod
+    def _engine_slot(dev, shared_chip, concurrent) -> str:
+        # the launch-policy classes (stand-alone / several batches in flight; branches on side streams or not) keep SEPARATE engines per device, so
+        # that a 1-lane and an N-lane ClipPipeline on one generator do not evict each other's engine (and with it the arena their captured graphs
+        # point into)
+        return str(dev) + ("#shared" if shared_chip else "") + ("#branches" if concurrent else "")
+
+    def engine_peek(self, shared_chip=None, concurrent=None) -> Optional[GeneratorEngine]:
+        """The engine of the module's own device for that launch-policy class as it stands (None before its first use); never packs."""
+        o = self._origin()
+        sc = self.shared_chip if shared_chip is None else bool(shared_chip)
+        cc = self.concurrent if concurrent is None else bool(concurrent)
+        ent = self._dp().engines.get(self._engine_slot(next(o.parameters()).device, sc, cc))
+        return None if ent is None else ent[0]
+
     @property
     def _engine(self) -> Optional[GeneratorEngine]:
         """The engine of the module's own device (None before the first forward)."""
-        o = self._origin()
-        ent = self._dp().engines.get(str(next(o.parameters()).device))
-        return None if ent is None else ent[0]
+        return self.engine_peek()
 
-    def engine(self, device=None) -> GeneratorEngine:
-        """The engine (packed weight arena + workspaces) for `device` (default: the parameters' device).  One per device, kept on
+    def engine(self, device=None, shared_chip=None, concurrent=None) -> GeneratorEngine:
+        """The engine (packed weight arena + workspaces) for `device` (default: the parameters' device).  One per device (and launch-policy
+        class: `shared_chip` / `concurrent`, default the module's own flags; ClipPipeline passes its own per call and never writes the module's), kept on
         the ORIGIN module, so nn.DataParallel's per-forward replicas reuse it: weights and the version key come from the origin's
         parameters, the arena is packed and uploaded once per device and weight version."""
         o = self._origin()
@@ -720,14 +734,17 @@ class Transformer(ReplicaAware, nn.Module):
             dev = torch.device("cuda", torch.cuda.current_device())
         st = self._dp()
         with st.lock:
-            mode = (str(dev), self.precision, self.keep_taps, self.concurrent, self.fold_affine, self.fuse_se, self.shared_chip)
+            sc = self.shared_chip if shared_chip is None else bool(shared_chip)
+            cc = self.concurrent if concurrent is None else bool(concurrent)
+            slot = self._engine_slot(dev, sc, cc)
+            mode = (str(dev), self.precision, self.keep_taps, cc, self.fold_affine, self.fuse_se, sc)
             key = (mode, self._weights_version())
-            ent = st.engines.get(str(dev))
+            ent = st.engines.get(slot)
             if ent is None or ent[1] != key:
                 if ent is None or ent[1][0] != mode:
-                    ent = st.engines[str(dev)] = [GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=self.concurrent,
-                                                                  fold_affine=self.fold_affine, fuse_se=self.fuse_se, shared_chip=self.shared_chip,
-                                                                  **self._cfg), None]
+                    ent = st.engines[slot] = [GeneratorEngine(precision=self.precision, keep_taps=self.keep_taps, concurrent=cc,
+                                                              fold_affine=self.fold_affine, fuse_se=self.fuse_se, shared_chip=sc,
+                                                              **self._cfg), None]
                 ent[0].load_weights(o.state_dict(), dev)
                 ent[1] = key
             return ent[0]

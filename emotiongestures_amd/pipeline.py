@@ -24,22 +24,6 @@ import torch
 CAPTURE_MODE = "thread_local"
 
 
-def cu_masked_stream(device, cu_ids):
-    """A HIP stream whose kernels run only on the given compute units (hipExtStreamCreateWithCUMask; 256 CUs = 8 mask words), wrapped for torch.
-    Experiment hook of ClipPipeline (`EG_LANE_CU_MASK`): lanes as SPATIAL partitions of the chip instead of time-slicing all of it."""
-    import ctypes
-    hip = ctypes.CDLL(torch.__file__.rsplit("/", 1)[0] + "/lib/libamdhip64.so")
-    words = (ctypes.c_uint32 * 8)()
-    for cu in cu_ids:
-        words[cu >> 5] |= 1 << (cu & 31)
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
-    if rc != 0 or not h.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-    return torch.cuda.ExternalStream(h.value, device=device)
-
-
 class _Lane:
     __slots__ = ("slot", "stream", "graph", "inputs", "outputs", "done", "busy", "collected", "keep", "key")
 
@@ -59,14 +43,16 @@ class ClipPipeline:
         self.gen, self.vae, self.mel = models
         if branch_streams and lanes > 1:
             raise ValueError("branch_streams forks use per-handle side streams: only with lanes == 1")
-        self.gen.concurrent = bool(branch_streams)
-        self.gen.shared_chip = lanes > 1          # other lanes fill the chip: the products' tile is chosen for CU time (EgGeneratorConfig.reserved[4])
+        self.concurrent = bool(branch_streams)     # text / prior branches forked onto side streams inside the step (one lane only)
+        # other lanes fill the chip: the products' tile is chosen for CU time (EgGeneratorConfig.reserved[4]).  A property of THIS pipeline, passed to
+        # engine() per call: the generator keeps one engine per tile-policy class, so a 1-lane and an N-lane pipeline can live on one generator.
+        self.shared_chip = lanes > 1
         self.lanes: List[_Lane] = []
         self._next = 0
         for i in range(lanes):
             ln = _Lane()
             ln.slot = i
-            ln.stream = self._lane_stream(i, lanes)
+            ln.stream = torch.cuda.Stream(self.device)
             ln.inputs = {k: v.to(self.device).clone() for k, v in example_inputs.items()}
             ln.done = torch.cuda.Event()
             ln.collected = None
@@ -74,28 +60,23 @@ class ClipPipeline:
             self._capture(ln)
             self.lanes.append(ln)
 
-    def _lane_stream(self, i, lanes):
-        """The stream lane i replays on.  EG_LANE_CU_MASK (experiment): "contig" = lane i gets CUs [i * 256 / lanes, ...), "interleave" = CUs i, i + lanes, ...
-        (default: an ordinary stream; every lane may use the whole chip)."""
-        import os
-        mode = os.environ.get("EG_LANE_CU_MASK", "")
-        if mode not in ("contig", "interleave") or lanes < 2:
-            return torch.cuda.Stream(self.device)
-        per = 256 // lanes
-        cus = range(i * per, (i + 1) * per) if mode == "contig" else range(i, 256, lanes)
-        return cu_masked_stream(self.device, list(cus))
-
     # one step on the current stream, reading the lane's static buffers
     def _step(self, ln: _Lane):
         g = ln.inputs
         with torch.no_grad():
-            spec = self.mel(g["audio"], out_frames=self.gen.engine().cfg.spec_len, slot=ln.slot) if self.mel is not None else g["spec"]
+            eng = self._gen_engine()
+            spec = self.mel(g["audio"], out_frames=eng.cfg.spec_len, slot=ln.slot) if self.mel is not None else g["spec"]
             sampled = self.vae.sample(g["label"], z=g["z"], slot=ln.slot) if self.vae is not None else g.get("sampled")
-            return self.gen(spec, g["text"], g["pre_pose"], sampled, slot=ln.slot)
+            return eng.forward(spec, g["text"], g["pre_pose"], sampled, slot=ln.slot)      # = Transformer.forward in eval mode, on this pipeline's engine
+
+    def _gen_engine(self):
+        if self.gen.training:
+            raise RuntimeError("ClipPipeline runs eval-mode modules (call generator.eval())")
+        return self.gen.engine(shared_chip=self.shared_chip, concurrent=self.concurrent)
 
     def _engine_state(self):
         """What a captured graph has baked in as raw pointers: the engines, their weight arenas and this lane's workspaces."""
-        eng = self.gen.engine()
+        eng = self._gen_engine()
         veng = self.vae.engine() if self.vae is not None else None
         return eng, eng.arena, veng, (veng.arena if veng is not None else None)
 
@@ -138,7 +119,7 @@ class ClipPipeline:
         i = self._next
         self._next = (self._next + 1) % len(self.lanes)
         ln = self.lanes[i]
-        eng = self.gen._engine
+        eng = self.gen.engine_peek(self.shared_chip, self.concurrent)
         if eng is None or id(eng) != ln.key[0] or id(eng.arena) != ln.key[1]:
             raise RuntimeError("ClipPipeline: the generator's engine / weight arena changed after capture (weights reloaded or "
                                "precision / keep_taps / concurrent flipped); call refresh() before launching")

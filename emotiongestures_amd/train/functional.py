@@ -210,7 +210,7 @@ def _linear_ex(x, lda, w, ldw, bias, res, y, M, N, K, relu, prec, gate=None, dro
 # (4352 rows) the chained step takes 28.12 ms against 27.86 ms without -- stand-alone the pre-split product is only 4-17 us ahead of the fp32-input
 # kernel per launch at these shapes (tools/bench_ops.py gemm: 14.0 / 29.6 / 39.8 / 40.6 us against 18.4 / 35.4 / 46.0 / 57.7 us for 4352 x {512, 1536, 2048} x 512
 # and 4352 x 512 x 2048), and writing the images (LayerNorm outputs, the 2048-wide hidden and its gradient: ~36 MB per FFN each way) costs more than that.
-PRESPLIT_ROWS = int(__import__("os").environ.get("EG_TRAIN_PRESPLIT_ROWS", str(1 << 30)))
+PRESPLIT_ROWS = 1 << 30          # off (measured slower at every batch size tried); tests lower it to cover the image entry points
 
 
 def presplit_ok(rows: int, k: int) -> bool:
@@ -1210,6 +1210,12 @@ class _MHABlock(torch.autograd.Function):
 
 def mha_block(m, xq, xkv=None, p_attn=0.0, p_fc=0.0):
     """m: a MultiHeadAttention parameter holder.  xkv None: self attention (k = v = q = xq); else k = v = xkv."""
+    dq = m.w_qs.weight.shape[0]
+    if m.w_ks.weight.shape[0] != dq or m.w_vs.weight.shape[0] != dq or dq % m.n_head or m.fc.weight.shape[1] != dq:
+        # the block slices ONE fused Q|K|V product by the projection width and hands n_head x (width / n_head) heads to the attention kernel for
+        # K and V alike (the reference's only configuration: d_k = d_v = 64, SubLayers.py:17-28); anything else must take nets.mha_forward
+        raise L.EgError(f"mha_block: needs n_head*d_k == n_head*d_v (w_qs / w_ks / w_vs rows {dq} / {m.w_ks.weight.shape[0]} / "
+                        f"{m.w_vs.weight.shape[0]}, fc columns {m.fc.weight.shape[1]}, heads {m.n_head}); use the unfused path")
     y, yimg = _MHABlock.apply(xq, xkv, m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.fc.weight, m.layer_norm.weight, m.layer_norm.bias, m.n_head,
                               float(p_attn), float(p_fc), m.layer_norm.eps, images_of(xq), images_of(xkv) if xkv is not None else None)
     if yimg is not None:

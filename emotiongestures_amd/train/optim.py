@@ -46,8 +46,12 @@ class FlatParams:
         """Keep the split-bf16 weight images of all Linear / conv3x3 parameters resident and refresh them once per optimiser step.
         groups / skip: the fused-product plan of the model (`nets.weight_image_plan(model)`), see WeightImages."""
         from . import functional as F
+        plan = (tuple(tuple(id(p) for p in g) for g in groups), tuple(id(p) for p in skip))
         if self.images is None:
             self.images = WeightImages(self, groups, skip)
+            self._image_plan = plan
+        elif plan != self._image_plan:
+            raise L.EgError("enable_weight_images: called again with a different groups / skip plan (the images are built once per FlatParams)")
         F.register_weight_images(self.images)
         return self.images
 
@@ -134,7 +138,9 @@ class WeightImages:
         def add(ptr, owners, kinds):
             nonlocal first
             for kind, a, b, c, flag, floats, rows in kinds:
-                img = torch.empty(floats, dtype=torch.float32, device=dev)
+                # zeros, not empty: in bf16_only mode the refresh never writes the fp32 head; a consumer that reads it by mistake must get zeros
+                # (a loud all-zero result), not whatever the allocator left there
+                img = torch.zeros(floats, dtype=torch.float32, device=dev)
                 self.images[(ptr, kind, flag, rows)] = (img, owners)
                 entries.append((ptr, img.data_ptr(), kind, a, b, c, flag | (2 if self.bf16_only else 0), first))
                 first += int(lib.eg_pack_table_blocks(kind, a, b, flag))

@@ -167,6 +167,15 @@ def test_install_aliases_resolve_reference_import_lines():
         "from data_loader.data_preprocessor_expressive import DataPreprocessor\n"
         "from data_loader.lmdb_loader_BEAT_full import SpeechMotionDataset, one_hot_eid\n"
         "from utils.train_utils_BEAT import extract_melspectrogram, make_audio_fixed_length\n"
+        # :29 -- the metric is out of scope (librosa), the import line and the caller's construction (:185) are not; its methods refuse loudly
+        "from model.Beat_score_v2 import alignment\n"
+        "al = alignment(0.3, 2)\n"
+        "assert (al.sigma, al.order) == (0.3, 2)\n"
+        "try:\n"
+        "    al.load_audio(None, 0, True)\n"
+        "    raise SystemExit('load_audio did not refuse')\n"
+        "except NotImplementedError as e:\n"
+        "    assert 'librosa' in str(e)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)

@@ -161,6 +161,26 @@ def test_generator_and_cvae_under_data_parallel_equal_the_unwrapped_modules():
 
 
 @pytest.mark.gpu
+def test_a_one_clip_remainder_chunk_differs_only_by_summation_order():
+    """chunk invariance is bitwise for chunks of AT LEAST TWO clips.  A single clip (<= 64 rows) takes the one-clip product kernel
+    (csrc/gemm.hip gemm_skinny_kernel: K steps dealt to four waves, folded in a fixed order) and the split-K w_2 product, i.e. another K summation
+    order: B = 3 scattered 2 + 1 equals the unwrapped B = 3 forward bitwise on the 2-clip chunk and within 2e-5 on the 1-clip remainder."""
+    from conftest import clip_rel_l2
+    dev = torch.device("cuda:0")
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in synth_inputs(3, 34, 126, 4, seed=13).items() if k != "z"}
+    gen = build_mirror("spatial", 34, 126, 4, 4, seed=13, precision="bf16x3").to(dev)
+    wrapped = _dp(gen).eval()
+    with torch.no_grad():
+        ref = gen(inp["spec"], inp["text"], inp["pre_pose"], inp["sampled"])
+        out = wrapped(inp["spec"], inp["text"], inp["pre_pose"], inp["sampled"])
+        alone = gen(inp["spec"][2:], inp["text"][2:], inp["pre_pose"][2:], inp["sampled"][2:])
+    assert torch.equal(out[0][:2], ref[0][:2])                           # the 2-clip chunk: same bits as inside the batch of 3
+    assert torch.equal(out[0][2:], alone[0])                             # the remainder chunk IS the one-clip path
+    e = clip_rel_l2(out[0][2:].cpu().numpy(), ref[0][2:].cpu().numpy())
+    assert 0 < e < 2e-5, e                                               # order-only difference (and really another path: not bitwise)
+
+
+@pytest.mark.gpu
 def test_memory_variant_under_data_parallel_equals_per_chunk_forwards():
     """Models_memory couples the clips of a batch (TM_Memory_Net, Models_memory.py:288-289): under DataParallel each replica sees
     its chunk, as in the reference -- the wrapped output equals the unwrapped model run chunk by chunk."""

@@ -307,24 +307,3 @@ def test_beat_long_120_frames_matches_reference_golden_and_oracle(prec):
     assert rel_l2(got[3].cpu().numpy(), z["emotion_prediction"]) < POSE_TOL[prec] * 5
     assert rel_l2(digest(got[1].cpu().numpy(), 8192)["sample"], z["emotion_feature/sample"]) < POSE_TOL[prec]
     assert rel_l2(got[3].cpu().numpy(), ref[3].numpy()) < POSE_TOL[prec] * 5
-
-
-def test_fused_ffn_slab_kernel_matches_the_two_launch_path(monkeypatch):
-    """csrc/ffn.hip (opt-in: EG_FFN_FUSED): PositionwiseFeedForward as one slab kernel with the hidden in LDS.  One workgroup per slab ("1") is BITWISE
-    the default two pre-split launches (same products per element in the same order, the hidden split by the same function); with the hidden split
-    over 4 workgroups per slab ("4") the partial sums are folded by the LayerNorm in a fixed order: equal within 2e-5 at the pose, and repeatable."""
-    model = build_mirror("spatial", 34, 126, 4, 4, seed=13, precision="bf16x3").to(dev())
-    inp = synth_inputs(8, seed=13)
-    g = {k: torch.from_numpy(v).to(dev()) for k, v in inp.items()}
-
-    def run(mode):
-        if mode is None:
-            monkeypatch.delenv("EG_FFN_FUSED", raising=False)
-        else:
-            monkeypatch.setenv("EG_FFN_FUSED", mode)
-        with torch.no_grad():
-            return model(g["spec"], g["text"], g["pre_pose"], g["sampled"])[0].clone()
-    ref, one, four, four_again = run(None), run("1"), run("4"), run("4")
-    assert torch.equal(one, ref)
-    assert torch.equal(four, four_again) and not torch.equal(four, ref)
-    assert clip_rel_l2(four.cpu().numpy(), ref.cpu().numpy()) < 2e-5          # another summation order over the hidden chunks, six FFNs deep (measured 8e-6)

@@ -359,44 +359,6 @@ def test_attention_mask_matches_reference_golden(prec):
         assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < tol and float((a1 - a0).abs().max()) < 10 * tol
 
 
-def test_conv32_teams_kernel_is_bitwise_the_persistent_kernel(monkeypatch):
-    """csrc/conv.hip conv3x3_c32_teams_kernel (EG_CONV32_TEAMS = 2 | 3: teams of 4 waves per workgroup sharing ONE LDS copy of the 9 taps' weights,
-    3 waves per SIMD) against the default persistent 32 -> 32 kernel: same arithmetic and summation order per output element, so identical bits --
-    with the fused SE tail (gate + residual + ReLU in the epilogue), with the pooling partials, and on a tile count that leaves some teams idle."""
-    from emotiongestures_amd import ops
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(5)
-    for (B, H, W) in ((3, 128, 124), (1, 20, 40), (5, 37, 33)):
-        x = torch.randn(B, H, W, 32, generator=g).to(dev)
-        w = (torch.randn(32, 32, 3, 3, generator=g) * 0.05)
-        res = torch.randn(B, H, W, 32, generator=g).to(dev)
-        wp = ops.pack_conv3x3_weight(w, dev)[0]
-        outs = {}
-        for teams in (None, "2", "3"):
-            if teams is None:
-                monkeypatch.delenv("EG_CONV32_TEAMS", raising=False)
-            else:
-                monkeypatch.setenv("EG_CONV32_TEAMS", teams)
-            y, gap = ops.conv3x3(x, w, relu=True, want_gap=True, precision="bf16x3", packed=(wp, None, None, None))
-            outs[teams] = (y.clone(), gap.clone())
-        for teams in ("2", "3"):
-            assert torch.equal(outs[teams][0], outs[None][0]) and torch.equal(outs[teams][1], outs[None][1]), (B, H, W, teams)
-    # the whole generator (stage 1: six 32 -> 32 convolutions, three of them with the fused SE tail: gate + residual + ReLU in the epilogue)
-    from conftest import build_mirror
-    from emotiongestures_amd.synth import synth_inputs
-    model = build_mirror("spatial", 34, 126, 4, 4, seed=4, precision="bf16x3").to(dev)
-    inp = {k: torch.from_numpy(v).to(dev) for k, v in synth_inputs(3, seed=4).items()}
-    poses = {}
-    for teams in (None, "3"):
-        if teams is None:
-            monkeypatch.delenv("EG_CONV32_TEAMS", raising=False)
-        else:
-            monkeypatch.setenv("EG_CONV32_TEAMS", teams)
-        with torch.no_grad():
-            poses[teams] = model(inp["spec"], inp["text"], inp["pre_pose"], inp["sampled"])[0].clone()
-    assert torch.equal(poses["3"], poses[None])
-
-
 def test_channel_split_convolutions_are_bitwise_the_unsplit_kernels(monkeypatch):
     """csrc/conv.hip conv3x3_bf16_kernel<..., SPLIT>: at small batches the 64 -> 64 and 128 -> 128 convolutions have fewer pixel tiles than the chip has
     CUs, so the launch function also spreads the output channels over workgroups (EG_CONV_SPLIT = 1 | 2 | 4 forces a split; default: by tile count).
@@ -432,7 +394,7 @@ def test_channel_split_convolutions_are_bitwise_the_unsplit_kernels(monkeypatch)
 
 
 def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatch):
-    """csrc/gemm.hip gemm_skinny_kernel (default: M <= 64 rows; here forced on up to 1024 through EG_GEMM_SKINNY_ROWS; bf16x3: 16 output columns of a 64-row block per workgroup, K steps dealt to the four waves, operands straight from
+    """csrc/gemm.hip gemm_skinny_kernel (M <= 64 rows; bf16x3: 16 output columns of a 64-row block per workgroup, K steps dealt to the four waves, operands straight from
     global memory, fixed-order fold): against a float64 reference within the split-bf16 bound, and against the tiled kernels (EG_GEMM_SKINNY=0) at
     summation-order noise -- ragged M / N / K, bias, ReLU, both residual forms and the causal row shift (a_shift) included."""
     from emotiongestures_amd import ops
@@ -440,8 +402,7 @@ def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatc
     g = torch.Generator().manual_seed(31)
     for (M, K, N, kw) in ((34, 512, 512, {}), (1, 512, 1536, dict(bias=True)), (64, 2048, 512, dict(bias=True, res1=True)), (16, 300, 126, dict(bias=True, relu=True)),
                           (60, 128, 512, dict(bias=True, res1=True, relu=True, res2=True)), (34, 124, 512, dict(bias=True)), (47, 512, 2048, dict(bias=True, relu=True)),
-                          (34, 512, 512, dict(bias=True, a_shift=4, a_seq=34)), (68, 512, 512, dict(bias=True)), (544, 512, 512, dict(bias=True, res1=True)),
-                          (544, 2048, 512, dict(bias=True, relu=True)), (300, 512, 2048, dict(bias=True)), (1000, 128, 126, dict(bias=True, a_shift=2, a_seq=50))):
+                          (34, 512, 512, dict(bias=True, a_shift=4, a_seq=34)), (64, 512, 2048, dict(bias=True)), (50, 128, 126, dict(bias=True, a_shift=2, a_seq=50))):
         x = torch.randn(M, K, generator=g).to(dev)
         w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
         b = torch.randn(N, generator=g).to(dev) if kw.get("bias") else None
@@ -449,7 +410,6 @@ def test_one_clip_products_match_fp32_reference_and_the_tiled_kernels(monkeypatc
         r2 = torch.randn(M, N, generator=g).to(dev) if kw.get("res2") else None
         sh, sq = kw.get("a_shift", 0), kw.get("a_seq", 0)
         outs = {}
-        monkeypatch.setenv("EG_GEMM_SKINNY_ROWS", "1024")
         for sk in ("0", "1"):
             monkeypatch.setenv("EG_GEMM_SKINNY", sk)
             outs[sk] = ops.linear(x, w, b, r1, r2, relu=bool(kw.get("relu")), a_shift=sh, a_seq=sq, precision="bf16x3")

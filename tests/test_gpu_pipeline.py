@@ -50,6 +50,43 @@ def test_pipeline_matches_eager_in_order(lanes, branch):
     assert pipe.outputs(lane)[0].shape == (B, 34, 126)
 
 
+def test_pipelines_of_both_lane_classes_share_one_generator():
+    """a 1-lane (stand-alone tile policy, branches on side streams) and an N-lane pipeline (shared-chip tile policy) alive on ONE generator
+    (bench.py's gpu_b1 leg beside the main pipeline).  The launch-policy hints are per pipeline, the generator keeps one engine per class: neither
+    pipeline goes stale when the other is built or used, each arena is packed once, and both return what an eager forward returns."""
+    from emotiongestures_amd.pipeline import ClipPipeline
+    dev = torch.device("cuda:0")
+    models = _models(dev)
+    gen, vae, mel = models
+    b4, b1 = _batch(4, 700, dev), _batch(1, 701, dev)
+    many = ClipPipeline(models, b4, dev, lanes=2)
+    one = ClipPipeline(models, b1, dev, lanes=1, branch_streams=True)
+    assert gen.shared_chip is False and gen.concurrent is False           # the pipelines wrote nothing onto the shared module
+    e_many, e_one = many._gen_engine(), one._gen_engine()
+    assert e_many is not e_one and e_many.uploads == 1 and e_one.uploads == 1
+    for _ in range(3):                                                     # interleaved use: no RuntimeError("... changed after capture")
+        many.wait(many.launch_next())
+        one.wait(one.launch_next())
+    assert not many.stale() and not one.stale()
+    many.refresh(); one.refresh()                                          # re-capture keeps each pipeline on its own class
+    assert many._gen_engine() is e_many and one._gen_engine() is e_one and e_many.uploads == 1 and e_one.uploads == 1
+    with torch.no_grad():
+        ref4 = gen(mel(b4["audio"], out_frames=124), b4["text"], b4["pre_pose"], vae.sample(b4["label"], z=b4["z"]))
+        ref1 = gen(mel(b1["audio"], out_frames=124), b1["text"], b1["pre_pose"], vae.sample(b1["label"], z=b1["z"]))
+    got4, got1 = list(many.run([b4]))[0], list(one.run([b1]))[0]
+    # the 128 x 128 product tile of the shared-chip class accumulates K in the same order as the 64 x 64 tile (DESIGN.md section 5): same bits
+    for a, r in zip(got4, ref4):
+        assert torch.equal(a, r)
+    for a, r in zip(got1, ref1):
+        assert torch.equal(a, r)
+    # a weight update reaches both classes: each repacks once, both pipelines notice
+    with torch.no_grad():
+        gen.post_projector[6].bias.add_(1.0)
+    assert many.stale() and one.stale()
+    got4b = list(many.run([b4]))[0]
+    assert torch.allclose(got4b[0], got4[0] + 1.0, atol=1e-5) and many._gen_engine().uploads == 2
+
+
 def test_pipeline_refuses_cpu():
     from emotiongestures_amd.pipeline import ClipPipeline
     with pytest.raises(RuntimeError):

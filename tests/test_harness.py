@@ -68,6 +68,16 @@ def test_metric_functions_host_side():
     f2 = O.frechet_distance(a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False))
     assert abs(f1 - f2) < 1e-9 and f1 > 0
     assert abs(H.calculate_frechet_distance(a.mean(0), np.cov(a, rowvar=False), a.mean(0), np.cov(a, rowvar=False))) < 1e-6
+    # model/FHD_score.py:196-213: ANY ValueError inside the try returns 100 -- the imaginary-component case and scipy refusing a NaN product alike;
+    # model/embedding_space_evaluator.py:156-209 has no try: the same inputs raise there
+    nan_cov = np.eye(4)
+    nan_cov[0, 0] = np.nan
+    indefinite = np.diag([1.0, -1.0])
+    assert H.calculate_frechet_distance(np.zeros(4), np.eye(4), np.zeros(4), nan_cov) == 100
+    assert H.calculate_frechet_distance(np.zeros(2), indefinite, np.zeros(2), np.eye(2)) == 100
+    for bad in ((np.zeros(4), np.eye(4), np.zeros(4), nan_cov), (np.zeros(2), indefinite, np.zeros(2), np.eye(2))):
+        with pytest.raises(ValueError):
+            H.calculate_frechet_distance(*bad, imaginary="raise")
     act = rng.randn(8 * 60, 512)
     np.random.seed(7)
     d1, i1 = H.diversity_score(act, 60)
