@@ -171,17 +171,13 @@ def parse_args():
     ap.add_argument("--train-graph", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--no-train-dropout", action="store_true",
                     help="--train: run the step with every Dropout at p = 0 (the gradient-parity configuration) instead of the reference's train() graph")
+    ap.add_argument("--dp-train-batch", type=int, default=16,
+                    help="clips per GPU per step of the data-parallel training leg that the default line carries at --gpus N > 1 (16 x 8 GPUs = global 128)")
     ap.add_argument("--train-batch", type=int, default=16, help="clips per GPU per training step (16 = global 128 on 8 GPUs, SURVEY.md §8d cfg 3)")
     return ap.parse_args()
 
 
 # ---- self-launch: `python bench.py --gpus N` without an outer torchrun ------------------------------------------------------
-def _free_port():
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def self_launch(n):
     """Parent side of `--gpus N`.  Runs BEFORE anything touches the GPU (torch.cuda.device_count() does not initialise it on
     this image; is_available() would), never re-execs: N fresh children, one per GPU, this process only waits for them."""
@@ -190,11 +186,14 @@ def self_launch(n):
         ndev = torch.cuda.device_count()
         if ndev < n and os.environ.get("EG_BENCH_BACKEND", "nccl") == "nccl":       # gloo: the one-GPU test of the data-parallel path shares the device
             raise SystemExit(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible; refusing to oversubscribe")
-    port = _free_port()
+    # rendezvous through a file the ranks open themselves (emotiongestures_amd/dist.py init_process_group): no probed-then-released TCP port that
+    # another process could take before rank 0 binds it
+    from emotiongestures_amd.dist import new_store_path
+    store = new_store_path("eg_bench")
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_BENCH_CHILD="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), EG_DIST_STORE=store, EG_BENCH_CHILD="1")
+        env.pop("MASTER_PORT", None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     # poll: the first worker that fails takes its siblings down (they would otherwise sit in the rendezvous / a collective until a timeout);
@@ -223,13 +222,17 @@ def self_launch(n):
                 raise SystemExit(f"bench.py: workers exceeded EG_BENCH_TIMEOUT_S; terminated (exit codes {rcs})")
             raise SystemExit(f"bench.py: worker rank {failed[0]} failed with exit code {failed[1]}; siblings terminated (exit codes {rcs})")
         time.sleep(0.05)
+    try:
+        os.unlink(store)
+    except OSError:
+        pass
     return 0
 
 
 def dry_worker(args, rank, world):
     """Launcher plumbing only (no GPU): rendezvous over gloo, barrier, max-over-ranks reduce, one JSON line from rank 0."""
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emotiongestures_amd.dist import init_process_group
+    dist = init_process_group("gloo", rank, world)
     dist.barrier()
     tt = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -387,14 +390,14 @@ def diversity_leg(precision, dev, steps, B=64, R=32):
 TRAIN_FLOP_PER_CLIP = 3.0 * FLOP_PER_CLIP      # forward + input gradients + weight gradients of the generator; CVAE and losses not counted
 
 
-def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=None, backend="nccl", segments=0, dropout=False):
+def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=None, backend="nccl", segments=0, dropout=False, payload=None):
     """One timed configuration of the training step (generator + emotion CVAE: forward + 100*smooth_l1 + CE + backward + bucketed gradient
     all-reduce + fused Adam on B clips per GPU).  precision: arithmetic of the convolutions / Linear products ("f32" = the gradient-parity
     configuration); graph: replay the step from captured hipGraph(s) instead of issuing every kernel through autograd.
     dropout=True: the graph the REFERENCE trains -- every nn.Dropout of its train() mode active (encoder input, MHA / FFN outputs, the 0.2 layers
     of the projection MLPs and of the CVAE, the attention probabilities; SubLayers.py:54,79, Modules.py:21) on the library's counter-based mask
     stream (`train_dropout`; under a graph the mask epoch lives on the device: GraphedStep / SegmentedStep(stochastic=True)).  dropout=False is the
-    gradient-parity configuration (p = 0)."""
+    gradient-parity configuration (p = 0).  payload: what the gradient buckets travel as ("f32" | "bf16"; default EG_GRAD_PAYLOAD or f32)."""
     from emotiongestures_amd import _lib
     from emotiongestures_amd.builders import build_mirror
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
@@ -416,13 +419,13 @@ def train_leg(dev, B, precision, graph, steps, warmup, rank=0, world=1, dist=Non
 
     F.set_precision(precision)
     try:
-        return _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier)
+        return _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier, payload)
     finally:                    # also when a leg raises: the process-wide precision / image registry / mask epoch never leak into the next leg
         F.reset_state()
         torch.cuda.empty_cache()
 
 
-def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier):
+def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, backend, dropout, lib, g, target, label, eps, barrier, payload=None):
     from emotiongestures_amd.builders import build_mirror
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.synth import load_synth_weights
@@ -511,7 +514,7 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
         else:
             # data parallel: the step is cut into per-bucket graph segments (forward + the backward up to bucket 0 complete, then one segment per
             # further bucket); bucket k's all-reduce runs on the side stream while segment k+1 replays, Adam follows the last reduction
-            gb.payload = os.environ.get("EG_GRAD_PAYLOAD", "f32")          # "bf16": buckets travel as bfloat16 (half the xGMI bytes)
+            gb.payload = payload or os.environ.get("EG_GRAD_PAYLOAD", "f32")          # "bf16": buckets travel as bfloat16 (half the xGMI bytes)
             ss = SegmentedStep(forward_loss, gb, opt, device=dev, warmup=max(1, warmup), stochastic=bool(dropout))
             run = lambda: ss.run(exposed=ar_ms)
             seg[0] = ss
@@ -526,11 +529,20 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
         loss = run()
     barrier()
     el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
     exposed = float(np.mean([a.elapsed_time(b) for a, b in ar_ms])) if ar_ms else None
+    by_rank = None
+    if dist is not None:
+        # every rank's own clock over the same K steps (both ends behind a barrier, so they differ only by barrier skew) and its exposed wait
+        on = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([el, -1.0 if exposed is None else exposed], device=on, dtype=torch.float64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        els = [float(t[0]) for t in seen]
+        exs = [float(t[1]) for t in seen if float(t[1]) >= 0]
+        el = max(els)
+        by_rank = {"ms_per_step_max": round(max(els) / steps * 1e3, 3), "ms_per_step_min": round(min(els) / steps * 1e3, 3),
+                   "allreduce_exposed_ms_per_step_max": round(max(exs), 3) if exs else None,
+                   "allreduce_exposed_ms_per_step_min": round(min(exs), 3) if exs else None}
     value = B * world * steps / el
     tf = value * TRAIN_FLOP_PER_CLIP / 1e12 / world
     out = {"value": round(value, 2), "ms_per_step": round(el / steps * 1e3, 3), "dtype": precision, "clips_per_gpu_per_step": B,
@@ -540,6 +552,9 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
            "allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 3),
            "allreduce_exposed_bytes_per_step": None if seg[0] is None else seg[0].exposed_bytes(),
            "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
+    if by_rank is not None:
+        out["ranks"] = by_rank
+        out["gradient_payload"] = gb.payload if graph and collective else "f32"
     if os.environ.get("EG_TRAIN_DIGEST") == "1":     # bitwise identity of the parameters after warmup + steps (tests: segmented step over RCCL vs the one-graph step)
         import hashlib
         out["param_digest"] = hashlib.sha256(fp.flat.cpu().numpy().tobytes()).hexdigest()
@@ -611,6 +626,8 @@ def train_worker(args, rank, world, dev, dist, backend):
             "frac_of_mfma_peak": main_leg["frac_of_mfma_peak"]}
         if "param_digest" in main_leg:
             line["param_digest"] = main_leg["param_digest"]
+        if "ranks" in main_leg:
+            line["ranks"] = main_leg["ranks"]
         if facts is not None:
             line["collectives"] = facts
         if parity is not None:
@@ -644,13 +661,10 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or os.environ.get("EG_FORCE_COLLECTIVES") == "1":      # the latter: a 1-rank RCCL group, so that every collective site really issues its call
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        from emotiongestures_amd.dist import init_process_group, new_store_path
+        if "MASTER_PORT" not in os.environ and "EG_DIST_STORE" not in os.environ:       # a lone rank that was asked for a group (EG_FORCE_COLLECTIVES)
+            os.environ["EG_DIST_STORE"] = new_store_path("eg_bench1")
+        dist = init_process_group(backend, rank, world, device=dev)
 
     from emotiongestures_amd import _lib
     lib = _lib.load()
@@ -818,11 +832,34 @@ def main():
                     extra[name] = {"error": repr(e)[:400]}
                 torch.cuda.empty_cache()
 
+    # ---- N > 1: BASELINE configs[2] -- the data-parallel training step (16 clips per GPU: global batch 128 on 8 GPUs), every rank, gradients
+    # averaged over RCCL in per-stage buckets between the backward's graph segments; fp32 and bf16 bucket payloads.  Then the process group is torn
+    # down: what follows (roofline, per-launch events) is rank 0's alone, and no other rank sits in a collective waiting for it. ----
+    train_dp = None
+    facts = None
+    if dist is not None:
+        if world > 1 and not args.no_train_legs:
+            step = pipe = None
+            torch.cuda.empty_cache()
+            train_dp = {}
+            for pay in ("f32", "bf16"):
+                rec = train_leg(dev, args.dp_train_batch, "bf16x3", True, max(5, args.steps // 2), 3, rank, world, dist, backend, dropout=True, payload=pay)
+                nparam, nb = rec.pop("trainable_parameters"), rec.pop("buckets")
+                rec["gradient_bytes_per_step"] = (4 if pay == "f32" else 2) * nparam
+                rec["buckets"] = nb
+                train_dp[f"payload_{pay}"] = rec
+        facts = collective_facts(dist, backend, dev)
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank != 0:
+            return 0
+
     # ---- roofline leg: per-launch HIP-event timing of the contraction kernels over K more steps (same stream) ----
     if rank == 0 and not args.no_roofline:
         cap = 400 * max(args.steps, 1)
         gen.concurrent = False                  # per-launch durations are only meaningful without overlapping side streams
-        gen.shared_chip = lanes > 1             # the tile policy of the TIMED configuration (other legs' pipelines reset the hint on the shared model)
+        gen.shared_chip = lanes > 1             # the tile policy of the TIMED configuration, for this eager step (pipelines carry their own hint)
         eager_step = make_step(gen, vae, mel, None)
         for _ in range(3):                      # warm: clocks up, kernels / weights resident, before per-launch events are taken
             eager_step()
@@ -899,8 +936,10 @@ def main():
                 par = train_leg(dev, tb, "f32", False, 3, 1)
                 for k in ("trainable_parameters", "buckets", "allreduce_exposed_ms_per_step"):
                     rec.pop(k, None)
-                rec["parity"] = ("p0 only: gradients are pinned against the reference's autograd with every Dropout at p = 0 (`parity_p0` times that step); with Dropout "
-                                 "on the mask stream is the library's own (not torch's), checked for keep rate / reproducibility, not element-wise")
+                rec["parity"] = ("element-wise with Dropout ON and at p = 0: the library's masks are a pure function of (seed, stream offset + index, p); "
+                                 "tests/test_gpu_training.py injects them at the reference's 26 Dropout sites (oracle autograd, and the reference's own modules "
+                                 "for tests/golden/dropout_grads.npz) and compares every parameter gradient of this step (TED, B = 2, f32); `parity_p0` times "
+                                 "the same step with every Dropout at p = 0")
                 rec["parity_p0"] = {k: p0[k] for k in ("value", "ms_per_step", "first_loss", "final_loss", "library_launches_per_step", "frac_of_mfma_peak")}
                 rec["f32_eager"] = {k: par[k] for k in ("value", "ms_per_step", "first_loss", "library_launches_per_step", "frac_of_mfma_peak")}
                 rec["hbm"] = train_hbm_gb_per_step(tb)
@@ -912,11 +951,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_g, sd_v, inp)
 
-    facts = collective_facts(dist, backend, dev)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
+        if train_dp is not None:
+            train = {f"b{args.dp_train_batch}_data_parallel": dict(train_dp, global_batch=args.dp_train_batch * world,
+                                               note="BASELINE configs[2]: generator + emotion CVAE, reference Dropout placements active, bf16x3 arithmetic, one "
+                                                    "process per GPU, SegmentedStep (per-stage hipGraph segments, bucket all-reduces between them on a side stream)")}
         line = {
             "metric": "gesture clips/sec (34 frames, 43 joints)", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -4,12 +4,41 @@ Inference needs no collective: clips are independent units, weights are replicat
 contiguous slice of the batch (what ``nn.DataParallel`` does on dim 0 in the reference,
 test_emotion_gesture_diversity_iterative.py:137-138).  ``gather_poses`` is the optional metric-side collection
 (17 KB per clip); it is never on the timed data path.
+
+``init_process_group`` is the one rendezvous of every one-process-per-GPU launcher of this package (bench.py's self-launch, the
+K-fold loop's workers, the two-rank tests): a launcher that starts its own ranks hands them a FILE (``EG_DIST_STORE``) instead of a
+probed TCP port, so there is no window in which another process can take "the free port" between the probe and rank 0's bind (round 5's
+flaky two-rank test).  Under an outer launcher (torchrun: MASTER_ADDR / MASTER_PORT in the environment) it is plain ``env://``.
 """
 from __future__ import annotations
 
 from typing import Tuple
 
 import torch
+
+
+def new_store_path(tag: str = "eg") -> str:
+    """A fresh rendezvous file name for `EG_DIST_STORE` (the launcher passes it to the ranks it starts; rank 0 creates the file)."""
+    import os
+    import tempfile
+    import uuid
+    return os.path.join(tempfile.gettempdir(), f"{tag}_store_{os.getpid()}_{uuid.uuid4().hex}")
+
+
+def init_process_group(backend: str, rank: int, world: int, device=None, timeout_s: float = 600.0):
+    """torch.distributed.init_process_group over a FileStore when the launcher published one in EG_DIST_STORE, else env:// (MASTER_ADDR /
+    MASTER_PORT).  backend "nccl" is RCCL on ROCm; `device` binds the communicator to the rank's GPU at once (eager init)."""
+    import datetime
+    import os
+    import torch.distributed as dist
+    kw = {"timeout": datetime.timedelta(seconds=timeout_s)}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    path = os.environ.get("EG_DIST_STORE")
+    if path:
+        kw["store"] = dist.FileStore(path, world)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

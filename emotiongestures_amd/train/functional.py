@@ -63,6 +63,7 @@ def reset_state() -> None:
     register_weight_images(None)
     _WS.clear()
     _DROP["epoch"] = None
+    _DROP["log"] = None
     manual_seed(0)
     _PENDING_COUNTERS.clear()
 
@@ -479,7 +480,25 @@ def begin_dropout_step() -> None:
 def next_dropout_offset(numel: int) -> int:
     off = _DROP["offset"]
     _DROP["offset"] = off + (int(numel) + 1023) // 1024 * 1024
+    log = _DROP.get("log")
+    if log is not None:             # tests: the (offset, numel) of every Dropout site of a step, in call order (record_dropout_sites)
+        log.append((off, int(numel)))
     return off
+
+
+def record_dropout_sites(on: bool = True):
+    """Start (-> the list that will fill) / stop recording the (stream offset, element count) of every Dropout site the forward visits.  The masks
+    themselves are a pure function of (seed, offset + flat index, p): `dropout_mask` returns one, oracle.dropout_keep_mask restates it in numpy."""
+    _DROP["log"] = [] if on else None
+    return _DROP["log"]
+
+
+def dropout_mask(p: float, seed: int, offset: int, numel: int, device) -> torch.Tensor:
+    """keep / (1 - p) per element of the site at stream position `offset`: eg_dropout applied to ones (what every fused epilogue multiplies by)."""
+    ones = torch.ones(int(numel), dtype=torch.float32, device=device)
+    y = torch.empty_like(ones)
+    L.check(_lib().eg_dropout_dev(_ptr(ones), _ptr(y), ones.numel(), float(p), int(seed) & 0xFFFFFFFF, int(offset), None, _stream(ones.device)), "eg_dropout")
+    return y
 
 
 class _Dropout(torch.autograd.Function):

@@ -68,6 +68,91 @@ class bn_training:
         _BN_TRAINING = self.prev
 
 
+# ---- train-mode nn.Dropout at the reference's sites ----------------------------------------------------------------------
+# The oracle never DRAWS a mask: a caller injects them (`with dropout_masks(fn)`), keyed by the NAME the nn.Dropout module has in the reference's
+# model (`named_modules()`), e.g. "encoder.layer_stack.0.slf_attn.attention.dropout" (Modules.py:11,21).  With nothing injected every site is
+# the identity: eval(), or the p = 0 gradient-parity configuration.  tests/golden/make_golden_dropout_grad.py drives the REFERENCE's own modules
+# with the same masks under the same names, which pins the placements below.
+_DROPOUT = None
+
+
+class dropout_masks:
+    """`fn(site, x) -> tensor of x's shape holding keep / (1 - p) per element, or None (identity)`."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _DROPOUT
+        self.prev, _DROPOUT = _DROPOUT, self.fn
+
+    def __exit__(self, *a):
+        global _DROPOUT
+        _DROPOUT = self.prev
+
+
+def _drop(site: str, x: torch.Tensor) -> torch.Tensor:
+    if _DROPOUT is None:
+        return x
+    m = _DROPOUT(site, x)
+    return x if m is None else x * m
+
+
+# The library's mask stream (emotiongestures_amd/csrc/common.h mix32 / dropout_keep, train/functional.py next_dropout_offset), restated in integer
+# numpy so that the masks of a training step can be computed WITHOUT the GPU: element i of a site lives at counter `offset + i` (row-major flat
+# index of the tensor the nn.Dropout sees), keep <=> hash(seed, counter) >= p * 2^32; a site of n elements advances the stream by n rounded up
+# to 1024.  Bit-exact integer work: tests/test_gpu_training.py compares it with eg_dropout on the GPU element for element.
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(h: np.ndarray) -> np.ndarray:
+    h = h ^ (h >> np.uint64(16))
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h = h ^ (h >> np.uint64(13))
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    return h ^ (h >> np.uint64(16))
+
+
+def dropout_keep_mask(seed: int, offset: int, numel: int, p: float) -> np.ndarray:
+    """bool[numel]: the library's keep decisions for one nn.Dropout(p) site at stream position `offset` (no device epoch: eager steps)."""
+    ctr = np.arange(numel, dtype=np.uint64) + np.uint64(offset)
+    thr = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    lo = _mix32((ctr & _M32) ^ np.uint64(seed & 0xFFFFFFFF))
+    h = _mix32((lo + (ctr >> np.uint64(32)) * np.uint64(0x9E3779B9) + np.uint64(0x6A09E667)) & _M32)
+    return h >= thr
+
+
+def dropout_site_plan(cfg: "GenCfg", batch: int, p_model: float = 0.2, p_attn: float = 0.1):
+    """The nn.Dropout sites of Transformer.forward (spatial variant, train() mode) that lie on the path to the losses, in the order the library's
+    train-mode forward visits them (emotiongestures_amd/train/nets.py generator_forward), as (reference module name, tensor shape, p).
+    p: Models_spatial_memory.py:477 (dropout=0.2 -> Encoder / Decoder / MultiHeadAttention / PositionwiseFeedForward), Modules.py:8
+    (attn_dropout=0.1), the literal nn.Dropout(0.2) of the Sequentials (:107,316,490,511,530-534).  Not listed: the text branch's Dropouts
+    (tcn.py, :161 -- the text embedding feeds neither loss, :577,616) and SP_Memory_Net_v2's (its result is discarded, :276-295)."""
+    b, f, d, h = batch, cfg.frames, cfg.d_model, cfg.n_head
+    plan = [("audio_encoder.dropout", (b, f, d), 0.2), ("prior_seq_encoder.post_header.1", (b, f, d), 0.2),
+            ("emotion_proj.1", (b, f, d), 0.2), ("semantic_proj.1", (b, f, d), 0.2), ("encoder.dropout", (b, f, d), p_model)]
+    for stack, attn in (("encoder", "slf_attn"), ("decoder", "enc_attn")):
+        for l in range(cfg.n_layers):
+            q = f"{stack}.layer_stack.{l}"
+            plan += [(f"{q}.{attn}.attention.dropout", (b, h, f, f), p_attn), (f"{q}.{attn}.dropout", (b, f, d), p_model),
+                     (f"{q}.pos_ffn.dropout", (b, f, d), p_model)]
+    plan += [("post_projector.1", (b, f, 4 * d), 0.2), ("post_projector.3", (b, f, d), 0.2), ("post_projector.5", (b, f, cfg.pose_dim), 0.2)]
+    return plan
+
+
+def dropout_plan_masks(plan, seed: int):
+    """-> ({site: float32 mask tensor keep / (1 - p)}, [(offset, numel)] in plan order): the library's masks for that plan from stream position 0."""
+    masks, where, off = {}, [], 0
+    for site, shape, p in plan:
+        n = int(np.prod(shape))
+        keep = dropout_keep_mask(seed, off, n, p)
+        inv = np.float32(1.0) / (np.float32(1.0) - np.float32(p))          # the kernels' fp32 1 / (1 - p)
+        masks[site] = torch.from_numpy((keep.astype(np.float32) * inv).reshape(shape))
+        where.append((off, n))
+        off += (n + 1023) // 1024 * 1024
+    return masks, where
+
+
 def _bn(sd: SD, p: str, x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """BatchNorm{1,2}d: eval mode = running statistics + affine (torch default eps 1e-5); inside `bn_training()` = batch statistics."""
     if _BN_TRAINING:
@@ -129,7 +214,7 @@ def audio_encoder(sd: SD, p: str, spec: torch.Tensor, taps: Optional[dict] = Non
     x = x.reshape(b, f, -1)
     if taps is not None:
         taps["audio_map"] = x
-    return _lin(sd, p + ".fc2", _lin(sd, p + ".fc1", x))
+    return _lin(sd, p + ".fc2", _drop(p + ".dropout", _lin(sd, p + ".fc1", x)))          # fc1 -> Dropout(0.2) -> fc2, :128-130
 
 
 # --------------------------------------------------------------------------------------------
@@ -181,7 +266,7 @@ def sp_memory_v1(sd: SD, p: str, initial: torch.Tensor, pred: torch.Tensor, cfg:
     torch.mm of a [1,D] by a [D,1] is an inner product."""
     b = initial.shape[0]
     mem = initial[:, cfg.prior_frames - cfg.chunk:, :].reshape(b, -1)
-    mem = _lin(sd, p + ".spatial_chunk_encoder.2", _lin(sd, p + ".spatial_chunk_encoder.0", mem))   # [B,D]
+    mem = _lin(sd, p + ".spatial_chunk_encoder.2", _drop(p + ".spatial_chunk_encoder.1", _lin(sd, p + ".spatial_chunk_encoder.0", mem)))   # [B,D]
     head = pred[:, :cfg.chunk, :]
     s = torch.sigmoid((head * mem[:, None, :]).sum(-1, keepdim=True))
     out = pred.clone()
@@ -194,9 +279,9 @@ def tm_memory(sd: SD, p: str, initial: torch.Tensor, pred: torch.Tensor, cfg: Ge
     contract over the *batch* axis (:288-289), so clips in one batch are coupled."""
     b = initial.shape[0]
     mem = initial[:, cfg.prior_frames - cfg.chunk:, :].reshape(b, -1)
-    mem = _lin(sd, p + ".temporal_chunk_encoder.2", _lin(sd, p + ".temporal_chunk_encoder.0", mem))     # [B,D]
+    mem = _lin(sd, p + ".temporal_chunk_encoder.2", _drop(p + ".temporal_chunk_encoder.1", _lin(sd, p + ".temporal_chunk_encoder.0", mem)))     # [B,D]
     pe = pred[:, :cfg.chunk, :].reshape(b, -1)
-    pe = _lin(sd, p + ".temporal_memory_encoder.2", _lin(sd, p + ".temporal_memory_encoder.0", pe))     # [B,chunk]
+    pe = _lin(sd, p + ".temporal_memory_encoder.2", _drop(p + ".temporal_memory_encoder.1", _lin(sd, p + ".temporal_memory_encoder.0", pe)))     # [B,chunk]
     score = mem @ (mem.t() @ pe)
     w = torch.softmax(score, dim=1)
     out = pred.clone()
@@ -214,7 +299,7 @@ def prior_memory_encoder(sd: SD, p: str, prior: torch.Tensor, cfg: GenCfg) -> to
         pred = sp_memory_v1(sd, p + ".spatial_memory", prior, pred, cfg)
         pred = tm_memory(sd, p + ".temporal_memory", prior, pred, cfg)
     out = torch.cat((prior, pred), 1)
-    return _lin(sd, p + ".post_header.2", _lin(sd, p + ".post_header.0", out))
+    return _lin(sd, p + ".post_header.2", _drop(p + ".post_header.1", _lin(sd, p + ".post_header.0", out)))       # Linear -> Dropout(0.2) -> Linear, :360-364
 
 
 # --------------------------------------------------------------------------------------------
@@ -235,20 +320,20 @@ def multi_head_attention(sd: SD, p: str, q: torch.Tensor, k: torch.Tensor, v: to
     if mask is not None:
         scores = scores.masked_fill(mask.unsqueeze(1) == 0, -1e9)
     attn = torch.softmax(scores, dim=-1)
-    o = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(b, lq, -1)
-    o = F.linear(o, sd[p + ".fc.weight"]) + residual
+    o = torch.matmul(_drop(p + ".attention.dropout", attn), vh).transpose(1, 2).contiguous().view(b, lq, -1)      # Modules.py:21
+    o = _drop(p + ".dropout", F.linear(o, sd[p + ".fc.weight"])) + residual                                          # SubLayers.py:54-55
     return _ln(sd, p + ".layer_norm", o), attn
 
 
 def positionwise_ffn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     """PositionwiseFeedForward.forward, Full_model/SubLayers.py:74-84."""
-    return _ln(sd, p + ".layer_norm", _lin(sd, p + ".w_2", F.relu(_lin(sd, p + ".w_1", x))) + x)
+    return _ln(sd, p + ".layer_norm", _drop(p + ".dropout", _lin(sd, p + ".w_2", F.relu(_lin(sd, p + ".w_1", x)))) + x)      # :79-80
 
 
 def encoder(sd: SD, p: str, x: torch.Tensor, cfg: GenCfg, taps: Optional[dict] = None, tag: str = "enc") -> torch.Tensor:
     """Encoder.forward, Full_model/Models_spatial_memory.py:413-436; PositionalEncoding.forward :46-48;
     EncoderLayer.forward Full_model/Layers.py:18-22."""
-    x = x + sd[p + ".position_enc.pos_table"][:, :x.shape[1]]
+    x = _drop(p + ".dropout", x + sd[p + ".position_enc.pos_table"][:, :x.shape[1]])        # :422
     for l in range(cfg.n_layers):
         q = f"{p}.layer_stack.{l}"
         x, _ = multi_head_attention(sd, q + ".slf_attn", x, x, x, cfg)
@@ -282,8 +367,8 @@ def generator_forward(sd: SD, cfg: GenCfg, spec: torch.Tensor, text: torch.Tenso
     text_embedding = text_encoder_tcn(sd, "text_encoder", text, cfg)
     feat = audio_encoder(sd, "audio_encoder", spec.unsqueeze(1), taps=taps)
     pr = prior_memory_encoder(sd, "prior_seq_encoder", prior, cfg)
-    emo = _lin(sd, "emotion_proj.2", _lin(sd, "emotion_proj.0", feat))
-    sem = _lin(sd, "semantic_proj.2", _lin(sd, "semantic_proj.0", feat))
+    emo = _lin(sd, "emotion_proj.2", _drop("emotion_proj.1", _lin(sd, "emotion_proj.0", feat)))              # :488-491
+    sem = _lin(sd, "semantic_proj.2", _drop("semantic_proj.1", _lin(sd, "semantic_proj.0", feat)))           # :509-512
     h = emo.reshape(emo.shape[0], -1)
     for i in (0, 2, 4):
         h = F.relu(_lin(sd, f"emotion_classifer_header.{i}", h))
@@ -293,8 +378,8 @@ def generator_forward(sd: SD, cfg: GenCfg, spec: torch.Tensor, text: torch.Tenso
     enc = encoder(sd, "encoder", fusion, cfg, taps=taps)
     dec = decoder(sd, "decoder", pr, enc, cfg, taps=taps)
     pose = dec
-    for i in (0, 2, 4, 6):
-        pose = _lin(sd, f"post_projector.{i}", pose)
+    for i in (0, 2, 4, 6):                              # Linear, Dropout(0.2), Linear, Dropout(0.2), Linear, Dropout(0.2), Linear (:528-536)
+        pose = _lin(sd, f"post_projector.{i}", pose if i == 0 else _drop(f"post_projector.{i - 1}", pose))
     if taps is not None:
         taps.update(audio_feat=feat, prior_enc=pr, fusion=fusion)
     return pose, emo, sem, emo_pred, text_embedding
@@ -302,7 +387,8 @@ def generator_forward(sd: SD, cfg: GenCfg, spec: torch.Tensor, text: torch.Tenso
 
 def generator_train_loss(sd: SD, cfg: GenCfg, spec, text, prior, target_pose, label):
     """One training objective of BASELINE configs[2] (SURVEY.md §8d cfg 3): 100 * SmoothL1/Huber(pose, target) + CE(emotion
-    logits, label), model in train() mode (batch-statistics BatchNorm), dropout p = 0.  Returns (loss, pose, emotion logits)."""
+    logits, label), model in train() mode (batch-statistics BatchNorm), every nn.Dropout the identity unless the caller injects masks
+    (`with dropout_masks(...)`).  Returns (loss, pose, emotion logits)."""
     with bn_training():
         pose, _emo, _sem, pred, _txt = generator_forward(sd, cfg, spec, text, prior, None)
     loss = 100.0 * F.smooth_l1_loss(pose, target_pose) + F.cross_entropy(pred, label)

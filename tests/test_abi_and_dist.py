@@ -123,8 +123,8 @@ def test_shard_range_properties():
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from emotiongestures_amd.dist import shard_range, shard_batch, gather_poses
-dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+from emotiongestures_amd.dist import shard_range, shard_batch, gather_poses, init_process_group
+init_process_group("gloo", int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
 n = 7
 full = torch.arange(n * 34 * 126, dtype=torch.float32).view(n, 34, 126)
@@ -140,7 +140,8 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     """N>1 path on CPU: two gloo ranks shard 7 clips 4/3, run independently, and all-gather the ragged pose shards."""
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, EG_DIST_STORE=str(tmp_path / "store"), WORLD_SIZE="2")         # file rendezvous: no fixed or probed TCP port
+    env.pop("MASTER_PORT", None)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]

@@ -29,6 +29,20 @@ def test_self_launch_two_workers_dry():
     assert rec["max_elapsed"] == 2.0                        # MAX over ranks of (1 + rank)
 
 
+def test_outer_launcher_env_rendezvous_dry():
+    """What the driver's torchrun does: RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, no EG_DIST_STORE -> env:// rendezvous."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, EG_BENCH_DRY="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29567")
+        env.pop("EG_DIST_STORE", None)
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    recs = [json.loads(ln) for o in outs for ln in o[0].splitlines() if ln.startswith("{")]
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and recs[0]["max_elapsed"] == 2.0
+
+
 def test_world_size_mismatch_is_refused():
     # an outer launcher that started 1 rank while --gpus says 2 (the round-1 bench silently reported n_gpus 1)
     env = dict(os.environ, EG_BENCH_DRY="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")

@@ -121,7 +121,8 @@ _WORKER = textwrap.dedent('''
     import torch.nn as nn
     from emotiongestures_amd.train.optim import GradBuckets, flatten_parameters
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emotiongestures_amd.dist import init_process_group
+    init_process_group("gloo", rank, world)
     torch.manual_seed(0)
     model = nn.Sequential(nn.Linear(300, 500), nn.ReLU(), nn.Linear(500, 700), nn.ReLU(), nn.Linear(700, 10))
     unused = nn.Linear(5, 5)                      # a parameter group that never receives a gradient
@@ -233,17 +234,71 @@ def test_gradient_buckets_two_gloo_ranks(tmp_path):
     (per-phase reductions between backward segments, fp32 and bf16 payloads) gives the same averaged gradients."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EG_ROOT=ROOT)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", EG_DIST_STORE=str(tmp_path / "store"), EG_ROOT=ROOT)
+        env.pop("MASTER_PORT", None)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}:\n{o[-3000:]}"
+
+
+def test_generator_gradients_with_dropout_on_oracle_vs_reference_golden():
+    """Dropout ON (round-5 verdict item 4): the oracle's train-mode forward with the library's masks injected at ITS Dropout sites against the
+    REFERENCE's own modules driven by the same masks under the same module names (tests/golden/make_golden_dropout_grad.py) -- loss, outputs and
+    every parameter gradient.  Pins the oracle's 26 Dropout placements (incl. Modules.py:21 on the attention probabilities); the masks are the
+    integer restatement of the HIP library's counter hash (oracle.dropout_keep_mask), which the GPU test compares with eg_dropout bit for bit."""
+    from oracle import emogest_oracle as O
+    from emotiongestures_amd.builders import build_mirror
+    from emotiongestures_amd.synth import hash_unit
+    z = np.load(os.path.join(GOLDEN, "dropout_grads.npz"))
+    batch, seed, mseed = [int(v) for v in z["gen/meta"]]
+    sd = {k: v.detach().clone() for k, v in build_mirror("spatial", 34, 126, 4, 4, seed=seed).state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    plan = O.dropout_site_plan(O.GenCfg(), batch)
+    masks, where = O.dropout_plan_masks(plan, mseed)
+    assert [list(w) for w in where] == z["gen/sites"].tolist() and [s for s, _sh, _p in plan] == list(z["gen/site_names"])
+    assert list(z["gen/reference_call_order"]) == list(z["gen/site_names"])            # the reference visits the sites in the library's order
+    # the keep rates are what p says (a wrong threshold or a stuck hash would show here), and the masks differ from site to site
+    for site, _shape, p in plan:
+        keep = float((masks[site] > 0).float().mean())
+        assert abs(keep - (1 - p)) < 0.02, (site, keep)
+    assert not torch.equal(masks["emotion_proj.1"], masks["semantic_proj.1"])
+    inp = synth_inputs(batch, 34, 126, 4, seed=seed)
+    target = torch.from_numpy((hash_unit("train.target_pose", batch * 34 * 126, seed) - 0.5).astype(np.float32).reshape(batch, 34, 126))
+    label = torch.from_numpy(inp["label"]).argmax(1)
+    seen = []
+
+    def inject(site, x):
+        if site not in masks:
+            return None
+        seen.append(site)
+        return masks[site]
+    with O.dropout_masks(inject):
+        loss, pose, pred = O.generator_train_loss(sd, O.GenCfg(), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                                  torch.from_numpy(inp["pre_pose"]), target, label)
+    loss.backward()
+    assert sorted(seen) == sorted(masks)
+    assert abs(float(loss.detach()) - float(z["gen/loss"])) / float(z["gen/loss"]) < 1e-5
+    assert float(z["gen/loss"]) != pytest.approx(float(np.load(os.path.join(GOLDEN, "grads.npz"))["gen/loss"]), rel=1e-3)       # not the p = 0 step
+    assert np.abs(pose.detach().numpy() - z["gen/pose"]).max() < 1e-4 and np.abs(pred.detach().numpy() - z["gen/emotion_prediction"]).max() < 1e-4
+    worst, n = 0.0, 0
+    for k, v in sd.items():
+        if f"gen/g/{k}/norm" not in z.files or k == "audio_encoder.final_conv1.bias":      # buffers, gradient-less parameters; the bias in front of a
+            continue                                                                          # train-mode BatchNorm (exactly zero: round-off on both sides)
+        tower = k.startswith("audio_encoder.feat_extractor.")       # ReLU-mask flips between two fp32 forwards move single tower gradients (see the GPU tests)
+        g = v.grad.detach().reshape(-1).double().numpy()
+        stride = max(1, g.size // 64)
+        ref_n, ref_s = float(z[f"gen/g/{k}/norm"]), z[f"gen/g/{k}/sample"].astype(np.float64)
+        e = abs(np.linalg.norm(g) - ref_n) / ref_n
+        worst, n = max(worst, e), n + 1
+        assert e < (2e-2 if tower else 2e-4), (k, e)
+        assert np.abs(g[::stride][:64] - ref_s).max() < (5e-2 if tower else 1e-3) * max(np.abs(ref_s).max(), ref_n / np.sqrt(g.size)), k
+    assert n >= 255, n
+    print(f"dropout-on oracle vs reference: {n} parameter gradients, worst norm error {worst:.2e}")
 
 
 def test_cvae_gradients_oracle_vs_reference_golden():
