@@ -347,7 +347,7 @@ def test_tower_site_backward_matches_reference_golden(site, precision, tol):
 
 
 # ---- network level -----------------------------------------------------------------------------------------------------------
-def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_flip=None):
+def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_flip=None, upstream_of_relu=(), upstream_tol=None):
     """Per-parameter relative L2 of the gradient.  Parameters under `tower_prefix` (the ReLU/BatchNorm convolution tower) get
     `tower_tol`: a ReLU's gradient is discontinuous at 0, the two fp32 forwards differ by ~6e-6, and ONE flipped mask element
     changes everything upstream of it (measured with tools/debug_block_grad.py: 2 of 253,952 mask elements of layer3.5.conv1
@@ -355,7 +355,10 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
     test_se_block_backward_on_real_activations).  Everything else must meet `tol`.
     behind_flip: the tower parameters that sit directly behind a flipped mask element at these weights / inputs, BY NAME -- only they may exceed
     2.5 x tower_tol (and must stay under 0.5: a flipped unit of an SE hidden layer with C/8 units x B samples is a large share of that layer's
-    gradient); every other tower parameter is held to 2.5 x tower_tol.  (None: the round-5 form, max < 0.5 for any tower parameter.)"""
+    gradient); every other tower parameter is held to 2.5 x tower_tol.  (None: the round-5 form, max < 0.5 for any tower parameter.)
+    upstream_of_relu / upstream_tol: name prefixes OUTSIDE the tower that still lie upstream of a ReLU (fusion_proj's and the classifier header's:
+    final_conv1, bn1, fc1, fc2, the projections feeding them) -- they inherit the gradient mass of a mask element decided differently there and are
+    held to `upstream_tol`; everything behind the last ReLU of its path meets `tol`."""
     worst, worst_tower, n, tight = 0.0, 0.0, 0, 0
     tower_errs = []
     outliers = {}
@@ -384,7 +387,10 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
                 print(f"   {k:60s} {e:.2e}")
         else:
             worst = max(worst, e)
-            assert e < tol, f"{k}: gradient rel-L2 {e:.2e}"
+            up = upstream_tol is not None and k.startswith(tuple(upstream_of_relu))
+            assert e < (upstream_tol if up else tol), f"{k}: gradient rel-L2 {e:.2e}"
+            if os.environ.get("EG_GRAD_REPORT") and e >= tol:
+                print(f"   {k:60s} {e:.2e}  (upstream of an MLP ReLU)")
     # tower: the bulk within tower_tol; an isolated parameter may sit right behind a flipped unit (an SE hidden layer has C/8 units
     # x B samples: one flipped unit is a large share of its gradient)
     te = np.sort(np.asarray(tower_errs))
@@ -399,8 +405,11 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
 
 # Tower parameters that sit directly behind a ReLU mask element the GPU's fp32 forward and the CPU oracle's decide differently at these synthetic
 # weights / inputs (found with EG_GRAD_REPORT=1; a kernel change that alters a summation order can move a flip and with it these lists)
-TED_STEP_BEHIND_FLIP = None
-DROPOUT_STEP_BEHIND_FLIP = None
+TED_STEP_BEHIND_FLIP = ()            # p = 0 step: no tower parameter above 5e-2 (worst 3.3e-3: layer1.1.se.fc.0)
+DROPOUT_STEP_BEHIND_FLIP = ()        # Dropout-ON step: the whole tower sits 1.1e-3 .. 3.3e-3 off (a mask element of an MLP ReLU downstream of it), none above 5e-2
+# outside the tower, but upstream of fusion_proj's / the classifier header's ReLUs (Models_spatial_memory.py:497-507,519-527)
+UPSTREAM_OF_MLP_RELU = ("audio_encoder.final_conv1", "audio_encoder.bn1", "audio_encoder.fc1", "audio_encoder.fc2", "emotion_proj.", "semantic_proj.",
+                        "fusion_proj.0.", "emotion_classifer_header.0.", "emotion_classifer_header.2.", "emotion_classifer_header.4.")
 
 
 def test_generator_train_step_gradients_match_oracle():
@@ -489,8 +498,13 @@ def test_generator_train_step_with_dropout_on_matches_oracle_and_reference():
     assert np.abs(emo.detach().cpu().numpy()[:, ::4, ::16] - z["gen/emotion_feature"]).max() < 1e-4
     p0 = np.load(os.path.join(GOLDEN, "grads.npz"))
     assert abs(float(loss.detach()) - float(p0["gen/loss"])) > 1e-2 * float(p0["gen/loss"])           # and really not the p = 0 step
-    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2, behind_flip=DROPOUT_STEP_BEHIND_FLIP)
-    assert n == 260
+    # With Dropout on, the kept activations are scaled by 1.25 and a few pre-activations of the MLP ReLUs land within fp32 round-off of zero: the two
+    # fp32 forwards decide such an element differently and everything UPSTREAM of that ReLU moves by its share of the gradient (measured: 3.0e-4 at
+    # final_conv1, 1.1e-3 .. 3.3e-3 across the tower) -- those parameters are named and held to 5e-3 / the tower bounds; everything behind the last
+    # ReLU of its path (encoder, decoder, post_projector, prior encoder, fusion_proj.2, the header's last layer) must meet 1e-4.
+    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2, behind_flip=DROPOUT_STEP_BEHIND_FLIP,
+                                                        upstream_of_relu=UPSTREAM_OF_MLP_RELU, upstream_tol=5e-3)
+    assert n == 260 and tight >= 120
     print(f"generator, Dropout ON: {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; "
           f"{tight} within 1e-4")
 
