@@ -13,6 +13,7 @@
 //                          channel-quad planar image [ci/4][pixel][4]: a ds_read_b128 per lane, bank-conflict
 //                          free for 16 consecutive pixels (plane stride = 0 mod 16 slots, stride 1; odd, stride 2),
 //   D: each lane owns 4 consecutive output channels of one pixel -> one 16-byte NHWC store per tile.
+#include <type_traits>
 #include "common.h"
 
 // (Measured and dropped in round 1: s_setprio around the MFMA cluster costs 20-50 % here -- hipcc stops interleaving the LDS
@@ -33,6 +34,7 @@ struct ConvArgs {
     // staging: x' = x * in_scale[ci] + in_shift[ci] for pixels inside the image, zero padding stays zero) -- split-bf16 kernels only
     const float* in_scale = nullptr; const float* in_shift = nullptr;
     int wrow = 0;                       // channel-split launches: row length of the weight images (the convolution's padded output channels)
+    const float* res_q = nullptr;       // DG2 only: a gradient on the dy grid ([B][H][W][cout]) added to the (even, even) phase -- the stride-2 1x1 shortcut's
     unsigned int* dbg = nullptr;        // diagnostic build only (EG_CONV32_STAMP=1): per-wave phase cycle sums of the persistent 32->32 kernel
 };
 
@@ -42,6 +44,15 @@ template <int S, int TH> struct ConvGeom {
     static constexpr int NPIX = IH * IW;
     static constexpr int PL = (S == 1) ? ((NPIX + 15) / 16 * 16) : (NPIX | 1);
     static constexpr int MT = TH * 2 / 4;
+};
+
+// Input gradient of a STRIDE-2 convolution (conv3x3_bf16_kernel, DG2): the tile is TH x 32 pixels of dy; a base pixel (i, j) owns the four dx pixels
+// (2i + py, 2j + px) and needs dy at (i, j), (i, j + 1), (i + 1, j), (i + 1, j + 1): halo of one row / column on the HIGH side only.
+template <int TH> struct ConvGeomDG2 {
+    static constexpr int IH = TH + 1;
+    static constexpr int IW = 33;
+    static constexpr int NPIX = IH * IW;
+    static constexpr int PL = (NPIX + 15) / 16 * 16;
 };
 
 // ---- fp32 MFMA path -------------------------------------------------------------------------
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
             const int id = wave * MT + t;
             const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
             const bool valid = (oy < a.Ho) && (ox < a.Wo);
-            f4 v = acc[t][n] + bi;
+            f4 v = acc[0][t][n] + bi;
             if (a.relu) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -204,10 +215,20 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 // weight images' row length `a.wrow`): small batches of the 64- and 128-channel stages have fewer pixel tiles than the chip has CUs (one clip: 8 tiles of
 // 128 -> 128), so the channels are spread over workgroups too.  Same pixel -> (wave, tile, lane) map (WM, MT) and the same K order as the unsplit
 // instantiation: every output element and every pooling partial is bitwise the same, whichever the launch function picks.
-template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS, int RING, bool SPLIT = false>
+//
+// DG2: the INPUT GRADIENT of a stride-2 convolution (F.conv2d's dgrad for the two `_make_layer` entry convolutions, ResNetSE34V2.py:40-55) on the same
+// machinery, phase-decomposed: x here is dy [B][H][W][CIN] (CIN = the convolution's output channels: the contraction), y is dx [B][Ho][Wo][cout],
+// Ho = the convolution's input height.  dx[2i + py][2j + px] only receives the taps whose parity matches: (even, even) 1 tap, (even, odd) / (odd, even)
+// 2, (odd, odd) 4 -- 9 tap-products per FOUR output pixels instead of the 36 a zero-upsampled stride-1 convolution would issue.  One step is still one
+// (tap, 32-channel chunk) with the same weight ring; it accumulates into the phase the tap belongs to (4 x the accumulators, hence the smaller
+// tiles of the launch table).  The weight images are those of the rotated, transposed filter the stride-1 input gradients use (pack flip):
+// image tap t' is the filter's tap (2 - t'/3, 2 - t'%3), which reads dy at (i + (t'/3 == 2), j + (t'%3 == 2)).
+template <int CIN, int NTT, int S, int TH, int WM, int WN, int TERMS, int RING, bool SPLIT = false, bool DG2 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const bf8* __restrict__ whi,
                                                            const bf8* __restrict__ wlo) {
-    using G = ConvGeom<S, TH>;
+    static_assert(!DG2 || (S == 1 && !SPLIT), "DG2 tiles the dy grid with unit stride");
+    using G = typename std::conditional<DG2, ConvGeomDG2<TH>, ConvGeom<S, TH>>::type;
+    constexpr int PH = DG2 ? 4 : 1;                 // output phases (accumulator sets)
     constexpr int COUTP = NTT * 16, IW = G::IW, NPIX = G::NPIX, PL = G::PL;
     constexpr int MT = TH * 2 / WM, NT = NTT / WN;
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
@@ -237,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
     }
     const int ty = tile_id / a.tiles_x, tx = tile_id - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * 32;
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int iy0 = DG2 ? oy0 : oy0 * S - 1, ix0 = DG2 ? ox0 : ox0 * S - 1;
 
     int pbase[MT];
 #pragma unroll
@@ -245,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         const int id = wm * MT + t;
         pbase[t] = ((id >> 1) * S) * IW + ((id & 1) * 16 + li) * S;
     }
-    f4 acc[MT][NT];
+    f4 acc[PH][MT][NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[t][n] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[ph][t][n] = (f4){0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ xb = a.x + (size_t)b * a.H * a.W * CIN;
 
     // one step's weights = NIMG runs of WIMG slots; 64-slot (1 KiB) pieces are dealt round-robin to the 4 waves
@@ -371,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         }
     };
     auto read_x = [&](Frags& f, int tap) {
-        const int kh = tap / 3, kw = tap - kh * 3, toff = kh * IW + kw;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = DG2 ? (kh == 2 ? IW : 0) + (kw == 2 ? 1 : 0) : kh * IW + kw;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             f.xh[t] = tile[kq * PL + pbase[t] + toff];
@@ -379,16 +403,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         }
     };
     static_assert(MT % 2 == 0, "a step's MFMAs are issued as two halves (pixel tiles)");
-    auto mfma_half = [&](const Frags& f, int half) {
+    auto mfma_half = [&](const Frags& f, int half, int tap) {
+        const int ph = DG2 ? (tap / 3 != 1 ? 2 : 0) + (tap % 3 != 1 ? 1 : 0) : 0;      // (py, px): a centre row / column tap lands on even rows / columns
 #pragma unroll
         for (int t = half * (MT / 2); t < (half + 1) * (MT / 2); ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if (TERMS == 3) {
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[n], f.xh[t], acc[t][n], 0, 0, 0);
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[t][n], 0, 0, 0);
+                    acc[ph][t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[n], f.xh[t], acc[ph][t][n], 0, 0, 0);
+                    acc[ph][t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xl[t], acc[ph][t][n], 0, 0, 0);
                 }
-                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[t][n], 0, 0, 0);
+                acc[ph][t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[n], f.xh[t], acc[ph][t][n], 0, 0, 0);
             }
     };
     static_assert(RING == 3, "schedule below assumes a 3-slot ring");
@@ -431,11 +456,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         for (int tap = 0; tap < 9; ++tap) {
             const int step = chunk * 9 + tap;
             if (step + 2 < NSTEP) issue_weights(step + 2, (tap + 2) % 3);
-            mfma_half(fr[tap & 1], 0);
+            mfma_half(fr[tap & 1], 0, tap);
             mid_sync(step + 2 < NSTEP);
             if (tap < 8) { read_w(fr[(tap + 1) & 1], tap + 1); read_x(fr[(tap + 1) & 1], tap + 1); }
-            mfma_half(fr[tap & 1], 1);
+            mfma_half(fr[tap & 1], 1, tap);
         }
+    }
+
+    if constexpr (DG2) {
+        // four phases: dx[2 * by + py][2 * bx + px] for the base pixel (by, bx) of the dy grid; the (even, even) phase also takes the gradient that
+        // arrives on the dy grid (the stride-2 1x1 shortcut reads exactly those pixels of x)
+        const size_t ohw = (size_t)a.Ho * a.Wo;
+        float* __restrict__ yb = a.y + (size_t)b * ohw * a.cout;
+        const float* __restrict__ rq = a.res_q ? a.res_q + (size_t)b * a.H * a.W * a.cout : nullptr;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int id = wm * MT + t;
+                const int by = oy0 + (id >> 1), bx = ox0 + (id & 1) * 16 + li;
+                const int oy = 2 * by + py, ox = 2 * bx + px;
+                if (by < a.H && bx < a.W && oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int co = (wn * NT + n) * 16 + kq * 4;
+                        if (co < a.cout) {
+                            f4 v = acc[ph][t][n];
+                            if (ph == 0 && rq) v += *reinterpret_cast<const f4*>(rq + ((size_t)by * a.W + bx) * a.cout + co);
+                            *reinterpret_cast<f4*>(yb + ((size_t)oy * a.Wo + ox) * a.cout + co) = v;
+                        }
+                    }
+                }
+            }
+        }
+        return;
     }
 
     // epilogue: v = acc + bias; relu; v*scale + shift.  Pixel offsets are 32-bit and computed once per pixel tile; the
@@ -462,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         const float* __restrict__ rb = a.res ? a.res + (size_t)b * hw * a.cout : nullptr;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            f4 v = acc[t][n] + bi;
+            f4 v = acc[0][t][n] + bi;
             if (a.relu) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -1056,6 +1111,19 @@ int launch_conv_split_t(ConvArgs a, int batch, const bf8* whi, const bf8* wlo, h
     hipLaunchKernelGGL(kern, dim3(a.tiles, batch, a.cout / (NTS * 16)), dim3(256), LDS_BYTES, st, a, whi, wlo);
     return eg_check_launch("conv3x3 (channel split)");
 }
+// Input gradient of a stride-2 convolution (conv3x3_bf16_kernel, DG2): KCH = the convolution's output channels (the contraction), NTN * 16 = its input
+// channels; grid over TH x 32 tiles of the dy grid.
+template <int KCH, int NTN, int TH, int WM, int WN>
+int launch_dgrad_s2_t(const ConvArgs& a, int batch, const bf8* whi, const bf8* wlo, hipStream_t st) {
+    constexpr int RING = 3;
+    using G = ConvGeomDG2<TH>;
+    constexpr size_t LDS_BYTES = sizeof(bf8) * (size_t)(2 * 4 * G::PL + RING * 2 * 4 * NTN * 16);
+    auto kern = conv3x3_bf16_kernel<KCH, NTN, 1, TH, WM, WN, 3, RING, false, true>;
+    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES, "conv3x3 (stride-2 input gradient)")) return rc;
+    dim3 grid(eg_cdiv(a.W, 32) * eg_cdiv(a.H, TH), batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, a, whi, wlo);
+    return eg_check_launch("conv3x3 (stride-2 input gradient)");
+}
 // how many ways to split the channels of a C -> C body convolution with `wgs` pixel-tile workgroups: keep the launch near one workgroup per CU
 int conv_channel_split(int wgs, int max_split) {
     const char* e = getenv("EG_CONV_SPLIT");            // A/B switch, read per call: 1 = never, 2, 4 (a captured graph keeps what it was captured with)
@@ -1270,6 +1338,34 @@ int conv3x3_dispatch(const float* x, const float* w, const float* bias, const fl
     return EG_ERR_UNSUPPORTED;
 }
 }  // namespace
+
+// dx = F.conv2d's input gradient of nn.Conv2d(cin -> cout, k = 3, pad = 1, stride = 2) (the `_make_layer` entry convolutions, ResNetSE34V2.py:40-55):
+// dy [batch][ho][wo][cout], w_flip = the packed images of the rotated, transposed filter (cout -> cin: the image the stride-1 input gradients use),
+// dx [batch][h][w][cin] with ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1.  res_q (optional): a gradient [batch][ho][wo][cin] that belongs to the
+// pixels (2i, 2j) of dx -- the stride-2 1x1 shortcut's input gradient (:43-47) -- added in the epilogue instead of scattered into a zero map.
+// Split-bf16 (EG_PREC_BF16X3) only; (cin, cout) in {(32, 64), (64, 128), (128, 256)}.  Every element of dx is written.
+extern "C" int eg_conv3x3_dgrad_s2(const float* dy, const float* w_flip, const float* res_q, float* dx, int32_t batch, int32_t h, int32_t wdt, int32_t cin,
+                                   int32_t cout, int32_t precision, void* stream) {
+    EG_REQUIRE(dy && w_flip && dx && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3_dgrad_s2: null pointer or empty shape");
+    EG_REQUIRE(precision == EG_PREC_BF16X3, EG_ERR_UNSUPPORTED, "eg_conv3x3_dgrad_s2: split-bf16 arithmetic only (precision %d)", precision);
+    EG_REQUIRE(eg_aligned16(dy) && eg_aligned16(w_flip) && eg_aligned16(dx) && (!res_q || eg_aligned16(res_q)), EG_ERR_ALIGN,
+               "eg_conv3x3_dgrad_s2: pointers must be 16-byte aligned");
+    ConvArgs a;
+    a.x = dy; a.w = w_flip; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr; a.y = dx; a.gap = nullptr;
+    a.H = (h - 1) / 2 + 1; a.W = (wdt - 1) / 2 + 1; a.Ho = h; a.Wo = wdt;          // the kernel's "input" is dy, its output dx
+    a.cout = cin; a.relu = 0; a.nchw = 0; a.tiles_x = eg_cdiv(a.W, 32); a.tiles = 0;
+    a.res_q = res_q;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t f32_floats = (size_t)9 * cout * cin;                              // the flipped image: cout "input" channels -> cin "output" channels
+    const bf8* whi = reinterpret_cast<const bf8*>(w_flip + f32_floats);
+    const bf8* wlo = whi + (size_t)9 * (cout / 8) * cin;
+    EgProfScope prof((int64_t)cin * 1000000 + (int64_t)cout * 1000 + 200 + 8, 2.0 * 9 * cin * cout * (double)a.H * a.W * batch, st);
+    if (cin == 32 && cout == 64) return launch_dgrad_s2_t<64, 2, 4, 4, 1>(a, batch, whi, wlo, st);
+    if (cin == 64 && cout == 128) return launch_dgrad_s2_t<128, 4, 2, 2, 2>(a, batch, whi, wlo, st);
+    if (cin == 128 && cout == 256) return launch_dgrad_s2_t<256, 8, 1, 1, 4>(a, batch, whi, wlo, st);
+    eg_set_error("eg_conv3x3_dgrad_s2: unsupported channels %d -> %d", cin, cout);
+    return EG_ERR_UNSUPPORTED;
+}
 
 extern "C" int eg_stem_conv(const float* x, const float* w9xc, const float* bias, const float* scale, const float* shift,
                             float* y, int32_t batch, int32_t h, int32_t wdt, int32_t c, void* stream) {

@@ -548,6 +548,7 @@ def _pack_conv(w, flip=False):
 
 
 PAD_WGRAD = True            # False: ragged-width weight gradients on the fp32 implicit GEMM (A/B switch of the tests)
+S2_DGRAD = __import__("os").environ.get("EG_S2_DGRAD", "1") != "0"      # False: stride-2 input gradients through the column product + col2im (A/B switch)
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -622,11 +623,19 @@ class _Conv3x3(torch.autograd.Function):
         ctx.stride, ctx.has_b, ctx.need_dx = stride, b is not None, x.requires_grad
         ctx.params = (w, b)
         ctx.passthrough = bool(passthrough)
+        ctx.pass_sub = passthrough == "sub"
         outs = (y,)
         if want_gap:
             ctx.mark_non_differentiable(gap)
             outs += (gap,)
-        if passthrough:         # a second use of x (the block's residual branch): its gradient comes back into THIS backward and is added in the
+        if ctx.pass_sub:
+            # the second consumer is the stride-2 1x1 shortcut (ResNetSE34V2.py:43-47), which reads x[:, ::s, ::s] only: hand it that quarter map; its
+            # gradient comes back on the quarter grid and the stride-2 input-gradient kernel adds it to the pixels it belongs to -- no zero-filled
+            # full-resolution map is written and re-read
+            xs = torch.empty(B, Ho, Wo, Ci, dtype=torch.float32, device=dev)
+            L.check(lib.eg_subsample(_ptr(xd), _ptr(xs), B, H, W, Ci, stride, 0, _stream(dev)), "eg_subsample")
+            outs += (xs,)
+        elif passthrough:       # a second use of x (the block's residual branch): its gradient comes back into THIS backward and is added in the
             outs += (x.view_as(x),)                 # dgrad launch's epilogue instead of a separate map-sized add (fork)
         return outs if len(outs) > 1 else y
 
@@ -638,6 +647,10 @@ class _Conv3x3(torch.autograd.Function):
         B, H, W, Ci = x.shape
         Co = w.shape[0]
         if dy is None:              # only the alias was used downstream
+            if dres is not None and ctx.pass_sub:
+                full = torch.empty_like(x)
+                L.check(lib.eg_subsample(_ptr(_chk(dres)), _ptr(full), B, H, W, Ci, ctx.stride, 1, _stream(x.device)), "eg_subsample")
+                dres = full
             return (_chk(dres) if dres is not None else None), None, None, None, None, None, None, None, None, None
         dyd = _chk(dy)
         if y is not None:
@@ -704,11 +717,24 @@ class _Conv3x3(torch.autograd.Function):
             L.check(lib.eg_conv3x3_se(_ptr(dyp), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, 64, Ci, 1, 0, 0, _PREC["conv"],
                                       _stream(dev)), "eg_conv3x3 (dgrad, padded)")
             dres = None
+        elif ctx.need_dx and ctx.stride == 2 and _PREC["conv"] == L.EG_PREC_BF16X3 and S2_DGRAD and (Ci, Co) in ((32, 64), (64, 128), (128, 256)):
+            # stride-2 entry convolution of a stage: the phase-decomposed MFMA input gradient (9 tap products per four dx pixels), the shortcut's
+            # quarter-grid gradient added in its epilogue -- instead of the [pixels, 9 Ci] column product + col2im (+ the zero-filled scatter)
+            wp = _pack_conv(w, flip=True)
+            dx = torch.empty_like(x)
+            rq = _chk(dres) if (dres is not None and ctx.pass_sub) else None
+            L.check(lib.eg_conv3x3_dgrad_s2(_ptr(dyd), _ptr(wp), _ptr(rq), _ptr(dx), B, H, W, Ci, Co, _PREC["conv"], _stream(dev)), "eg_conv3x3_dgrad_s2")
+            if rq is not None:
+                dres = None
         elif ctx.need_dx:
             wmat_t = w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()   # [(kh,kw,ci), co] = Wmat^T
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
             dx = torch.empty_like(x)
             L.check(lib.eg_im2col3x3(_ptr(dcol), _ptr(dx), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_col2im3x3")
+        if dres is not None and ctx.pass_sub:       # the shortcut's quarter-grid gradient on a path without the fused epilogue: scatter, then add
+            full = torch.empty_like(x)
+            L.check(lib.eg_subsample(_ptr(_chk(dres)), _ptr(full), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_subsample")
+            dres = full
         if dres is not None:        # passthrough on a path without the fused epilogue (or no dx wanted): the plain add
             dx = raw_ew(EW_ADD, dx, _chk(dres)) if dx is not None else _chk(dres)
         return dx, dw, db, None, None, None, None, None, None, None
@@ -717,7 +743,8 @@ class _Conv3x3(torch.autograd.Function):
 def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False, passthrough=False):
     """want_gap: also return the per-(clip, tile) channel sums of the output; defer_mask: the ReLU's backward is applied by the consumer;
     passthrough: also return an alias of the input for its second consumer (the residual branch) -- the two gradients are then summed in the
-    input-gradient launch's epilogue instead of by a `fork`."""
+    input-gradient launch's epilogue instead of by a `fork`; passthrough="sub" (stride > 1): that consumer is the strided 1x1 shortcut, the extra
+    output is x[:, ::stride, ::stride] and its gradient comes back on that grid."""
     aff = getattr(x_nhwc, "_eg_in_affine", None)        # a deferred BatchNorm produced x: (scale, shift) to apply while staging
     if aff is not None:
         return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough, aff[0], aff[1])

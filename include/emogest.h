@@ -520,6 +520,15 @@ int eg_conv3x3_wgrad_mfma_oihw(const float* x, const float* dy, float* dw, int32
 /* ... of a convolution whose input was x' = x * in_scale[ci] + in_shift[ci] (eg_conv3x3_sq_in_affine): the affine is re-applied while x is staged. */
 int eg_conv3x3_wgrad_mfma_oihw_in_affine(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dw, int32_t batch, int32_t h,
                                          int32_t w, int32_t cin, int32_t cout, float* workspace, int64_t workspace_floats, void* stream);
+/* Input gradient of nn.Conv2d(cin -> cout, k = 3, pad = 1, stride = 2) -- the `_make_layer` entry convolutions, Full_model/ResNetSE34V2.py:40-55 (F.conv2d's
+ * dgrad under autograd) -- on the split-bf16 matrix pipe, phase-decomposed: each dx pixel (2i + py, 2j + px) only receives the taps whose parity
+ * matches (9 tap products per four pixels).  dy [batch][ho][wo][cout] NHWC with ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1; w_flip = the packed
+ * images of the rotated, transposed filter (eg_pack_conv3x3 with flip = 1: what the stride-1 input gradients read); dx [batch][h][w][cin], every
+ * element written.  res_q (optional, [batch][ho][wo][cin]): a gradient that belongs to the pixels (2i, 2j) of dx -- the input gradient of the
+ * stride-2 1x1 shortcut (:43-47), which reads exactly those pixels -- added in the epilogue instead of being scattered into a zero map first.
+ * precision: EG_PREC_BF16X3 only; (cin, cout) in {(32, 64), (64, 128), (128, 256)}; else EG_ERR_UNSUPPORTED. */
+int eg_conv3x3_dgrad_s2(const float* dy, const float* w_flip, const float* res_q, float* dx, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                        int32_t precision, void* stream);
 /* Weight and bias gradient of nn.Linear on the split-bf16 matrix pipe (3 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate):
  *   dw[n][k] = sum_r dy[r][n] * x[r][k]   (dy [rows, n] at pitch ldy, x [rows, k] at pitch ldx, dw at pitch lddw);  db[n] = sum_r dy[r][n] (db may be NULL).
  * F.linear's parameter gradients under autograd (every nn.Linear of Full_model/Models_spatial_memory.py, SubLayers.py:30-84).  Deterministic: rows
