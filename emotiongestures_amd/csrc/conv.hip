@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
             const int id = wave * MT + t;
             const int oy = oy0 + (id >> 1), ox = ox0 + (id & 1) * 16 + li;
             const bool valid = (oy < a.Ho) && (ox < a.Wo);
-            f4 v = acc[0][t][n] + bi;
+            f4 v = acc[t][n] + bi;
             if (a.relu) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
