@@ -175,6 +175,38 @@ def test_conv_epilogue_squares_give_batchnorm_statistics(B, H, W, Ci, Co, s):
         F.flush_batch_counters()
 
 
+@pytest.mark.parametrize("B,H,W,C", [(16, 128, 124, 32), (3, 33, 70, 64), (64, 16, 20, 128), (2, 9, 9, 256)])
+def test_one_launch_batchnorm_statistics_are_bitwise_the_two_launch_path(B, H, W, C, monkeypatch):
+    """csrc/train.hip bn_stats_sq_small_kernel (batches of up to 64 clips: clip_sums_sq + bn_finalize_sq as one launch, same accumulators and fold
+    order) against the two launches (EG_BN_STATS_FUSED=0): mean, rstd, the folded affine, the running statistics and the per-clip sums of the SE
+    pooling -- identical bits, through both entry points (eg_bn_train_stats_sq / eg_bn_train_forward_sq)."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    tiles = int(lib.eg_conv3x3_gap_tiles(H, W, C, C, 1))
+    gap = T("gap", (2, B, tiles, C), -3, 5).to(DEV)
+    gap[1] = gap[1].abs() * 7 + gap[0] * gap[0] / 64
+    g, b = T("g", (C,), 0.5, 1.5).to(DEV), T("b", (C,)).to(DEV)
+    ws = torch.empty(int(lib.eg_colreduce_workspace_floats(C)), device=DEV)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EG_BN_STATS_FUSED", mode)
+        mean, rstd, aff = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(2, C, device=DEV)
+        rm, rv = T("rm", (C,)).to(DEV), T("rv", (C,), 0.5, 1.5).to(DEV)
+        L.check(lib.eg_bn_train_stats_sq(_ptr(gap), _ptr(gap[1]), tiles, B, _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(rm), _ptr(rv), _ptr(aff[0]), _ptr(aff[1]),
+                                         B * H * W, C, 0.1, 1e-5, _ptr(ws), _stream(torch.device(DEV))), "eg_bn_train_stats_sq")
+        mean2, rstd2, clip = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(B, C, device=DEV)
+        rm2, rv2 = T("rm", (C,)).to(DEV), T("rv", (C,), 0.5, 1.5).to(DEV)
+        L.check(lib.eg_bn_train_forward_sq(None, _ptr(gap), _ptr(gap[1]), tiles, B, None, None, None, _ptr(mean2), _ptr(rstd2), _ptr(clip), _ptr(rm2), _ptr(rv2),
+                                           B * H * W, C, 0.1, 1e-5, _ptr(ws), _stream(torch.device(DEV))), "eg_bn_train_forward_sq")
+        torch.cuda.synchronize()
+        outs[mode] = [t.clone() for t in (mean, rstd, aff, rm, rv, mean2, rstd2, clip, rm2, rv2)]
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert torch.equal(a_, b_)
+    ref_mean = gap[0].double().sum((0, 1)) / (B * H * W)
+    assert rel(outs["1"][0].cpu(), ref_mean.float().cpu()) < 1e-6 and float(outs["1"][7].abs().sum()) > 0
+
+
 def test_batchnorm_layernorm_se_attention():
     from emotiongestures_amd.train import functional as F
     from types import SimpleNamespace as NS
@@ -415,7 +447,7 @@ def test_tower_site_backward_matches_reference_golden(site, precision, tol):
 
 
 # ---- network level -----------------------------------------------------------------------------------------------------------
-def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_flip=None, strict=(), strict_tol=None):
+def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_flip=None, loose=(), loose_tol=None):
     """Per-parameter relative L2 of the gradient.  Parameters under `tower_prefix` (the ReLU/BatchNorm convolution tower) get
     `tower_tol`: a ReLU's gradient is discontinuous at 0, the two fp32 forwards differ by ~6e-6, and ONE flipped mask element
     changes everything upstream of it (measured with tools/debug_block_grad.py: 2 of 253,952 mask elements of layer3.5.conv1
@@ -424,7 +456,7 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
     behind_flip: the tower parameters that sit directly behind a flipped mask element at these weights / inputs, BY NAME -- only they may exceed
     2.5 x tower_tol (and must stay under 0.5: a flipped unit of an SE hidden layer with C/8 units x B samples is a large share of that layer's
     gradient); every other tower parameter is held to 2.5 x tower_tol.  (None: the round-5 form, max < 0.5 for any tower parameter.)
-    strict / strict_tol: name prefixes outside the tower held to the tighter `strict_tol` instead of `tol` (the parameters with no ReLU downstream)."""
+    loose / loose_tol: name prefixes OUTSIDE the tower that sit upstream of a ReLU element known to be decided differently: held to `loose_tol`."""
     worst, worst_tower, n, tight = 0.0, 0.0, 0, 0
     tower_errs = []
     outliers = {}
@@ -453,10 +485,10 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
                 print(f"   {k:60s} {e:.2e}")
         else:
             worst = max(worst, e)
-            st = strict_tol is not None and k.startswith(tuple(strict))
+            lo = loose_tol is not None and k.startswith(tuple(loose))
             if os.environ.get("EG_GRAD_REPORT"):
-                print(f"   {k:60s} {e:.2e}{'  (strict)' if st else ''}")
-            assert e < (strict_tol if st else tol), f"{k}: gradient rel-L2 {e:.2e}"
+                print(f"   {k:60s} {e:.2e}{'  (upstream of a flipped ReLU element)' if lo else ''}")
+            assert e < (loose_tol if lo else tol), f"{k}: gradient rel-L2 {e:.2e}"
     # tower: the bulk within tower_tol; an isolated parameter may sit right behind a flipped unit (an SE hidden layer has C/8 units
     # x B samples: one flipped unit is a large share of its gradient)
     te = np.sort(np.asarray(tower_errs))
@@ -471,13 +503,18 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
 
 # Tower parameters that sit directly behind a ReLU mask element the GPU's fp32 forward and the CPU oracle's decide differently at these synthetic
 # weights / inputs (found with EG_GRAD_REPORT=1; a kernel change that alters a summation order can move a flip and with it these lists)
+BEAT_STEP_BEHIND_FLIP = {"spatial": None, "memory": None}
+BEAT_LONG_STEP_BEHIND_FLIP = {"f32": None, "bf16x3": None}
+EMOTION_NET_BEHIND_FLIP = None
 TED_STEP_BEHIND_FLIP = ()            # p = 0 step: no tower parameter above 5e-2 (worst 3.3e-3: layer1.1.se.fc.0)
 DROPOUT_STEP_BEHIND_FLIP = ()        # Dropout-ON step: the whole tower sits 2e-4 .. 3.3e-3 off (a ReLU mask element downstream of it), none above 5e-2
-# Outside the tower every parameter except the ones BEHIND THE LAST ReLU of the network still lies upstream of one: the six PositionwiseFeedForward
-# hidden layers alone hold 68 x 2048 x 6 = 835 k ReLU elements (SubLayers.py:78), and an element whose pre-activation is within fp32 round-off of
-# zero is decided differently by the two fp32 forwards about once per step.  Such an element moves everything upstream of it by its share of the
-# gradient (measured with these masks: 1.8e-4 .. 3.9e-4 from fusion_proj.2 back to final_conv1).  Only these prefixes have no ReLU downstream:
-BEHIND_THE_LAST_RELU = ("decoder.layer_stack.2.pos_ffn.w_2.", "decoder.layer_stack.2.pos_ffn.layer_norm.", "post_projector.", "emotion_classifer_header.6.")
+# Outside the tower: with these masks ONE hidden unit of encoder.layer_stack.0.pos_ffn (relu(w_1 x), SubLayers.py:78; 68 x 2048 x 6 = 835 k such ReLU
+# elements in the step) has a pre-activation within fp32 round-off of zero and is decided differently by the GPU's and the CPU's fp32 forwards.  That
+# element carries 4e-4 of w_1's gradient and everything UPSTREAM of it inherits its share (measured 1.1e-4 .. 4.1e-4: the list below, and the whole
+# tower at 2e-4 .. 3.3e-3); every other parameter -- encoder layers 1-2, the decoder, post_projector, the prior encoder, layer 0's w_2 / LayerNorms --
+# agrees to 1.8e-6 .. 4e-6.  A Dropout site applied with a wrong mask, scale or placement moves the gradients behind it by O(1).
+DROPOUT_STEP_UPSTREAM_OF_THE_FLIP = ("audio_encoder.final_conv1", "audio_encoder.bn1", "audio_encoder.fc1", "audio_encoder.fc2", "emotion_proj.", "semantic_proj.",
+                                     "fusion_proj.", "encoder.layer_stack.0.slf_attn.", "encoder.layer_stack.0.pos_ffn.w_1.")
 
 
 def test_generator_train_step_gradients_match_oracle():
@@ -566,11 +603,9 @@ def test_generator_train_step_with_dropout_on_matches_oracle_and_reference():
     assert np.abs(emo.detach().cpu().numpy()[:, ::4, ::16] - z["gen/emotion_feature"]).max() < 1e-4
     p0 = np.load(os.path.join(GOLDEN, "grads.npz"))
     assert abs(float(loss.detach()) - float(p0["gen/loss"])) > 1e-2 * float(p0["gen/loss"])           # and really not the p = 0 step
-    # Tolerances: 1e-4 behind the last ReLU (nothing but fp32 round-off can differ there), 2e-3 for everything upstream of one (see
-    # BEHIND_THE_LAST_RELU), the tower's own bounds inside it.  A Dropout site applied with a wrong mask, scale or placement moves the affected
-    # gradients by O(1) -- three orders of magnitude above these bounds.
-    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 2e-3, "audio_encoder.feat_extractor.", 2e-2, behind_flip=DROPOUT_STEP_BEHIND_FLIP,
-                                                        strict=BEHIND_THE_LAST_RELU, strict_tol=1e-4)
+    # 1e-4 everywhere outside the tower except the named parameters upstream of the one flipped FFN unit (2e-3); the tower's own bounds inside it
+    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2, behind_flip=DROPOUT_STEP_BEHIND_FLIP,
+                                                        loose=DROPOUT_STEP_UPSTREAM_OF_THE_FLIP, loose_tol=2e-3)
     assert n == 260
     print(f"generator, Dropout ON: {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; "
           f"{tight} within 1e-4")
@@ -611,7 +646,8 @@ def test_beat_long_generator_train_step_matches_oracle(precision, tol):
     assert tuple(pose.shape) == (B, Fr, D)
     assert abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach()) < tol
     assert rel(pose.detach(), pose_ref.detach()) < tol
-    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 5 * tol, "audio_encoder.feat_extractor.", 2e-2 if precision == "f32" else 5e-2)
+    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 5 * tol, "audio_encoder.feat_extractor.", 2e-2 if precision == "f32" else 5e-2,
+                                                        behind_flip=BEAT_LONG_STEP_BEHIND_FLIP[precision])
     print(f"BEAT-long generator ({precision}): {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower {worst_tower:.2e}")
 
 
@@ -643,7 +679,7 @@ def test_beat_generator_train_step_matches_oracle(variant):
     assert abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-5
     assert rel(pose.detach(), pose_ref.detach()) < 2e-5
     n = 0
-    tower, rest = [], {}
+    tower, rest, tower_out = [], {}, {}
     for k, p in model.named_parameters():
         gr = sd[k].grad
         if gr is None or float(gr.abs().max()) == 0.0:
@@ -659,10 +695,16 @@ def test_beat_generator_train_step_matches_oracle(variant):
         e = rel(p.grad, gr)
         if k.startswith("audio_encoder.feat_extractor."):
             tower.append(e)
+            if e >= 5e-2:
+                tower_out[k] = e
         else:
             rest[k] = e
     te = np.sort(np.asarray(tower))
+    if tower_out:
+        print(f"BEAT {variant}: tower parameters above 5e-2 (behind a flipped ReLU mask element): " + ", ".join(f"{k} {e:.1e}" for k, e in tower_out.items()))
     assert np.median(te) < 2e-2 and te[-1] < 0.5, f"tower errors: median {np.median(te):.2e} max {te[-1]:.2e}"
+    stray = {k: e for k, e in tower_out.items() if BEAT_STEP_BEHIND_FLIP[variant] is not None and k not in BEAT_STEP_BEHIND_FLIP[variant]}
+    assert not stray, f"tower gradients off by more than 5e-2 outside the known flipped-mask sites: {stray}"
     # Outside the tower: everything BEHIND the last ReLU of a path agrees to fp32 round-off; parameters upstream of the projection MLPs' ReLUs
     # (final_conv1, bn1, fc1, fc2, the first projection layers) inherit the gradient mass of any mask element the two fp32 forwards decide
     # differently (measured here: 1.6e-3 at these inputs; every operator is held to 2e-5 on identical inputs by the operator tests above)
@@ -700,7 +742,7 @@ def test_emotion_net_train_step_and_adam():
     loss.backward()
     assert abs(float(loss) - float(z["emo/loss"])) / float(z["emo/loss"]) < 1e-5            # vs the REFERENCE's loss
     assert np.abs(logits.detach().cpu().numpy() - z["emo/logits"]).max() < 1e-4
-    worst, worst_tower, n, tight = _compare_param_grads(net, sd, 1e-4, "emotion_encoder.", 2e-2)
+    worst, worst_tower, n, tight = _compare_param_grads(net, sd, 1e-4, "emotion_encoder.", 2e-2, behind_flip=EMOTION_NET_BEHIND_FLIP)
     print(f"EmotionNet: {n} parameter gradients; MLP head worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; {tight} within 1e-4")
     # one Adam step vs torch.optim.Adam fed the SAME (HIP) gradients: the first step moves every weight by ~lr * sign(g), so the
     # optimiser has to be compared on identical gradients
