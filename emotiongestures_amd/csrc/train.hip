@@ -622,79 +622,6 @@ __global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __res
     }
 }
 
-// The two launches above as ONE for batches of up to 64 clips (the 16-clip share of the 8-GPU step: 26 BatchNorms x 2 launches of ~5 us, each
-// mostly latency): one wave per channel, lane b owns clip b -- it folds that clip's tile partials keeping clip_sums_sq_kernel's NG = 256 / C
-// interleaved accumulators and their fold order, then the clips are combined by the same wave_sum_d: every output is bitwise what the
-// two-launch path writes (tests/test_gpu_training.py compares them).
-template <int NG>
-__global__ __launch_bounds__(256) void bn_stats_sq_small_kernel(const float* __restrict__ gap, const float* __restrict__ gap_sq, int tiles, int B, int C,
-                                                                long rows, float eps, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                                float* __restrict__ run_mean, float* __restrict__ run_var, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float* __restrict__ aff_scale,
-                                                                float* __restrict__ aff_shift, float* __restrict__ clip_sum) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    float s[NG];
-    double sd[NG], q[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) { s[g] = 0.f; sd[g] = 0.0; q[g] = 0.0; }
-    if (lane < B) {
-        const float* __restrict__ gp = gap + (size_t)lane * tiles * C + c;
-        const float* __restrict__ gq = gap_sq + (size_t)lane * tiles * C + c;
-        for (int k0 = 0; k0 < tiles; k0 += NG) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int k = k0 + g;
-                if (k < tiles) {
-                    const float v = gp[(size_t)k * C];
-                    s[g] += v;
-                    sd[g] += (double)v;
-                    q[g] += (double)gq[(size_t)k * C];
-                }
-            }
-        }
-    }
-    float a = 0.f;
-    double ad = 0.0, aq = 0.0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) { a += s[g]; ad += sd[g]; aq += q[g]; }
-    if (clip_sum && lane < B) clip_sum[(size_t)lane * C + c] = a;
-    double S = 0.0, Q = 0.0;
-    if (lane < B) { S += ad; Q += aq; }
-    S = wave_sum_d(S);
-    Q = wave_sum_d(Q);
-    if (lane != 0) return;
-    const double m = S / (double)rows;
-    double var = Q / (double)rows - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (aff_scale) {
-        aff_scale[c] = rstd[c] * gamma[c];
-        aff_shift[c] = beta[c] - mean[c] * (rstd[c] * gamma[c]);
-    }
-    if (run_mean) {
-        const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
-    }
-}
-// -> true when the one-launch form was taken (batch <= 64, C in {32, 64, 128, 256}; EG_BN_STATS_FUSED=0, read per call, keeps the two launches: A/B and tests)
-static bool launch_bn_stats_sq_small(const float* gap, const float* gap_sq, int tiles, int batch, int c, long rows, float eps, float momentum, float* mean,
-                                     float* rstd, float* run_mean, float* run_var, const float* gamma, const float* beta, float* aff_scale, float* aff_shift,
-                                     float* clip_sum, hipStream_t st) {
-    if (batch > 64 || c < 32 || 256 % c) return false;
-    if (const char* e = getenv("EG_BN_STATS_FUSED")) { if (e[0] == '0') return false; }
-    const dim3 grid(eg_cdiv(c, 4)), block(256);
-    switch (256 / c) {
-        case 8: hipLaunchKernelGGL(bn_stats_sq_small_kernel<8>, grid, block, 0, st, gap, gap_sq, tiles, batch, c, rows, eps, momentum, mean, rstd, run_mean, run_var, gamma, beta, aff_scale, aff_shift, clip_sum); break;
-        case 4: hipLaunchKernelGGL(bn_stats_sq_small_kernel<4>, grid, block, 0, st, gap, gap_sq, tiles, batch, c, rows, eps, momentum, mean, rstd, run_mean, run_var, gamma, beta, aff_scale, aff_shift, clip_sum); break;
-        case 2: hipLaunchKernelGGL(bn_stats_sq_small_kernel<2>, grid, block, 0, st, gap, gap_sq, tiles, batch, c, rows, eps, momentum, mean, rstd, run_mean, run_var, gamma, beta, aff_scale, aff_shift, clip_sum); break;
-        default: hipLaunchKernelGGL(bn_stats_sq_small_kernel<1>, grid, block, 0, st, gap, gap_sq, tiles, batch, c, rows, eps, momentum, mean, rstd, run_mean, run_var, gamma, beta, aff_scale, aff_shift, clip_sum); break;
-    }
-    return true;
-}
-
 // SE gate of one clip from the pooled BatchNorm output, pooled[c] = gamma (clip_sum/HW - mean) rstd + beta = mean_hw(bn2(c2)):
 // h = relu(W1 pooled + b1), gate = sigmoid(W2 h + b2) (ResNetBlocks.py:92-96).  One workgroup per clip, C <= 256.
 __global__ __launch_bounds__(256) void se_gate_train_kernel(const float* __restrict__ clip_sum, const float* __restrict__ mean,
@@ -1661,16 +1588,11 @@ extern "C" int eg_bn_train_forward_sq(const float* x, const float* gap_partial, 
     EG_REQUIRE((int64_t)4 * batch * c <= eg_colreduce_workspace_floats(c) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EG_ERR_WORKSPACE,
                "eg_bn_train_forward_sq: batch %d does not fit the reduction workspace", batch);
     double* clip_d = reinterpret_cast<double*>(workspace);
-    if (launch_bn_stats_sq_small(gap_partial, gap_sq_partial, tiles, batch, c, (long)rows, eps, momentum, save_mean, save_rstd, running_mean, running_var, nullptr,
-                                 nullptr, nullptr, nullptr, clip_sum, ST)) {
-        if (int rc = eg_check_launch("bn_stats_sq (one launch)")) return rc;
-    } else {
-        hipLaunchKernelGGL(clip_sums_sq_kernel, dim3(batch), dim3(256), 0, ST, gap_partial, gap_sq_partial, tiles, c, clip_sum, clip_d);
-        if (int rc = eg_check_launch("clip_sums_sq")) return rc;
-        hipLaunchKernelGGL(bn_finalize_sq_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, clip_d, batch, c, (long)rows, eps, momentum, save_mean, save_rstd,
-                           running_mean, running_var);
-        if (int rc = eg_check_launch("bn_finalize_sq")) return rc;
-    }
+    hipLaunchKernelGGL(clip_sums_sq_kernel, dim3(batch), dim3(256), 0, ST, gap_partial, gap_sq_partial, tiles, c, clip_sum, clip_d);
+    if (int rc = eg_check_launch("clip_sums_sq")) return rc;
+    hipLaunchKernelGGL(bn_finalize_sq_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, clip_d, batch, c, (long)rows, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var);
+    if (int rc = eg_check_launch("bn_finalize_sq")) return rc;
     if (!y) return EG_OK;
     return launch_bn_apply(x, save_mean, save_rstd, gamma, beta, y, rows, c, ST);
 }
@@ -1687,9 +1609,6 @@ extern "C" int eg_bn_train_stats_sq(const float* gap_partial, const float* gap_s
     EG_REQUIRE((int64_t)4 * batch * c <= eg_colreduce_workspace_floats(c) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EG_ERR_WORKSPACE,
                "eg_bn_train_stats_sq: batch %d does not fit the reduction workspace", batch);
     double* clip_d = reinterpret_cast<double*>(workspace);
-    if (launch_bn_stats_sq_small(gap_partial, gap_sq_partial, tiles, batch, c, (long)rows, eps, momentum, save_mean, save_rstd, running_mean, running_var, gamma,
-                                 beta, aff_scale, aff_shift, nullptr, ST))
-        return eg_check_launch("bn_stats_sq (one launch)");
     hipLaunchKernelGGL(clip_sums_sq_kernel, dim3(batch), dim3(256), 0, ST, gap_partial, gap_sq_partial, tiles, c, (float*)nullptr, clip_d);
     if (int rc = eg_check_launch("clip_sums_sq")) return rc;
     hipLaunchKernelGGL(bn_finalize_sq_kernel, dim3(eg_cdiv(c, 4)), dim3(256), 0, ST, clip_d, batch, c, (long)rows, eps, momentum, save_mean, save_rstd,

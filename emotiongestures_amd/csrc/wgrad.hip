@@ -256,9 +256,9 @@ Plan plan_wgrad(int B, int H, int W, int Ci, int Co) {
     const int slots = 512;                                        // co-resident workgroups: 2 per CU (launch bounds; 68 KB LDS at 32 x 64)
     const int want = slots / p.nct > 8 ? slots / p.nct : 8;       // unit lists (each runs nct workgroups)
     p.R = H;
-    int min_r = 16;
-    if (const char* e = getenv("EG_WGRAD_MIN_R")) { const int v = atoi(e); if (v >= 2) min_r = v; }      // experiment hook (round 6 A/B)
-    while (B * p.strips * eg_cdiv(H, p.R) < want && p.R > min_r) p.R = (p.R + 1) / 2;
+    // 16-row chunks at least: 8-row chunks (twice the unit lists and partials at 16 clips) were measured slower, 7.92 vs 7.77 ms per step
+    // (profiles/r06_train_ab.txt)
+    while (B * p.strips * eg_cdiv(H, p.R) < want && p.R > 16) p.R = (p.R + 1) / 2;
     p.chunks = eg_cdiv(H, p.R);
     p.units = B * p.strips * p.chunks;
     p.upw = eg_cdiv(p.units, want);

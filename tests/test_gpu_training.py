@@ -175,38 +175,6 @@ def test_conv_epilogue_squares_give_batchnorm_statistics(B, H, W, Ci, Co, s):
         F.flush_batch_counters()
 
 
-@pytest.mark.parametrize("B,H,W,C", [(16, 128, 124, 32), (3, 33, 70, 64), (64, 16, 20, 128), (2, 9, 9, 256)])
-def test_one_launch_batchnorm_statistics_are_bitwise_the_two_launch_path(B, H, W, C, monkeypatch):
-    """csrc/train.hip bn_stats_sq_small_kernel (batches of up to 64 clips: clip_sums_sq + bn_finalize_sq as one launch, same accumulators and fold
-    order) against the two launches (EG_BN_STATS_FUSED=0): mean, rstd, the folded affine, the running statistics and the per-clip sums of the SE
-    pooling -- identical bits, through both entry points (eg_bn_train_stats_sq / eg_bn_train_forward_sq)."""
-    from emotiongestures_amd import _lib as L
-    from emotiongestures_amd.engine import _ptr, _stream
-    lib = L.load()
-    tiles = int(lib.eg_conv3x3_gap_tiles(H, W, C, C, 1))
-    gap = T("gap", (2, B, tiles, C), -3, 5).to(DEV)
-    gap[1] = gap[1].abs() * 7 + gap[0] * gap[0] / 64
-    g, b = T("g", (C,), 0.5, 1.5).to(DEV), T("b", (C,)).to(DEV)
-    ws = torch.empty(int(lib.eg_colreduce_workspace_floats(C)), device=DEV)
-    outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("EG_BN_STATS_FUSED", mode)
-        mean, rstd, aff = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(2, C, device=DEV)
-        rm, rv = T("rm", (C,)).to(DEV), T("rv", (C,), 0.5, 1.5).to(DEV)
-        L.check(lib.eg_bn_train_stats_sq(_ptr(gap), _ptr(gap[1]), tiles, B, _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(rm), _ptr(rv), _ptr(aff[0]), _ptr(aff[1]),
-                                         B * H * W, C, 0.1, 1e-5, _ptr(ws), _stream(torch.device(DEV))), "eg_bn_train_stats_sq")
-        mean2, rstd2, clip = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(B, C, device=DEV)
-        rm2, rv2 = T("rm", (C,)).to(DEV), T("rv", (C,), 0.5, 1.5).to(DEV)
-        L.check(lib.eg_bn_train_forward_sq(None, _ptr(gap), _ptr(gap[1]), tiles, B, None, None, None, _ptr(mean2), _ptr(rstd2), _ptr(clip), _ptr(rm2), _ptr(rv2),
-                                           B * H * W, C, 0.1, 1e-5, _ptr(ws), _stream(torch.device(DEV))), "eg_bn_train_forward_sq")
-        torch.cuda.synchronize()
-        outs[mode] = [t.clone() for t in (mean, rstd, aff, rm, rv, mean2, rstd2, clip, rm2, rv2)]
-    for a_, b_ in zip(outs["1"], outs["0"]):
-        assert torch.equal(a_, b_)
-    ref_mean = gap[0].double().sum((0, 1)) / (B * H * W)
-    assert rel(outs["1"][0].cpu(), ref_mean.float().cpu()) < 1e-6 and float(outs["1"][7].abs().sum()) > 0
-
-
 def test_batchnorm_layernorm_se_attention():
     from emotiongestures_amd.train import functional as F
     from types import SimpleNamespace as NS
@@ -503,9 +471,9 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
 
 # Tower parameters that sit directly behind a ReLU mask element the GPU's fp32 forward and the CPU oracle's decide differently at these synthetic
 # weights / inputs (found with EG_GRAD_REPORT=1; a kernel change that alters a summation order can move a flip and with it these lists)
-BEAT_STEP_BEHIND_FLIP = {"spatial": None, "memory": None}
-BEAT_LONG_STEP_BEHIND_FLIP = {"f32": None, "bf16x3": None}
-EMOTION_NET_BEHIND_FLIP = None
+BEAT_STEP_BEHIND_FLIP = {"spatial": (), "memory": ()}                # no tower parameter above 5e-2 in either variant
+BEAT_LONG_STEP_BEHIND_FLIP = {"f32": (), "bf16x3": ()}               # none above 2.5 x the tower bound
+EMOTION_NET_BEHIND_FLIP = ("emotion_encoder.layer1.1.se.fc.0.weight", "emotion_encoder.layer1.1.se.fc.0.bias")       # 7.8e-2: one hidden SE unit (4 units x 2 samples)
 TED_STEP_BEHIND_FLIP = ()            # p = 0 step: no tower parameter above 5e-2 (worst 3.3e-3: layer1.1.se.fc.0)
 DROPOUT_STEP_BEHIND_FLIP = ()        # Dropout-ON step: the whole tower sits 2e-4 .. 3.3e-3 off (a ReLU mask element downstream of it), none above 5e-2
 # Outside the tower: with these masks ONE hidden unit of encoder.layer_stack.0.pos_ffn (relu(w_1 x), SubLayers.py:78; 68 x 2048 x 6 = 835 k such ReLU
@@ -703,7 +671,7 @@ def test_beat_generator_train_step_matches_oracle(variant):
     if tower_out:
         print(f"BEAT {variant}: tower parameters above 5e-2 (behind a flipped ReLU mask element): " + ", ".join(f"{k} {e:.1e}" for k, e in tower_out.items()))
     assert np.median(te) < 2e-2 and te[-1] < 0.5, f"tower errors: median {np.median(te):.2e} max {te[-1]:.2e}"
-    stray = {k: e for k, e in tower_out.items() if BEAT_STEP_BEHIND_FLIP[variant] is not None and k not in BEAT_STEP_BEHIND_FLIP[variant]}
+    stray = {k: e for k, e in tower_out.items() if k not in BEAT_STEP_BEHIND_FLIP[variant]}
     assert not stray, f"tower gradients off by more than 5e-2 outside the known flipped-mask sites: {stray}"
     # Outside the tower: everything BEHIND the last ReLU of a path agrees to fp32 round-off; parameters upstream of the projection MLPs' ReLUs
     # (final_conv1, bn1, fc1, fc2, the first projection layers) inherit the gradient mass of any mask element the two fp32 forwards decide
@@ -1279,7 +1247,8 @@ def test_bf16x3_training_step_tracks_the_f32_step():
     assert float(np.median(tower)) < 2e-2
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 31, 128, 128), (3, 20, 62, 64, 64), (2, 37, 70, 32, 32), (1, 5, 9, 64, 32), (2, 33, 33, 32, 64), (5, 32, 31, 256, 256)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 31, 128, 128), (3, 20, 62, 64, 64), (2, 37, 70, 32, 32), (1, 5, 9, 64, 32), (2, 33, 33, 32, 64), (5, 32, 31, 256, 256),
+                                         (300, 16, 33, 32, 32), (150, 8, 40, 64, 64)])       # the last two: more units than unit lists (two units per workgroup)
 def test_conv3x3_wgrad_mfma_matches_fp32_wgrad(B, H, W, Ci, Co):
     """eg_conv3x3_wgrad_mfma (split-bf16, pixels transposed while staged) against the fp32 implicit-GEMM weight gradient and, for
     one tap, a float64 einsum: ragged strips (W % 32 != 0), row chunks, several units per workgroup, 1..8 channel tiles."""
