@@ -515,7 +515,29 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
             # data parallel: the step is cut into per-bucket graph segments (forward + the backward up to bucket 0 complete, then one segment per
             # further bucket); bucket k's all-reduce runs on the side stream while segment k+1 replays, Adam follows the last reduction
             gb.payload = payload or os.environ.get("EG_GRAD_PAYLOAD", "f32")          # "bf16": buckets travel as bfloat16 (half the xGMI bytes)
-            ss = SegmentedStep(forward_loss, gb, opt, device=dev, warmup=max(1, warmup), stochastic=bool(dropout))
+            # the emotion CVAE's forward + backward beside the generator's losses and backward here too (as in the one-graph step above): forked inside
+            # segment 0's loss function, joined at the end of segment 0 (after_backward), all inside that captured segment
+            side_dp = torch.cuda.Stream(dev) if os.environ.get("EG_TRAIN_SIDE_CVAE", "1") != "0" else None
+            hold = {}
+
+            def loss_dp():
+                cur = torch.cuda.current_stream(dev)
+                pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+                emo_d = emo.detach()
+                side_dp.wait_stream(cur)
+                with torch.cuda.stream(side_dp):
+                    rec, mu, logvar = vae(emo_d, g["label"], eps)
+                    loss_v = F.add(F.smooth_l1_loss(rec, emo_d, 1.0, 1.0), F.kld_loss(mu, logvar, 1.0))
+                    loss_v.backward()
+                    hold["v"] = loss_v.detach()
+                return F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label))
+
+            def join_dp(step_):
+                torch.cuda.current_stream(dev).wait_stream(side_dp)
+                step_.loss = F.add(step_.loss.detach(), hold["v"])            # the reported loss: generator + CVAE, as the one-stream step's
+
+            ss = SegmentedStep(forward_loss if side_dp is None else loss_dp, gb, opt, device=dev, warmup=max(1, warmup), stochastic=bool(dropout),
+                               after_backward=None if side_dp is None else join_dp)
             run = lambda: ss.run(exposed=ar_ms)
             seg[0] = ss
             mode = f"{ss.n_segments} hipGraph segments per step (backward cut at the tower output and per tower stage), bucket all-reduces between them on a side stream ({gb.payload} payload)"

@@ -106,11 +106,16 @@ class SegmentedStep:
     loss_fn() runs the train-mode forward and returns the loss tensor (no zero_grad / backward / optimiser calls inside).
     use_graphs=False issues the same phases eagerly (the CPU test of the bucket ordering; also the fallback while debugging).
     stochastic=True: the model's dropout is on (`train_dropout`): the mask epoch moves to the device before the warm-up, so that every replay
-    of the segments draws fresh masks (forward and backward of one step share the epoch: it advances once per step, in segment 0)."""
+    of the segments draws fresh masks (forward and backward of one step share the epoch: it advances once per step, in segment 0).
+    after_backward: see __init__."""
 
-    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower", "layer3", "layer2"), warmup: int = 3, use_graphs: bool = True, stochastic: bool = False):
+    def __init__(self, loss_fn, buckets, optimizer, device=None, cuts=("tower", "layer3", "layer2"), warmup: int = 3, use_graphs: bool = True, stochastic: bool = False,
+                 after_backward=None):
         from . import nets
         self.loss_fn, self.gb, self.opt, self.nets = loss_fn, buckets, optimizer, nets
+        # after_backward(step): called at the end of phase 0, behind loss.backward() -- where a loss_fn that forked part of the step onto another stream
+        # (bench.py: the emotion CVAE's forward + backward beside the generator's) joins it again, inside the captured segment; it may replace step.loss
+        self.after_backward = after_backward
         self.ctx = nets.CutContext(cuts)
         self.use_graphs = bool(use_graphs)
         self.dev = torch.device(device) if device is not None else buckets.fp.grad.device
@@ -166,6 +171,8 @@ class SegmentedStep:
         finally:
             self.nets._CUTS["ctx"] = None
         self.loss.backward()
+        if self.after_backward is not None:
+            self.after_backward(self)
         return list(self.gb.launched)
 
     def _phase_cut(self, i):
