@@ -518,6 +518,8 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
             # the emotion CVAE's forward + backward beside the generator's losses and backward here too (as in the one-graph step above): forked inside
             # segment 0's loss function, joined at the end of segment 0 (after_backward), all inside that captured segment
             side_dp = torch.cuda.Stream(dev) if os.environ.get("EG_TRAIN_SIDE_CVAE", "1") != "0" else None
+            if side_dp is not None and os.environ.get("EG_TRAIN_DP_AUX", "1") != "0":
+                model.aux_stream = torch.cuda.Stream(dev)        # the generator's text branch and prior-pose branch beside its audio tower, as in the one-graph step
             hold = {}
 
             def loss_dp():
