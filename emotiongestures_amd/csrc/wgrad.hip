@@ -36,6 +36,12 @@ struct WgradArgs {
     const float* in_scale = nullptr; const float* in_shift = nullptr;      // x' = x * in_scale[ci] + in_shift[ci] (in-image pixels) while staging: the folded BatchNorm
 };
 
+// Staging lanes whose pixel lies outside the image (or whose stage is outside the unit's rows) load from this line instead of branching around the
+// loads and zero-filling their registers: ~200 VALU + ~125 SALU per step against 54 MFMAs (profiles/r06_wgrad_pmc.txt), a quarter of them the
+// predication forest and register zero-fills of load_stage -> 158 + 112 with this line; same-box A/B: 190 -> 182 / 138.6 -> 135 / 138 -> 134 us per call
+// at 128 clips (32 / 64 / 128 channels), bitwise the same gradients (profiles/r06_train_ab.txt).
+__device__ __attribute__((aligned(64))) float eg_wgrad_zero_line[16];
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -112,17 +118,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(WgradArgs a)
         // r0 + i - 5 from the x stages i-5 .. i-3 (ring slots & 3) and the dy stage i-3 (slot & 1) while stage i-2 is written.
         f4 pv[3][4];
         auto load_stage = [&](f4 (&dst)[4], int j) {
-            dst[0] = dst[1] = dst[2] = dst[3] = (f4){0.f, 0.f, 0.f, 0.f};
             const int row = is_x ? r0 - 1 + j : r0 + j - 2;
             const bool rv = is_x ? (row >= 0 && row < a.H && j <= n + 1) : (is_d && j >= 2 && row < r1);
-            if (rv) {
-                const float* p = sp + (size_t)row * a.W * sC;
-                if (v0) { dst[0] = *reinterpret_cast<const f4*>(p); dst[1] = *reinterpret_cast<const f4*>(p + 4); }
-                if (v1) { dst[2] = *reinterpret_cast<const f4*>(p + sC); dst[3] = *reinterpret_cast<const f4*>(p + sC + 4); }
-                if (affine) {               // in-image pixels only: what lies outside stays the zero padding of the normalised map
-                    if (v0) { dst[0] = dst[0] * isc0 + ish0; dst[1] = dst[1] * isc1 + ish1; }
-                    if (v1) { dst[2] = dst[2] * isc0 + ish0; dst[3] = dst[3] * isc1 + ish1; }
-                }
+            const float* p = sp + (size_t)row * a.W * sC;
+            const bool in0 = rv && v0, in1 = rv && v1;
+            const float* p0 = in0 ? p : eg_wgrad_zero_line;                 // branch-free: out-of-image lanes read zeros (see eg_wgrad_zero_line)
+            const float* p1 = in1 ? p + sC : eg_wgrad_zero_line;
+            dst[0] = *reinterpret_cast<const f4*>(p0); dst[1] = *reinterpret_cast<const f4*>(p0 + 4);
+            dst[2] = *reinterpret_cast<const f4*>(p1); dst[3] = *reinterpret_cast<const f4*>(p1 + 4);
+            if (affine) {               // in-image pixels only: what lies outside stays the zero padding of the normalised map
+                if (in0) { dst[0] = dst[0] * isc0 + ish0; dst[1] = dst[1] * isc1 + ish1; }
+                if (in1) { dst[2] = dst[2] * isc0 + ish0; dst[3] = dst[3] * isc1 + ish1; }
             }
         };
         auto write_stage = [&](const f4 (&src)[4], int j) {
