@@ -135,11 +135,11 @@ SIGNATURES = {
     "eg_bn_train_forward_sq": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
     "eg_conv3x3_sq": (C.c_int, [_P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "eg_se_gate_train_forward": (C.c_int, [_P] * 12 + [_I, _I, _I, _P]),
-    "eg_se_tail_forward": (C.c_int, [_P] * 8 + [_I, _I, _I, _P]),
-    "eg_se_tail_backward_reduce": (C.c_int, [_P] * 6 + [_I, _I, _I, _P, _P]),
+    "eg_se_tail_forward": (C.c_int, [_P] * 9 + [_I, _I, _I, _P]),
+    "eg_se_tail_backward_reduce": (C.c_int, [_P] * 7 + [_I, _I, _I, _P, _P]),
     "eg_se_gate_train_backward": (C.c_int, [_P] * 16 + [_I, _I, _I, _P]),
     "eg_se_tail_backward_finish": (C.c_int, [_P] * 14 + [_I, _I, _I, _P]),
-    "eg_se_tail_backward_apply": (C.c_int, [_P] * 12 + [_I, _I, _I, _P]),
+    "eg_se_tail_backward_apply": (C.c_int, [_P] * 13 + [_I, _I, _I, _P]),
     "eg_colsum": (C.c_int, [_P, _P, _P, _P, _L, _I, _P, _P]),
     "eg_elementwise": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, _P]),
     "eg_conv3x3_wgrad_mfma_workspace_floats": (_L, [_I, _I, _I, _I, _I]),

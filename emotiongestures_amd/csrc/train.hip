@@ -342,13 +342,15 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
     }
 }
+// ReLU mask of a map as one nibble per float4 (bit k = component k > 0), eight float4 indices per 32-bit word (written by se_tail_fwd_kernel)
+__device__ __forceinline__ unsigned relu_nibble(const unsigned* __restrict__ bits, size_t i4) { return (bits[i4 >> 3] >> (4 * (unsigned)(i4 & 7))) & 15u; }
 // Fast path of level 1 when C divides 1024: the [rows, C] block is read as one float4 stream, thread t always sees the channel quad
 // (4t) mod C, 256 threads x 16 B = 4 KB per block-iteration fully coalesced; partials are combined through LDS in a fixed order.
 // Segmented: blockIdx.y = segment (a clip for the SE pooling, 1 segment for BatchNorm / bias / LayerNorm-affine sums),
 // blockIdx.x = chunk of rows inside the segment; part[seg][chunk][2][C].
 __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
                                                                float* __restrict__ part, long seg_rows, int C, long rows_per, int mode,
-                                                               const float* __restrict__ mask) {
+                                                               const float* __restrict__ mask, const unsigned* __restrict__ mask_bits = nullptr) {
     __shared__ f4 s0[256], s1[256];
     const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const long r0 = (long)chunk * rows_per, r1 = (r0 + rows_per < seg_rows) ? r0 + rows_per : seg_rows;
@@ -360,6 +362,14 @@ __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __re
     const f4* a4 = reinterpret_cast<const f4*>(a + base);
     const f4* b4 = b ? reinterpret_cast<const f4*>(b + base) : nullptr;
     const f4* m4 = mask ? reinterpret_cast<const f4*>(mask + base) : nullptr;
+    const size_t g4 = base >> 2;                // float4 index of this block's first element in the whole map (mode 4 with mask_bits: the nibble index)
+    auto mload = [&](size_t f) -> f4 {
+        if (mask_bits) {
+            const unsigned nb = relu_nibble(mask_bits, g4 + f);
+            return (f4){(nb & 1u) ? 1.f : 0.f, (nb & 2u) ? 1.f : 0.f, (nb & 4u) ? 1.f : 0.f, (nb & 8u) ? 1.f : 0.f};
+        }
+        return m4[f];
+    };
     f4 u = (f4){0.f, 0.f, 0.f, 0.f}, v = u;
     const f4 zero4 = (f4){0.f, 0.f, 0.f, 0.f};
     auto fold = [&](f4 x, const f4& y, const f4& m) {         // one float4 of the stream into (u, v); same per-thread order as a plain loop
@@ -380,13 +390,13 @@ __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __re
         const f4 x0 = a4[f], x1 = a4[f + 256], x2 = a4[f + 512], x3 = a4[f + 768];
         f4 y0 = zero4, y1 = zero4, y2 = zero4, y3 = zero4, m0 = zero4, m1 = zero4, m2 = zero4, m3 = zero4;
         if (b4) { y0 = b4[f]; y1 = b4[f + 256]; y2 = b4[f + 512]; y3 = b4[f + 768]; }
-        if (mode == 4) { m0 = m4[f]; m1 = m4[f + 256]; m2 = m4[f + 512]; m3 = m4[f + 768]; }
+        if (mode == 4) { m0 = mload(f); m1 = mload(f + 256); m2 = mload(f + 512); m3 = mload(f + 768); }
         fold(x0, y0, m0);
         fold(x1, y1, m1);
         fold(x2, y2, m2);
         fold(x3, y3, m3);
     }
-    for (; f < n4; f += 256) fold(a4[f], b4 ? b4[f] : zero4, mode == 4 ? m4[f] : zero4);
+    for (; f < n4; f += 256) fold(a4[f], b4 ? b4[f] : zero4, mode == 4 ? mload(f) : zero4);
     s0[tid] = u;
     s1[tid] = v;
     __syncthreads();
@@ -655,7 +665,8 @@ __global__ __launch_bounds__(256) void se_gate_train_kernel(const float* __restr
 // out = relu(bn2(c2) * gate[b,c] + res): the block's tail in one pass (bn2's output is never written; the backward pass recomputes it).
 __global__ __launch_bounds__(256) void se_tail_fwd_kernel(const f4* __restrict__ c2, const f4* __restrict__ res, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ gate, f4* __restrict__ out, size_t n4, int hwq, int cq_n) {
+                                                          const float* __restrict__ gate, f4* __restrict__ out, size_t n4, int hwq, int cq_n,
+                                                          unsigned* __restrict__ relu_bits) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % cq_n) * 4;
         const size_t b = i / (size_t)hwq;
@@ -667,6 +678,15 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(const f4* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = fmaxf(((x[k] - mu[k]) * rs[k] * ga[k] + be[k]) * gt[k] + r[k], 0.f);
         out[i] = v;
+        if (relu_bits) {
+            // the ReLU mask [out > 0] as one nibble per float4 (bit k = component k), eight float4 indices per word: the backward passes read 1/32 of
+            // a map instead of `out`.  n4 is a multiple of 8 and i = tid (mod 8), so the eight lanes of a word are in or out of this iteration together.
+            unsigned w = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * (threadIdx.x & 7));
+            w |= __shfl_xor(w, 1, 64);
+            w |= __shfl_xor(w, 2, 64);
+            w |= __shfl_xor(w, 4, 64);
+            if ((threadIdx.x & 7) == 0) relu_bits[i >> 3] = w;
+        }
     }
 }
 
@@ -764,11 +784,19 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(const f4* __rest
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ gate,
                                                                 const float* __restrict__ dgap_hw, const float* __restrict__ m1, const float* __restrict__ m2,
-                                                                f4* __restrict__ dc2, f4* __restrict__ dres, size_t n4, int hwq, int cq_n) {
+                                                                f4* __restrict__ dc2, f4* __restrict__ dres, size_t n4, int hwq, int cq_n,
+                                                                const unsigned* __restrict__ relu_bits) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % cq_n) * 4;
         const size_t b = i / (size_t)hwq;
-        const f4 d = dout[i], o = out[i], x = c2[i];
+        const f4 d = dout[i], x = c2[i];
+        f4 o;
+        if (relu_bits) {
+            const unsigned nb = relu_nibble(relu_bits, i);
+            o = (f4){(nb & 1u) ? 1.f : 0.f, (nb & 2u) ? 1.f : 0.f, (nb & 4u) ? 1.f : 0.f, (nb & 8u) ? 1.f : 0.f};
+        } else {
+            o = out[i];
+        }
         const f4 mu = *reinterpret_cast<const f4*>(mean + c), rs = *reinterpret_cast<const f4*>(rstd + c), ga = *reinterpret_cast<const f4*>(gamma + c);
         const f4 a1 = *reinterpret_cast<const f4*>(m1 + c), a2 = *reinterpret_cast<const f4*>(m2 + c);
         const f4 gt = *reinterpret_cast<const f4*>(gate + b * (size_t)(cq_n * 4) + c);
@@ -1461,7 +1489,7 @@ namespace {
 constexpr long COL_MAX_PART = 2048;       // level-1 partials per reduction: 2048 workgroups x >= 64 KB keep 8 workgroups per CU streaming
 // rows = rows per segment; nseg segments back to back; partials part[seg][nblk][2][c] with nseg * nblk <= COL_MAX_PART
 int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, int c, int mode, float* part, int* nblk_out, hipStream_t st,
-               int nseg = 1, const float* mask = nullptr) {
+               int nseg = 1, const float* mask = nullptr, const unsigned* mask_bits = nullptr) {
     const bool fast = (c >= 4) && (1024 % c == 0) && eg_aligned16(a) && (!b || eg_aligned16(b));
     long cap = COL_MAX_PART / nseg;
     if (cap < 1) cap = 1;
@@ -1472,7 +1500,7 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
     nblk = (rows + rows_per - 1) / rows_per;
     *nblk_out = (int)nblk;
     if (fast) {
-        hipLaunchKernelGGL(col_partial_fast_kernel, dim3((unsigned)nblk, nseg), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode, mask);
+        hipLaunchKernelGGL(col_partial_fast_kernel, dim3((unsigned)nblk, nseg), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode, mask, mask_bits);
         return eg_check_launch("col_partial_fast");
     }
     EG_REQUIRE(mode != 4, EG_ERR_UNSUPPORTED, "column reduction behind a ReLU mask: C=%d must divide 1024 and the operands be 16-byte aligned", c);
@@ -1628,23 +1656,24 @@ extern "C" int eg_se_gate_train_forward(const float* clip_sum, const float* mean
 }
 
 extern "C" int eg_se_tail_forward(const float* c2, const float* res, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* gate, float* out, int32_t batch, int32_t hw, int32_t c, void* stream) {
+                                  const float* gate, float* out, uint32_t* relu_bits, int32_t batch, int32_t hw, int32_t c, void* stream) {
     EG_REQUIRE(c2 && res && mean && rstd && gamma && beta && gate && out, EG_ERR_BAD_ARG, "eg_se_tail_forward: null pointer");
     SE_TAIL_SHAPE("eg_se_tail_forward");
     EG_REQUIRE(eg_aligned16(c2) && eg_aligned16(res) && eg_aligned16(out) && eg_aligned16(gate), EG_ERR_ALIGN, "eg_se_tail_forward: 16-byte aligned maps");
     const size_t n4 = (size_t)batch * hw * c / 4;
+    EG_REQUIRE(!relu_bits || (n4 & 7) == 0, EG_ERR_UNSUPPORTED, "eg_se_tail_forward: the ReLU bit mask needs batch * hw * c to be a multiple of 32");
     hipLaunchKernelGGL(se_tail_fwd_kernel, grid1(n4), dim3(256), 0, ST, reinterpret_cast<const f4*>(c2), reinterpret_cast<const f4*>(res), mean, rstd, gamma,
-                       beta, gate, reinterpret_cast<f4*>(out), n4, hw * (c / 4), c / 4);
+                       beta, gate, reinterpret_cast<f4*>(out), n4, hw * (c / 4), c / 4, relu_bits);
     return eg_check_launch("se_tail_fwd");
 }
 
 // s1[b,c] = sum_hw dout [out > 0];  s2raw[b,c] = sum_hw dout [out > 0] (c2 - mean[c]).   workspace >= eg_colreduce_workspace_floats(c); batch <= 512.
-extern "C" int eg_se_tail_backward_reduce(const float* dout, const float* out, const float* c2, const float* mean, float* s1, float* s2raw,
-                                          int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream) {
-    EG_REQUIRE(dout && out && c2 && mean && s1 && s2raw && workspace && batch <= 512, EG_ERR_BAD_ARG, "eg_se_tail_backward_reduce: bad argument");
+extern "C" int eg_se_tail_backward_reduce(const float* dout, const float* out, const uint32_t* relu_bits, const float* c2, const float* mean, float* s1,
+                                          float* s2raw, int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream) {
+    EG_REQUIRE(dout && (out || relu_bits) && c2 && mean && s1 && s2raw && workspace && batch <= 512, EG_ERR_BAD_ARG, "eg_se_tail_backward_reduce: bad argument");
     SE_TAIL_SHAPE("eg_se_tail_backward_reduce");
     int nblk = 0;
-    if (int rc = col_reduce(dout, c2, mean, hw, c, 4, workspace, &nblk, ST, batch, out)) return rc;
+    if (int rc = col_reduce(dout, c2, mean, hw, c, 4, workspace, &nblk, ST, batch, relu_bits ? nullptr : out, relu_bits)) return rc;
     hipLaunchKernelGGL(col_finalize_kernel, dim3(eg_cdiv(c, 4), batch), dim3(256), 0, ST, workspace, nblk, c, s1, s2raw, 1.0f);
     return eg_check_launch("se_tail_bwd_reduce");
 }
@@ -1680,17 +1709,18 @@ extern "C" int eg_se_tail_backward_finish(const float* u1, const float* u2, cons
     return eg_check_launch("se_tail_bwd_finish");
 }
 
-extern "C" int eg_se_tail_backward_apply(const float* dout, const float* out, const float* c2, const float* mean, const float* rstd, const float* gamma,
-                                         const float* gate, const float* dgap_hw, const float* m1, const float* m2, float* dc2, float* dres, int32_t batch,
-                                         int32_t hw, int32_t c, void* stream) {
-    EG_REQUIRE(dout && out && c2 && mean && rstd && gamma && gate && dgap_hw && m1 && m2 && dc2 && dres, EG_ERR_BAD_ARG, "eg_se_tail_backward_apply: null pointer");
+extern "C" int eg_se_tail_backward_apply(const float* dout, const float* out, const uint32_t* relu_bits, const float* c2, const float* mean,
+                                         const float* rstd, const float* gamma, const float* gate, const float* dgap_hw, const float* m1, const float* m2,
+                                         float* dc2, float* dres, int32_t batch, int32_t hw, int32_t c, void* stream) {
+    EG_REQUIRE(dout && (out || relu_bits) && c2 && mean && rstd && gamma && gate && dgap_hw && m1 && m2 && dc2 && dres, EG_ERR_BAD_ARG,
+               "eg_se_tail_backward_apply: null pointer");
     SE_TAIL_SHAPE("eg_se_tail_backward_apply");
-    EG_REQUIRE(eg_aligned16(dout) && eg_aligned16(out) && eg_aligned16(c2) && eg_aligned16(dc2) && eg_aligned16(dres), EG_ERR_ALIGN,
+    EG_REQUIRE(eg_aligned16(dout) && (!out || eg_aligned16(out)) && eg_aligned16(c2) && eg_aligned16(dc2) && eg_aligned16(dres), EG_ERR_ALIGN,
                "eg_se_tail_backward_apply: 16-byte aligned maps");
     const size_t n4 = (size_t)batch * hw * c / 4;
     hipLaunchKernelGGL(se_tail_bwd_apply_kernel, grid1(n4), dim3(256), 0, ST, reinterpret_cast<const f4*>(dout), reinterpret_cast<const f4*>(out),
                        reinterpret_cast<const f4*>(c2), mean, rstd, gamma, gate, dgap_hw, m1, m2, reinterpret_cast<f4*>(dc2), reinterpret_cast<f4*>(dres), n4,
-                       hw * (c / 4), c / 4);
+                       hw * (c / 4), c / 4, relu_bits);
     return eg_check_launch("se_tail_bwd_apply");
 }
 

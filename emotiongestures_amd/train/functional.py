@@ -881,6 +881,9 @@ def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5, gap=None, relu_input
     return y
 
 
+SE_TAIL_RELU_BITS = __import__("os").environ.get("EG_SE_TAIL_BITS", "1") != "0"       # False: the tail's backward reads the block output for its ReLU mask (A/B)
+
+
 class _SEBlockTail(torch.autograd.Function):
     """relu(se(bn2(c2)) + res) of SEBasicBlock.forward (ResNetBlocks.py:28-36) as one operator: bn2's statistics from conv2's pooling
     partials + one centred pass, the SE gate per clip, one fused output pass; bn2's output is never stored (the backward recomputes it)."""
@@ -905,8 +908,11 @@ class _SEBlockTail(torch.autograd.Function):
         L.check(lib.eg_se_gate_train_forward(_ptr(clip), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(w1d), _ptr(b1d), _ptr(w2d), _ptr(b2d), _ptr(pooled),
                                              _ptr(h), _ptr(gate), B, hw, Cc, st), "eg_se_gate_train_forward")
         out = torch.empty_like(x)
-        L.check(lib.eg_se_tail_forward(_ptr(x), _ptr(r), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(out), B, hw, Cc, st), "eg_se_tail_forward")
-        ctx.save_for_backward(x, out, mean, rstd, clip, pooled, h, gate, g, bt, w1d, w2d)
+        # the tail's ReLU mask as bits (one nibble per float4): the two backward passes read it instead of the whole `out` map
+        bits = torch.empty(x.numel() // 32, dtype=torch.int32, device=dev) if (SE_TAIL_RELU_BITS and x.numel() % 32 == 0) else None
+        L.check(lib.eg_se_tail_forward(_ptr(x), _ptr(r), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(out), _ptr(bits), B, hw, Cc, st), "eg_se_tail_forward")
+        ctx.save_for_backward(x, out if bits is None else bits, mean, rstd, clip, pooled, h, gate, g, bt, w1d, w2d)
+        ctx.has_bits = bits is not None
         ctx.params = (gamma, beta, w1, b1, w2, b2)
         return out
 
@@ -914,6 +920,9 @@ class _SEBlockTail(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib()
         x, out, mean, rstd, clip, pooled, h, gate, g, bt, w1, w2 = ctx.saved_tensors
+        bits = None
+        if ctx.has_bits:
+            bits, out = out, None
         B, H, W, Cc = x.shape
         hw, dev, Ch = H * W, x.device, Cc // 8
         d = _chk(dout)
@@ -922,7 +931,7 @@ class _SEBlockTail(torch.autograd.Function):
         small = torch.empty(6, B, Cc, device=dev)                                   # s1, s2raw, dz2, dgap_hw, u1, u2
         s1, s2, dz2, dgap, u1, u2 = small.unbind(0)
         dz1 = torch.empty(B, Ch, device=dev)
-        L.check(lib.eg_se_tail_backward_reduce(_ptr(d), _ptr(out), _ptr(x), _ptr(mean), _ptr(s1), _ptr(s2), B, hw, Cc, _ptr(ws), st),
+        L.check(lib.eg_se_tail_backward_reduce(_ptr(d), _ptr(out), _ptr(bits), _ptr(x), _ptr(mean), _ptr(s1), _ptr(s2), B, hw, Cc, _ptr(ws), st),
                 "eg_se_tail_backward_reduce")
         L.check(lib.eg_se_gate_train_backward(_ptr(s1), _ptr(s2), _ptr(clip), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(h), _ptr(w1), _ptr(w2),
                                               _ptr(dz2), _ptr(dz1), _ptr(dgap), _ptr(u1), _ptr(u2), B, hw, Cc, st), "eg_se_gate_train_backward")
@@ -931,7 +940,7 @@ class _SEBlockTail(torch.autograd.Function):
         L.check(lib.eg_se_tail_backward_finish(_ptr(u1), _ptr(u2), _ptr(dz2), _ptr(dz1), _ptr(h), _ptr(pooled), _ptr(dg), _ptr(db), _ptr(m1), _ptr(m2),
                                                _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), B, hw, Cc, st), "eg_se_tail_backward_finish")
         dc2, dres = torch.empty_like(x), torch.empty_like(x)
-        L.check(lib.eg_se_tail_backward_apply(_ptr(d), _ptr(out), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(gate), _ptr(dgap), _ptr(m1), _ptr(m2),
+        L.check(lib.eg_se_tail_backward_apply(_ptr(d), _ptr(out), _ptr(bits), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(gate), _ptr(dgap), _ptr(m1), _ptr(m2),
                                               _ptr(dc2), _ptr(dres), B, hw, Cc, st), "eg_se_tail_backward_apply")
         return dc2, None, dres, dg, db, None, None, dw1, db1, dw2, db2, None, None
 

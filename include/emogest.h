@@ -492,19 +492,22 @@ int eg_bn_train_stats_sq(const float* gap_partial, const float* gap_sq_partial, 
 int eg_se_gate_train_forward(const float* clip_sum, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w1,
                              const float* b1, const float* w2, const float* b2, float* pooled, float* h, float* gate, int32_t batch, int32_t hw,
                              int32_t c, void* stream);
+/* relu_bits (optional, batch * hw * c / 32 words; needs batch * hw * c % 32 == 0): the tail's ReLU mask [out > 0] as one nibble per float4 of the
+ * map, eight float4 indices per word.  The two backward passes take it INSTEAD of `out` (then `out` may be NULL): they read 1/32 of a map where
+ * they read a whole one (3.4 GB of the 128-clip step's 78). */
 int eg_se_tail_forward(const float* c2, const float* res, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const float* gate, float* out, int32_t batch, int32_t hw, int32_t c, void* stream);
-int eg_se_tail_backward_reduce(const float* dout, const float* out, const float* c2, const float* mean, float* s1, float* s2raw,
-                               int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream);
+                       const float* gate, float* out, uint32_t* relu_bits, int32_t batch, int32_t hw, int32_t c, void* stream);
+int eg_se_tail_backward_reduce(const float* dout, const float* out, const uint32_t* relu_bits, const float* c2, const float* mean, float* s1,
+                               float* s2raw, int32_t batch, int32_t hw, int32_t c, float* workspace, void* stream);
 int eg_se_gate_train_backward(const float* s1, const float* s2raw, const float* clip_sum, const float* mean, const float* rstd,
                               const float* gamma, const float* beta, const float* gate, const float* h, const float* w1, const float* w2,
                               float* dz2, float* dz1, float* dgap_hw, float* u1, float* u2, int32_t batch, int32_t hw, int32_t c, void* stream);
 int eg_se_tail_backward_finish(const float* u1, const float* u2, const float* dz2, const float* dz1, const float* h, const float* pooled,
                                float* dgamma, float* dbeta, float* m1, float* m2, float* dw1, float* db1, float* dw2, float* db2,
                                int32_t batch, int32_t hw, int32_t c, void* stream);
-int eg_se_tail_backward_apply(const float* dout, const float* out, const float* c2, const float* mean, const float* rstd, const float* gamma,
-                              const float* gate, const float* dgap_hw, const float* m1, const float* m2, float* dc2, float* dres, int32_t batch,
-                              int32_t hw, int32_t c, void* stream);
+int eg_se_tail_backward_apply(const float* dout, const float* out, const uint32_t* relu_bits, const float* c2, const float* mean, const float* rstd,
+                              const float* gamma, const float* gate, const float* dgap_hw, const float* m1, const float* m2, float* dc2, float* dres,
+                              int32_t batch, int32_t hw, int32_t c, void* stream);
 /* o0[c] = sum_r a[r,c]; o1[c] = sum_r a[r,c]*b[r,c] (b NULL: sum a^2).  bias / LayerNorm affine gradients. */
 int eg_colsum(const float* a, const float* b, float* o0, float* o1, int64_t rows, int32_t c, float* workspace, void* stream);
 /* op: 0 relu(a) | 1 a*(b>0) | 2 leaky(a; s) | 3 a*(b>0 ? 1 : s) | 4 a+b | 5 a*s | 6 sigmoid(a) | 7 a*b*(1-b) | 8 a*b | 9 a+s*b | 10 exp(s*a) | 11 a*b[0] */
