@@ -350,6 +350,9 @@ template <int TERMS, int WN = 2>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     constexpr int NIMG = (TERMS == 3) ? 2 : 1;
     constexpr int TN = WN / 2;                                                     // 64-row weight image tiles per workgroup
+    // Ring depth: a 2-slot ring (48 KB: three workgroups per CU) is 7-17 % faster in a stand-alone loop at 4352 rows, where the operands stay in L2,
+    // and SLOWER inside the training step (+ 0.15 ms at 128 clips, + 0.3 ms at 16: profiles/r06_train_ab.txt) -- there every product meets operands the
+    // previous kernel has just written or weights from HBM, and the two-step prefetch distance is what hides that
     constexpr int RING = (WN == 2) ? 4 : 3, XS = 64 * 8, WIMG = 4 * 64, WS = TN * NIMG * WIMG, SLOT = XS + WS;      // 16-byte slots
     constexpr int G = 2 + TN * NIMG;                                               // LDS-DMA instructions per wave per step
     extern __shared__ __attribute__((aligned(16))) bf8 lds_raw[];                  // RING * SLOT slots of 16 bytes (bf8 and f4 alike)
