@@ -578,6 +578,8 @@ def _train_leg_body(dev, B, precision, graph, steps, warmup, rank, world, dist, 
            "trainable_parameters": int(sum(p.numel() for p in fp.params)), "buckets": len(gb.buckets)}
     if by_rank is not None:
         out["ranks"] = by_rank
+        if by_rank["allreduce_exposed_ms_per_step_max"] is not None:          # the step waits for the slowest rank's exposed reduction
+            out["allreduce_exposed_ms_per_step"] = by_rank["allreduce_exposed_ms_per_step_max"]
         out["gradient_payload"] = gb.payload if graph and collective else "f32"
     if os.environ.get("EG_TRAIN_DIGEST") == "1":     # bitwise identity of the parameters after warmup + steps (tests: segmented step over RCCL vs the one-graph step)
         import hashlib
