@@ -35,15 +35,28 @@ __device__ __forceinline__ int img_off(int row, int ch) {
 struct LinGradArgs {
     const float* dy; const float* x; float* dw; float* db; float* part; float* dbpart;
     int ldy, ldx, lddw, R, N, K, rows_per, S;
+    int xa = 0, xb = 0;     // XCD blocking of the tile grid: xa x xb = 8 blocks of (grid.x / xa) x (grid.y / xb) tiles, one per XCD; 0: launch order
 };
 
 __global__ __launch_bounds__(256, 2) void linear_wgrad_bf16_kernel(LinGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // 2 stages + bias scratch [16][64] floats
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64, sl = blockIdx.z;
+    // Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest), each XCD with its own L2.  In launch order XCD c owns ONE k tile and
+    // every n tile: its X column slice is fetched once, but all dY slices by every XCD (memory-side reads 4 x the algorithmic bytes, round 6's traffic
+    // table).  Remapped, XCD c owns a near-square block of tiles: (bw + bh) slices fetched per XCD instead of (1 + grid.y).
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if (a.xa) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int lin = ty * gx + tx;                  // gx * gy is a multiple of 8 here: the XCD of this workgroup is lin & 7 in every row slice z
+        const int xcd = lin & 7, j = lin >> 3;
+        const int bw = gx / a.xa, bh = gy / a.xb;
+        tx = (xcd % a.xa) * bw + j % bw;
+        ty = (xcd / a.xa) * bh + j / bw;
+    }
+    const int k0 = tx * 64, n0 = ty * 64, sl = blockIdx.z;
     const int r_beg = sl * a.rows_per, r_end = min(a.R, r_beg + a.rows_per);
     const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
-    const bool want_db = a.db != nullptr && blockIdx.x == 0;
+    const bool want_db = a.db != nullptr && tx == 0;
     // staging role: column quad cq (4 columns), rows rr + 16 i
     const int cq = tid & 15, rr = tid >> 4;
     const bool dy_vec = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) && (n0 + 64 <= a.N);
@@ -246,6 +259,18 @@ extern "C" int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x
         a.lddw = (int)eg_round_up(k, 4);
         a.part = workspace;
         a.dbpart = workspace + (size_t)p.S * n * a.lddw;
+    }
+    {   // XCD blocking: xa | grid.x, xb | grid.y, xa * xb = 8, the block with the smallest half perimeter (slices fetched per XCD)
+        const int gx = eg_cdiv(k, 64), gy = eg_cdiv(n, 64);
+        if ((gx * gy) % 8 == 0) {                          // same-box A/B against launch order: 128-clip step 25.32 -> 25.12 ms (profiles/r06_train_ab.txt)
+            int best = 1 << 30;
+            for (int xa = 1; xa <= 8; xa *= 2) {
+                const int xb = 8 / xa;
+                if (gx % xa || gy % xb) continue;
+                const int cost = gx / xa + gy / xb;
+                if (cost < best) { best = cost; a.xa = xa; a.xb = xb; }
+            }
+        }
     }
     EgProfScope prof(8, 2.0 * rows * (double)n * (double)k, st);
     constexpr size_t LDS_BYTES = 2 * LG_STAGE + 16 * 16 * sizeof(f4);
