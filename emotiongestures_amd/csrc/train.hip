@@ -348,9 +348,14 @@ __device__ __forceinline__ unsigned relu_nibble(const unsigned* __restrict__ bit
 // (4t) mod C, 256 threads x 16 B = 4 KB per block-iteration fully coalesced; partials are combined through LDS in a fixed order.
 // Segmented: blockIdx.y = segment (a clip for the SE pooling, 1 segment for BatchNorm / bias / LayerNorm-affine sums),
 // blockIdx.x = chunk of rows inside the segment; part[seg][chunk][2][C].
+// MODE and the mask form are template parameters: with them as runtime arguments the loop body was a forest of uniform branches and the mask loads
+// were issued behind them, after the two main streams (round 6: 4.4 TB/s where the apply passes reach 6.2).  MASK: 0 none, 1 a float map, 2 the nibble bits.
+template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
-                                                               float* __restrict__ part, long seg_rows, int C, long rows_per, int mode,
-                                                               const float* __restrict__ mask, const unsigned* __restrict__ mask_bits = nullptr) {
+                                                               float* __restrict__ part, long seg_rows, int C, long rows_per,
+                                                               const float* __restrict__ mask, const unsigned* __restrict__ mask_bits) {
+    constexpr int mode = MODE;
+    constexpr bool HAS_B = (MODE == 1 || MODE == 2 || MODE == 4);
     __shared__ f4 s0[256], s1[256];
     const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const long r0 = (long)chunk * rows_per, r1 = (r0 + rows_per < seg_rows) ? r0 + rows_per : seg_rows;
@@ -360,15 +365,16 @@ __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __re
     f4 mu = (f4){0.f, 0.f, 0.f, 0.f};
     if (mode >= 2) mu = *reinterpret_cast<const f4*>(mean + cq);
     const f4* a4 = reinterpret_cast<const f4*>(a + base);
-    const f4* b4 = b ? reinterpret_cast<const f4*>(b + base) : nullptr;
-    const f4* m4 = mask ? reinterpret_cast<const f4*>(mask + base) : nullptr;
+    const f4* b4 = HAS_B ? reinterpret_cast<const f4*>(b + base) : nullptr;
+    const f4* m4 = (MASK == 1) ? reinterpret_cast<const f4*>(mask + base) : nullptr;
     const size_t g4 = base >> 2;                // float4 index of this block's first element in the whole map (mode 4 with mask_bits: the nibble index)
     auto mload = [&](size_t f) -> f4 {
-        if (mask_bits) {
+        if constexpr (MASK == 2) {
             const unsigned nb = relu_nibble(mask_bits, g4 + f);
             return (f4){(nb & 1u) ? 1.f : 0.f, (nb & 2u) ? 1.f : 0.f, (nb & 4u) ? 1.f : 0.f, (nb & 8u) ? 1.f : 0.f};
         }
-        return m4[f];
+        if constexpr (MASK == 1) return m4[f];
+        return (f4){0.f, 0.f, 0.f, 0.f};
     };
     f4 u = (f4){0.f, 0.f, 0.f, 0.f}, v = u;
     const f4 zero4 = (f4){0.f, 0.f, 0.f, 0.f};
@@ -389,14 +395,19 @@ __global__ __launch_bounds__(256) void col_partial_fast_kernel(const float* __re
     for (; f + 768 < n4; f += 1024) {
         const f4 x0 = a4[f], x1 = a4[f + 256], x2 = a4[f + 512], x3 = a4[f + 768];
         f4 y0 = zero4, y1 = zero4, y2 = zero4, y3 = zero4, m0 = zero4, m1 = zero4, m2 = zero4, m3 = zero4;
-        if (b4) { y0 = b4[f]; y1 = b4[f + 256]; y2 = b4[f + 512]; y3 = b4[f + 768]; }
-        if (mode == 4) { m0 = mload(f); m1 = mload(f + 256); m2 = mload(f + 512); m3 = mload(f + 768); }
+        if constexpr (HAS_B) { y0 = b4[f]; y1 = b4[f + 256]; y2 = b4[f + 512]; y3 = b4[f + 768]; }
+        if constexpr (MODE == 4) { m0 = mload(f); m1 = mload(f + 256); m2 = mload(f + 512); m3 = mload(f + 768); }
         fold(x0, y0, m0);
         fold(x1, y1, m1);
         fold(x2, y2, m2);
         fold(x3, y3, m3);
     }
-    for (; f < n4; f += 256) fold(a4[f], b4 ? b4[f] : zero4, mode == 4 ? mload(f) : zero4);
+    for (; f < n4; f += 256) {
+        f4 y = zero4, m = zero4;
+        if constexpr (HAS_B) y = b4[f];
+        if constexpr (MODE == 4) m = mload(f);
+        fold(a4[f], y, m);
+    }
     s0[tid] = u;
     s1[tid] = v;
     __syncthreads();
@@ -1500,7 +1511,17 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
     nblk = (rows + rows_per - 1) / rows_per;
     *nblk_out = (int)nblk;
     if (fast) {
-        hipLaunchKernelGGL(col_partial_fast_kernel, dim3((unsigned)nblk, nseg), dim3(256), 0, st, a, b, mean, part, (long)rows, c, rows_per, mode, mask, mask_bits);
+        const dim3 grid((unsigned)nblk, nseg), block(256);
+#define CPF(M, K) hipLaunchKernelGGL((col_partial_fast_kernel<M, K>), grid, block, 0, st, a, b, mean, part, (long)rows, c, rows_per, mask, mask_bits)
+        if (mode == 4) {
+            EG_REQUIRE(b && (mask || mask_bits), EG_ERR_BAD_ARG, "column reduction behind a ReLU mask: needs the second operand and a mask");
+            if (mask_bits) CPF(4, 2); else CPF(4, 1);
+        } else if (mode == 0 && !b) CPF(0, 0);
+        else if (mode == 1 && b) CPF(1, 0);
+        else if (mode == 2 && b) CPF(2, 0);
+        else if (mode == 3 && !b) CPF(3, 0);
+        else { eg_set_error("column reduction: mode %d with%s a second operand", mode, b ? "" : "out"); return EG_ERR_BAD_ARG; }
+#undef CPF
         return eg_check_launch("col_partial_fast");
     }
     EG_REQUIRE(mode != 4, EG_ERR_UNSUPPORTED, "column reduction behind a ReLU mask: C=%d must divide 1024 and the operands be 16-byte aligned", c);
