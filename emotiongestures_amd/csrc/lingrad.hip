@@ -36,8 +36,14 @@ struct LinGradArgs {
     const float* dy; const float* x; float* dw; float* db; float* part; float* dbpart;
     int ldy, ldx, lddw, R, N, K, rows_per, S;
     int xa = 0, xb = 0;     // XCD blocking of the tile grid: xa x xb = 8 blocks of (grid.x / xa) x (grid.y / xb) tiles, one per XCD; 0: launch order
+    // CONVX: X is never materialised -- X[r = output pixel (b, oy, ox)][k = tap * Cin + ci] = x[b, oy * S + kh - 1, ox * S + kw - 1, ci] is gathered from the
+    // NHWC activation while the stage is loaded (the weight gradient of a 3x3 / pad 1 convolution of any stride: dW = dY^T im2col(x))
+    int cH = 0, cW = 0, cHo = 0, cWo = 0, cCin = 0, cS = 0;
 };
 
+__device__ __attribute__((aligned(64))) float eg_lingrad_zero_line[16];       // what out-of-image taps of the gathered operand read
+
+template <bool CONVX>
 __global__ __launch_bounds__(256, 2) void linear_wgrad_bf16_kernel(LinGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // 2 stages + bias scratch [16][64] floats
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -63,26 +69,61 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_bf16_kernel(LinGradArgs a
     const bool x_vec = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && (k0 + 64 <= a.K);
     f4 rd[4], rx[4];
     f4 bsum = (f4){0.f, 0.f, 0.f, 0.f};
+    // CONVX: this thread's column quad of the implicit matrix is one tap and four consecutive input channels (Cin % 4 == 0), fixed for the whole walk;
+    // its row -> pixel decomposition is carried along incrementally (rows advance by 16 inside a stage and by 64 between stages: a few compares, no division)
+    int tdy = 0, tdx = 0, tci = 0, pb = 0, py = 0, px = 0;
+    bool kval = true;
+    if (CONVX) {
+        const int kcol = k0 + 4 * cq;
+        kval = kcol < a.K;
+        const int tap = kval ? kcol / a.cCin : 0;
+        tci = kcol - tap * a.cCin;
+        tdy = tap / 3 - 1;
+        tdx = tap % 3 - 1;
+        const int r = r_beg + rr, hw = a.cHo * a.cWo;
+        pb = r / hw;
+        const int rem = r - pb * hw;
+        py = rem / a.cWo;
+        px = rem - py * a.cWo;
+    }
+    auto advance = [&](int& b_, int& y_, int& x_, int d) {          // d <= 64 rows on: at most 4 row wraps when Wo >= 16 (every map of the path); any Wo works
+        x_ += d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (x_ >= a.cWo) { x_ -= a.cWo; ++y_; }
+        while (x_ >= a.cWo) { x_ -= a.cWo; ++y_; }
+        while (y_ >= a.cHo) { y_ -= a.cHo; ++b_; }
+    };
     auto load = [&](int r0) {
+        int qb = pb, qy = py, qx = px;             // pixel of row r0 + rr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + rr + 16 * i;
             f4 vd = (f4){0.f, 0.f, 0.f, 0.f}, vx = vd;
             if (r < r_end) {
                 const float* dp = a.dy + (size_t)r * a.ldy + n0 + 4 * cq;
-                const float* xp = a.x + (size_t)r * a.ldx + k0 + 4 * cq;
                 if (dy_vec) vd = *reinterpret_cast<const f4*>(dp);
                 else
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (n0 + 4 * cq + j < a.N) vd[j] = dp[j];
-                if (x_vec) vx = *reinterpret_cast<const f4*>(xp);
-                else
+                if (CONVX) {
+                    const int iy = qy * a.cS + tdy, ix = qx * a.cS + tdx;
+                    const bool ok = kval && iy >= 0 && iy < a.cH && ix >= 0 && ix < a.cW;
+                    const float* xp = ok ? a.x + (((size_t)qb * a.cH + iy) * a.cW + ix) * a.cCin + tci : eg_lingrad_zero_line;
+                    vx = *reinterpret_cast<const f4*>(xp);
+                } else {
+                    const float* xp = a.x + (size_t)r * a.ldx + k0 + 4 * cq;
+                    if (x_vec) vx = *reinterpret_cast<const f4*>(xp);
+                    else
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (k0 + 4 * cq + j < a.K) vx[j] = xp[j];
+                        for (int j = 0; j < 4; ++j) if (k0 + 4 * cq + j < a.K) vx[j] = xp[j];
+                }
             }
             rd[i] = vd;
             rx[i] = vx;
+            if (CONVX) advance(qb, qy, qx, 16);
         }
+        if (CONVX) advance(pb, py, px, 64);        // the next stage starts 64 rows further
     };
     auto store = [&](int buf) {
         unsigned char* base = lds + buf * LG_STAGE;
@@ -244,9 +285,33 @@ extern "C" int64_t eg_linear_wgrad_mfma_workspace_floats(int32_t rows, int32_t n
     return p.S > 1 ? (int64_t)p.S * n * (int64_t)eg_round_up(k, 4) + (int64_t)p.S * n : 0;
 }
 
+namespace { int lingrad_launch(const float* dy, int32_t ldy, const float* x, int32_t ldx, float* dw, int32_t lddw, float* db, int32_t rows, int32_t n, int32_t k,
+                               float* workspace, int64_t workspace_floats, void* stream, const int* geo); }
+
 extern "C" int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x, int32_t ldx, float* dw, int32_t lddw, float* db, int32_t rows, int32_t n,
                                     int32_t k, float* workspace, int64_t workspace_floats, void* stream) {
     EG_REQUIRE(dy && x && dw && rows > 0 && n > 0 && k > 0 && ldy >= n && ldx >= k && lddw >= k, EG_ERR_BAD_ARG, "eg_linear_wgrad_mfma: bad argument");
+    return lingrad_launch(dy, ldy, x, ldx, dw, lddw, db, rows, n, k, workspace, workspace_floats, stream, nullptr);
+}
+
+// Weight gradient of nn.Conv2d(cin -> cout, k = 3, pad = 1, ANY stride) on the split-bf16 matrix pipe as dW = dY^T im2col(x) with the im2col matrix gathered
+// while the stage is loaded (the stride-2 entry convolutions of the tower, Full_model/ResNetSE34V2.py:40-55; the stride-1 body convolutions keep their
+// dedicated kernel, wgrad.hip).  dw_mat [cout][9 * cin] with (kh, kw, ci) fastest to slowest, as eg_conv3x3_wgrad writes it.  cin % 4 == 0.
+// workspace: eg_linear_wgrad_mfma_workspace_floats(batch * ho * wo, cout, 9 * cin).
+extern "C" int eg_conv3x3_wgrad_gather_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                            int32_t stride, float* workspace, int64_t workspace_floats, void* stream) {
+    EG_REQUIRE(x && dy && dw_mat && batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && (stride == 1 || stride == 2), EG_ERR_BAD_ARG,
+               "eg_conv3x3_wgrad_gather_mfma: bad argument");
+    EG_REQUIRE(cin % 4 == 0 && eg_aligned16(x), EG_ERR_UNSUPPORTED, "eg_conv3x3_wgrad_gather_mfma: cin %% 4 == 0 and a 16-byte aligned map");
+    const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    EG_REQUIRE((int64_t)batch * ho * wo < (1ll << 31), EG_ERR_UNSUPPORTED, "eg_conv3x3_wgrad_gather_mfma: too many output pixels");
+    const int geo[6] = {h, w, ho, wo, cin, stride};
+    return lingrad_launch(dy, cout, x, 9 * cin, dw_mat, 9 * cin, nullptr, batch * ho * wo, cout, 9 * cin, workspace, workspace_floats, stream, geo);
+}
+
+namespace {
+int lingrad_launch(const float* dy, int32_t ldy, const float* x, int32_t ldx, float* dw, int32_t lddw, float* db, int32_t rows, int32_t n, int32_t k,
+                   float* workspace, int64_t workspace_floats, void* stream, const int* geo) {
     const LgPlan p = plan_lingrad(rows, n, k);
     const int64_t need = eg_linear_wgrad_mfma_workspace_floats(rows, n, k);
     EG_REQUIRE(p.S == 1 || (workspace && workspace_floats >= need), EG_ERR_WORKSPACE, "eg_linear_wgrad_mfma: workspace %lld < %lld floats",
@@ -274,8 +339,14 @@ extern "C" int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x
     }
     EgProfScope prof(8, 2.0 * rows * (double)n * (double)k, st);
     constexpr size_t LDS_BYTES = 2 * LG_STAGE + 16 * 16 * sizeof(f4);
-    if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(linear_wgrad_bf16_kernel), LDS_BYTES, "eg_linear_wgrad_mfma")) return rc;
-    hipLaunchKernelGGL(linear_wgrad_bf16_kernel, dim3(eg_cdiv(k, 64), eg_cdiv(n, 64), p.S), dim3(256), LDS_BYTES, st, a);
+    if (geo) {
+        a.cH = geo[0]; a.cW = geo[1]; a.cHo = geo[2]; a.cWo = geo[3]; a.cCin = geo[4]; a.cS = geo[5];
+        if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(linear_wgrad_bf16_kernel<true>), LDS_BYTES, "eg_conv3x3_wgrad_gather_mfma")) return rc;
+        hipLaunchKernelGGL(linear_wgrad_bf16_kernel<true>, dim3(eg_cdiv(k, 64), eg_cdiv(n, 64), p.S), dim3(256), LDS_BYTES, st, a);
+    } else {
+        if (int rc = eg_ensure_dynamic_lds(reinterpret_cast<const void*>(linear_wgrad_bf16_kernel<false>), LDS_BYTES, "eg_linear_wgrad_mfma")) return rc;
+        hipLaunchKernelGGL(linear_wgrad_bf16_kernel<false>, dim3(eg_cdiv(k, 64), eg_cdiv(n, 64), p.S), dim3(256), LDS_BYTES, st, a);
+    }
     if (int rc = eg_check_launch("linear_wgrad_mfma")) return rc;
     if (p.S == 1) return EG_OK;
     const size_t total = (size_t)n * (a.lddw >> 2);
@@ -283,3 +354,4 @@ extern "C" int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, a.part, a.dbpart, dw, db, n, k, a.lddw, lddw, p.S);
     return eg_check_launch("linear_wgrad_reduce");
 }
+}  // namespace

@@ -549,6 +549,7 @@ def _pack_conv(w, flip=False):
 
 PAD_WGRAD = True            # False: ragged-width weight gradients on the fp32 implicit GEMM (A/B switch of the tests)
 S2_DGRAD = __import__("os").environ.get("EG_S2_DGRAD", "1") != "0"      # False: stride-2 input gradients through the column product + col2im (A/B switch)
+S2_WGRAD = __import__("os").environ.get("EG_S2_WGRAD", "1") != "0"      # False: stride-2 weight gradients on the fp32 implicit GEMM (A/B switch)
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -682,6 +683,14 @@ class _Conv3x3(torch.autograd.Function):
             L.check(lib.eg_conv3x3_wgrad_mfma_oihw(_ptr(x), _ptr(dyp), _ptr(dwp), B, H, W, Ci, Cop, _ptr(ws), ws.numel(), _stream(dev)),
                     "eg_conv3x3_wgrad_mfma")
             dw.copy_(dwp[:Co])                                              # data movement into the flat gradient slice
+        elif _PREC["conv"] == L.EG_PREC_BF16X3 and ctx.stride == 2 and Ci % 4 == 0 and S2_WGRAD:
+            # stride-2 entry convolution: dW = dY^T im2col(x) on the split-bf16 Linear weight-gradient kernel, the window gathered while x is staged
+            # (was the fp32 implicit GEMM below: 263 us per layer at 128 clips)
+            dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
+            need = int(lib.eg_linear_wgrad_mfma_workspace_floats(B * Ho * Wo, Co, 9 * Ci))
+            ws = _scratch(dev, need, "lingrad") if need else None
+            L.check(lib.eg_conv3x3_wgrad_gather_mfma(_ptr(x), _ptr(dy2), _ptr(dwm), B, H, W, Ci, Co, ctx.stride, _ptr(ws), ws.numel() if ws is not None else 0,
+                                                     _stream(dev)), "eg_conv3x3_wgrad_gather_mfma")
         elif Ci % 4 == 0:           # implicit GEMM over the output pixels (no im2col buffer)
             dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=dev)
             need = lib.eg_gemm_tn_workspace_floats(Co, 9 * Ci, B * Ho * Wo)

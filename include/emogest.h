@@ -539,6 +539,12 @@ int eg_conv3x3_dgrad_s2(const float* dy, const float* w_flip, const float* res_q
 int64_t eg_linear_wgrad_mfma_workspace_floats(int32_t rows, int32_t n, int32_t k);
 int eg_linear_wgrad_mfma(const float* dy, int32_t ldy, const float* x, int32_t ldx, float* dw, int32_t lddw, float* db, int32_t rows, int32_t n, int32_t k,
                          float* workspace, int64_t workspace_floats, void* stream);
+/* Weight gradient of nn.Conv2d(cin -> cout, k = 3, pad = 1, stride 1 | 2) on the split-bf16 matrix pipe as dW = dY^T im2col(x), the im2col matrix gathered
+ * from the NHWC map while the operand is staged (no column buffer): the stride-2 stage-entry convolutions, Full_model/ResNetSE34V2.py:40-55 (the stride-1
+ * body convolutions keep eg_conv3x3_wgrad_mfma).  dy [batch][ho][wo][cout], dw_mat [cout][9 * cin] ((kh, kw, ci) fastest to slowest, as eg_conv3x3_wgrad).
+ * cin % 4 == 0.  workspace >= eg_linear_wgrad_mfma_workspace_floats(batch * ho * wo, cout, 9 * cin).  Deterministic (fixed-order partials). */
+int eg_conv3x3_wgrad_gather_mfma(const float* x, const float* dy, float* dw_mat, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                 int32_t stride, float* workspace, int64_t workspace_floats, void* stream);
 /* Device-side build of the weight image eg_conv3x3 reads (eg_conv3x3_packed_floats(cin', round_up(cout',16)) floats: fp32 image, then the
  * bf16 hi / lo images), for weights that change every step.  flip_transpose = 0: conv weight [cout][cin][3][3] as in the state_dict
  * (cin' = cin, cout' = cout).  flip_transpose = 1: the filter of the input-gradient convolution, w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]

@@ -113,6 +113,33 @@ def test_stride2_input_gradient_kernel_matches_float64(B, H, W, Ci, Co):
         L.check(lib.eg_conv3x3_dgrad_s2(_ptr(dyd), _ptr(wp), None, _ptr(dx), B, H, W, Ci, Co, L.EG_PREC_F32, _stream(dx.device)), "eg_conv3x3_dgrad_s2")
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride", [(2, 128, 124, 32, 64, 2), (3, 64, 62, 64, 128, 2), (2, 17, 13, 32, 64, 2), (1, 31, 33, 64, 128, 2), (2, 16, 16, 128, 256, 2),
+                                                (40, 20, 18, 32, 64, 2), (2, 12, 20, 32, 32, 1)])
+def test_gathered_weight_gradient_matches_float64(B, H, W, Ci, Co, stride):
+    """eg_conv3x3_wgrad_gather_mfma (csrc/lingrad.hip, linear_wgrad_bf16_kernel<CONVX>): dW = dY^T im2col(x) with the 3x3 window gathered while x is
+    staged -- the stride-2 stage-entry convolutions' weight gradient (ResNetSE34V2.py:40-55) -- through the C ABI against float64 autograd of F.conv2d:
+    tower shapes, odd sizes (taps that fall off the last row / column), a ragged last k tile (9 * 32 = 288 columns), row slices (40 clips), stride 1."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = T("x", (B, H, W, Ci), -1, 1)
+    dy = T("dy", (B, Ho, Wo, Co), -1, 1)
+    w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    TF.conv2d(x.permute(0, 3, 1, 2).double(), w64, None, stride=stride, padding=1).backward(dy.permute(0, 3, 1, 2).double())
+    ref = w64.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci)                  # (kh, kw, ci)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    out = torch.full((Co, 9 * Ci), float("nan"), device=DEV)
+    need = int(lib.eg_linear_wgrad_mfma_workspace_floats(B * Ho * Wo, Co, 9 * Ci))
+    ws = torch.full((max(need, 1),), float("nan"), device=DEV)
+    L.check(lib.eg_conv3x3_wgrad_gather_mfma(_ptr(xd), _ptr(dyd), _ptr(out), B, H, W, Ci, Co, stride, _ptr(ws), ws.numel(), _stream(out.device)),
+            "eg_conv3x3_wgrad_gather_mfma")
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    e = float((got - ref).norm() / ref.norm())
+    assert e < 2e-5, (B, H, W, Ci, Co, stride, e)
+
+
 def test_stride2_block_backward_uses_the_fused_input_gradient_and_equals_the_column_path():
     """The stage-entry SEBasicBlock (stride-2 conv1 + the strided 1x1 shortcut, ResNetBlocks.py:21-37 / ResNetSE34V2.py:40-55) in the split-bf16 training
     mode: conv1's extra output is the quarter map the shortcut reads, the shortcut's gradient comes back on that grid and lands in the stride-2
