@@ -1724,6 +1724,50 @@ def test_layernorm_backward_ex_matches_torch_and_the_dropout_kernel(rows, D, p):
         assert torch.equal(a16[:, t, :, :r], b16[:, t, :, :r])
 
 
+class _ReluSites:
+    """Record the ReLU outputs of a training step (the epilogue ReLU of eg_linear_ex and the elementwise ones), in call order: two runs of the same
+    network that round differently can disagree on the SIGN of a pre-activation a few 1e-7 from zero, and then their gradients differ by that
+    unit's whole contribution (the ReLU gradient is discontinuous there) -- both are right.  flips(other) lists those units."""
+
+    def __init__(self, F):
+        self.F, self.sites = F, []
+
+    def __enter__(self):
+        F = self.F
+        self.keep = (F._linear_ex, F.relu, F.leaky_relu)
+        lin, relu, lrelu = self.keep
+
+        def lin_rec(x, lda, w, ldw, bias, res, y, M, N, K, relu_flag, prec, *a, **k):
+            out = lin(x, lda, w, ldw, bias, res, y, M, N, K, relu_flag, prec, *a, **k)
+            if relu_flag:
+                self.sites.append(("linear %dx%dx%d" % (M, N, K), y.detach().clone()))
+            return out
+
+        def relu_rec(x):
+            y = relu(x)
+            self.sites.append(("relu %s" % (tuple(x.shape),), x.detach().clone()))
+            return y
+
+        def lrelu_rec(x, slope=0.2):
+            y = lrelu(x, slope)
+            self.sites.append(("leaky_relu %s" % (tuple(x.shape),), x.detach().clone()))
+            return y
+        F._linear_ex, F.relu, F.leaky_relu = lin_rec, relu_rec, lrelu_rec
+        return self
+
+    def __exit__(self, *exc):
+        self.F._linear_ex, self.F.relu, self.F.leaky_relu = self.keep
+
+    def flips(self, other):
+        """[(site, value here, value there)] of the units whose ReLU mask differs between the two recordings (same sites in the same order)."""
+        assert [n for n, _ in self.sites] == [n for n, _ in other.sites]
+        out = []
+        for (name, a), (_n, b) in zip(self.sites, other.sites):
+            d = ((a > 0) != (b > 0)).nonzero()
+            out += [(name, float(a[tuple(i)]), float(b[tuple(i)])) for i in d.tolist()]
+        return out
+
+
 @pytest.mark.parametrize("precision,flat,dropout,chain", [("f32", False, False, False), ("f32", True, True, False), ("bf16x3", True, True, False),
                                                           ("bf16x3", True, False, False), ("bf16x3", True, True, True)])
 def test_fused_blocks_step_equals_the_operator_by_operator_step(precision, flat, dropout, chain):
@@ -1731,7 +1775,14 @@ def test_fused_blocks_step_equals_the_operator_by_operator_step(precision, flat,
     and the ReLU backward in GEMM epilogues, LayerNorm backward with both gradients and the affine sums) against the operator-by-operator
     composition they replace, on the whole generator + CVAE step: same loss, same gradient for every parameter.  With Dropout on, both draw the
     SAME masks (same call sites in the same order on the counter stream), so the comparison is as tight as without.  `flat`: parameters in the
-    flat buffer (fused weights are views, weight gradients land in adjacent flat slices, resident fused weight images)."""
+    flat buffer (fused weights are views, weight gradients land in adjacent flat slices, resident fused weight images).
+
+    ReLU flips: the two compositions round differently (split-K orders, epilogue order), so an FFN hidden unit whose pre-activation is a few 1e-7 from
+    zero can come out 0 on one side and 3e-7 on the other; the gradients then differ by that unit's contribution, which is 1e-3-relative on the small
+    gradients of the prior branch (round 6: an ulp-level change of the BatchNorm statistics re-rolled which units sit there and this test went from
+    0 to 3 flipped units at seed 31 -- tools/debug_chain_grads.py).  So the ReLU masks of both runs are recorded: the tight tolerance is asserted on an
+    input with NO flipped unit (the first of six seeds that has none); on an input with flips, every flipped pre-activation must be rounding-sized
+    (< 1e-5) and the gradients agree to 2e-2."""
     from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
     from emotiongestures_amd.train import functional as F
     from emotiongestures_amd.train import nets
@@ -1740,57 +1791,71 @@ def test_fused_blocks_step_equals_the_operator_by_operator_step(precision, flat,
     # producing LayerNorm / GEMM epilogue writes them, the consuming product reads them by LDS-DMA: functional.presplit_ok)
     B = 3
     old_rows = F.PRESPLIT_ROWS
-    F.PRESPLIT_ROWS = 64 if chain else 1 << 30
-    inp = synth_inputs(B, 34, 126, 4, seed=31)
-    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
     target = T("tgt", (B, 34, 126), -0.5, 0.5).to(DEV)
-    label = g["label"].argmax(1)
-    eps = g["z"]
-    out = []
-    try:
-        for fused in (False, True):
-            F.FUSE_BLOCKS = fused
-            F.set_precision(precision)
-            model = build_mirror("spatial", 34, 126, 4, 4, seed=2, precision="f32").to(DEV).train()
-            vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 2).to(DEV).train()
-            model.train_dropout = vae.train_dropout = dropout
-            both = torch.nn.ModuleList([model, vae])
-            if flat:
-                fp = flatten_parameters(both)
-                if precision != "f32":
-                    fp.enable_weight_images(*nets.weight_image_plan(both))
-            F.manual_seed(99)
-            n0 = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count())
-            pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
-            rec, mu, logvar = vae(emo.detach(), g["label"], eps)
-            loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
-                         F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
-            loss.backward()
-            torch.cuda.synchronize()
-            launches = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count()) - n0
-            grads = {n: p.grad.detach().clone() for n, p in both.named_parameters() if p.grad is not None}
-            out.append((float(loss.detach()), grads, launches))
-            if flat:
-                if fp.images is not None:
-                    F.unregister_weight_images(fp.images)
-                # the fused weight gradients were written straight into the flat buffer (adjacent slices of w_qs | w_ks | w_vs)
-                a = model.encoder.layer_stack[0].slf_attn
-                assert all(w.grad.data_ptr() == w._eg_slot.data_ptr() for w in (a.w_qs.weight, a.w_ks.weight, a.w_vs.weight)) or not fused
-    finally:
-        F.FUSE_BLOCKS = True
-        F.PRESPLIT_ROWS = old_rows
-        F.reset_state()
-    (l0, g0, n0), (l1, g1, n1) = out
-    assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
-    assert g0.keys() == g1.keys()
+
+    def run(seed):
+        inp = synth_inputs(B, 34, 126, 4, seed=seed)
+        g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+        label = g["label"].argmax(1)
+        eps = g["z"]
+        out = []
+        F.PRESPLIT_ROWS = 64 if chain else 1 << 30
+        try:
+            for fused in (False, True):
+                F.FUSE_BLOCKS = fused
+                F.set_precision(precision)
+                model = build_mirror("spatial", 34, 126, 4, 4, seed=2, precision="f32").to(DEV).train()
+                vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 2).to(DEV).train()
+                model.train_dropout = vae.train_dropout = dropout
+                both = torch.nn.ModuleList([model, vae])
+                if flat:
+                    fp = flatten_parameters(both)
+                    if precision != "f32":
+                        fp.enable_weight_images(*nets.weight_image_plan(both))
+                F.manual_seed(99)
+                n0 = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count())
+                with _ReluSites(F) as sites:
+                    pose, emo, _s, pred, _t = model(g["spec"], g["text"], g["pre_pose"], None)
+                    rec, mu, logvar = vae(emo.detach(), g["label"], eps)
+                    loss = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
+                                 F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)))
+                    loss.backward()
+                torch.cuda.synchronize()
+                launches = int(__import__("emotiongestures_amd")._lib.load().eg_launch_count()) - n0
+                grads = {n: p.grad.detach().clone() for n, p in both.named_parameters() if p.grad is not None}
+                out.append((float(loss.detach()), grads, launches, sites))
+                if flat:
+                    if fp.images is not None:
+                        F.unregister_weight_images(fp.images)
+                    # the fused weight gradients were written straight into the flat buffer (adjacent slices of w_qs | w_ks | w_vs)
+                    a = model.encoder.layer_stack[0].slf_attn
+                    assert all(w.grad.data_ptr() == w._eg_slot.data_ptr() for w in (a.w_qs.weight, a.w_ks.weight, a.w_vs.weight)) or not fused
+        finally:
+            F.FUSE_BLOCKS = True
+            F.PRESPLIT_ROWS = old_rows
+            F.reset_state()
+        return out
+
     # not bitwise: products that now carry a residual may take the split-K path (another K order); in split-bf16 the tower's small BatchNorm / SE
     # bias gradients amplify such last-bit differences upstream of a ReLU (the per-site tower test uses the same 3e-4)
     tol = 5e-5 if precision == "f32" else 3e-4
-    # final_conv1.bias sits directly in front of a BatchNorm: its gradient is analytically zero (both sides hold ~1e-6 of rounding noise)
-    errs = sorted(((rel(g1[k], g0[k]), k) for k in g0 if float(g0[k].norm()) > 0 and not k.endswith("final_conv1.bias")), reverse=True)
-    assert errs[0][0] < tol, errs[:5]
-    assert float(g1["0.audio_encoder.final_conv1.bias"].abs().max()) < 1e-4
-    assert n1 <= n0 - (100 if dropout else 60), (n0, n1)            # the point of the exercise: fewer launches per step (measured: 888 -> 778 / 840 -> 776)
+    for seed in (31, 32, 33, 34, 35, 36):
+        (l0, g0, n0, s0), (l1, g1, n1, s1) = run(seed)
+        assert abs(l0 - l1) <= 2e-6 * abs(l0), (seed, l0, l1)
+        assert g0.keys() == g1.keys()
+        assert len(s0.sites) >= 15, [n for n, _ in s0.sites]        # 9 FFN hidden layers + the ReLU MLPs + the TCN's activations
+        flips = s0.flips(s1)
+        assert all(max(abs(a), abs(b)) < 1e-5 for _n, a, b in flips), (seed, flips[:8])     # rounding-sized pre-activations only
+        # final_conv1.bias sits directly in front of a BatchNorm: its gradient is analytically zero (both sides hold ~1e-6 of rounding noise)
+        errs = sorted(((rel(g1[k], g0[k]), k) for k in g0 if float(g0[k].norm()) > 0 and not k.endswith("final_conv1.bias")), reverse=True)
+        assert float(g1["0.audio_encoder.final_conv1.bias"].abs().max()) < 1e-4
+        assert n1 <= n0 - (100 if dropout else 60), (n0, n1)        # the point of the exercise: fewer launches per step (measured: 888 -> 778 / 840 -> 776)
+        if not flips:
+            assert errs[0][0] < tol, (seed, errs[:5])
+            break
+        assert len(flips) <= 16 and errs[0][0] < 2e-2, (seed, flips[:8], errs[:5])
+    else:
+        pytest.fail("no input among six seeds without a flipped ReLU unit between the two compositions")
 
 
 @pytest.mark.parametrize("stride,cin,cout", [(1, 32, 32), (2, 32, 64), (1, 128, 128), (1, 64, 64)])
