@@ -1297,6 +1297,76 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
         p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
     }
 }
+// The float4 form both entry points launch when the four slices share a 16-byte phase (they do: one offset into four separately allocated flat
+// buffers): every thread owns four float4 per stream, all sixteen loads issued before any arithmetic (the scalar grid-stride loop above streamed
+// at 3.5 TB/s, round 6); the bias corrections of the device-count form are computed behind the loads.  The up to three elements in front of the
+// first 16-byte boundary and the n mod 4 behind the last float4 are updated by the first threads of workgroup 0 (no extra launch).  Same
+// per-element expression, same results.
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const float gi = g + wd * p;
+    const float mi = b1 * m + (1.f - b1) * gi;
+    const float vi = b2 * v + (1.f - b2) * gi * gi;
+    m = mi;
+    v = vi;
+    p -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+template <bool DEV>
+__global__ __launch_bounds__(256) void adam_v4_kernel(float* __restrict__ ps, const float* __restrict__ gs, float* __restrict__ ms, float* __restrict__ vs,
+                                                      int head, size_t n4, int tail, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                      float bc2_sqrt, const int* __restrict__ step) {
+    f4* p = reinterpret_cast<f4*>(ps + head);
+    const f4* g = reinterpret_cast<const f4*>(gs + head);
+    f4* m = reinterpret_cast<f4*>(ms + head);
+    f4* v = reinterpret_cast<f4*>(vs + head);
+    const size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    f4 pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = i0 + (size_t)k * 256;
+        if (i < n4) { pv[k] = p[i]; gv[k] = g[i]; mv[k] = m[i]; vv[k] = v[i]; }
+    }
+    if (DEV) {
+        const int t = *step;
+        bc1 = (float)(1.0 - pow((double)b1, (double)t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = i0 + (size_t)k * 256;
+        if (i < n4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pe = pv[k][r], me = mv[k][r], ve = vv[k][r];
+                adam_one(pe, gv[k][r], me, ve, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+                pv[k][r] = pe; mv[k][r] = me; vv[k][r] = ve;
+            }
+            m[i] = mv[k]; v[i] = vv[k]; p[i] = pv[k];
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < head + tail) {
+        const size_t e = (int)threadIdx.x < head ? (size_t)threadIdx.x : (size_t)head + n4 * 4 + (threadIdx.x - head);
+        float pe = ps[e], me = ms[e], ve = vs[e];
+        adam_one(pe, gs[e], me, ve, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        ms[e] = me; vs[e] = ve; ps[e] = pe;
+    }
+}
+template <bool DEV>
+void launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                 const int* step, hipStream_t st) {
+    const uintptr_t ph = reinterpret_cast<uintptr_t>(p) & 15;
+    const bool same_phase = (reinterpret_cast<uintptr_t>(g) & 15) == ph && (reinterpret_cast<uintptr_t>(m) & 15) == ph &&
+                            (reinterpret_cast<uintptr_t>(v) & 15) == ph && (ph & 3) == 0;
+    if (!same_phase || n < 8) {
+        if (DEV) hipLaunchKernelGGL(adam_dev_kernel, grid1(n, 16384), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, step);
+        else hipLaunchKernelGGL(adam_kernel, grid1(n, 16384), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        return;
+    }
+    const int head = (int)(((16 - ph) & 15) / 4);
+    const size_t n4 = (n - head) / 4;
+    const int tail = (int)(n - head - n4 * 4);
+    hipLaunchKernelGGL(adam_v4_kernel<DEV>, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, st, p, g, m, v, head, n4, tail, lr, b1, b2, eps, wd, bc1,
+                       bc2_sqrt, step);
+}
 __global__ void counter_add_kernel(int* c, int d) { *c += d; }
 
 // ---- Models_memory.py: the two memory nets of Prior_MemoryEncoder under autograd (the MLPs around them are ordinary Linear ops) ----------------
@@ -1955,8 +2025,7 @@ extern "C" int eg_counter_add(int32_t* counter, int32_t delta, void* stream) {
 extern "C" int eg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, const int32_t* step_dev, void* stream) {
     EG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev, EG_ERR_BAD_ARG, "eg_adam_step_dev: bad argument");
-    hipLaunchKernelGGL(adam_dev_kernel, grid1((size_t)n, 16384), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps,
-                       weight_decay, step_dev);
+    launch_adam<true>(param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, 0.f, 0.f, step_dev, ST);
     return eg_check_launch("adam_step_dev");
 }
 
@@ -1964,7 +2033,6 @@ extern "C" int eg_adam_step(float* param, const float* grad, float* exp_avg, flo
                             float weight_decay, int32_t step, void* stream) {
     EG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, EG_ERR_BAD_ARG, "eg_adam_step: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adam_kernel, grid1((size_t)n, 16384), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    launch_adam<false>(param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), nullptr, ST);
     return eg_check_launch("adam_step");
 }

@@ -317,6 +317,42 @@ def test_adam_matches_torch_optim():
         assert rel(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("dev_count", [False, True])
+def test_adam_float4_path_equals_the_scalar_kernel_on_every_slice_phase(dev_count):
+    """eg_adam_step / eg_adam_step_dev take the float4 kernel when the four slices share a 16-byte phase (bucket slices of the flat buffers do) and
+    update the elements in front of the first / behind the last float4 inside the same launch; a gradient slice on another phase forces the scalar
+    kernel.  Both must give the same bits for every (offset mod 4, length mod 4), including slices shorter than one workgroup."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    lib = L.load()
+    N = 70001
+    base = [T(k, (N + 8,), -1.0, 1.0).to(DEV) for k in ("p", "g", "m")] + [T("v", (N + 8,), 0.0, 1.0).to(DEV)]
+    step_dev = torch.tensor([3], dtype=torch.int32, device=DEV)
+    st = _stream(DEV)
+
+    def run(p, g, m, v):
+        n = p.numel()
+        if dev_count:
+            L.check(lib.eg_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, 2e-4, 0.5, 0.999, 1e-8, 1e-5, _ptr(step_dev), st), "eg_adam_step_dev")
+        else:
+            L.check(lib.eg_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, 2e-4, 0.5, 0.999, 1e-8, 1e-5, 3, st), "eg_adam_step")
+
+    for lo, n in ((0, N), (1, N - 2), (2, 4099), (3, 1025), (5, 9), (6, 8), (7, 31), (4, 70000), (1, 5)):
+        a = [t.clone() for t in base]
+        b = [t.clone() for t in base]
+        sa = [t[lo:lo + n] for t in a]
+        sb = [t[lo:lo + n] for t in b]
+        g_other = torch.empty(n + 8, device=DEV)[(lo + 1) % 4 + 1:][:n]              # the gradient on a different 16-byte phase: scalar kernel
+        assert (g_other.data_ptr() - sb[0].data_ptr()) % 16 != 0
+        g_other.copy_(sb[1])
+        run(*sa)
+        run(sb[0], g_other, sb[2], sb[3])
+        torch.cuda.synchronize()
+        for x, y, name in zip(a, b, "pgmv"):
+            assert torch.equal(x, y), (lo, n, name, float((x - y).abs().max()))        # bitwise, and nothing outside the slice touched
+        assert not torch.equal(a[0][lo:lo + n], base[0][lo:lo + n])
+
+
 # ---- block level: one SEBasicBlock at the activations / upstream gradient of a real training step ------------------------------------
 @pytest.mark.parametrize("li,bi", [(1, 1), (2, 0), (3, 5)])
 def test_se_block_backward_on_real_activations(li, bi):
