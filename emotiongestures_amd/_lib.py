@@ -147,6 +147,7 @@ SIGNATURES = {
     "eg_conv3x3_wgrad_mfma_oihw": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_conv3x3_wgrad_gather_mfma": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_conv3x3_dgrad_s2": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "eg_conv3x3_res_masked": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "eg_conv3x3_wgrad_mfma_oihw_in_affine": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "eg_conv3x3_sq_in_affine": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eg_bn_train_stats_sq": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, C.c_float, C.c_float, _P, _P]),

@@ -34,9 +34,23 @@ struct ConvArgs {
     // staging: x' = x * in_scale[ci] + in_shift[ci] for pixels inside the image, zero padding stays zero) -- split-bf16 kernels only
     const float* in_scale = nullptr; const float* in_shift = nullptr;
     int wrow = 0;                       // channel-split launches: row length of the weight images (the convolution's padded output channels)
+    const unsigned* res_bits = nullptr; // residual behind a ReLU mask: one bit per element of `res` (bit e & 31 of word e >> 5 = the nibble-per-float4 layout
+                                        // se_tail_fwd_kernel writes): v += bit ? res : 0 -- the SE block's identity shortcut gradient dout * (out > 0), never stored
     const float* res_q = nullptr;       // DG2 only: a gradient on the dy grid ([B][H][W][cout]) added to the (even, even) phase -- the stride-2 1x1 shortcut's
     unsigned int* dbg = nullptr;        // diagnostic build only (EG_CONV32_STAMP=1): per-wave phase cycle sums of the persistent 32->32 kernel
 };
+// a quad of the residual, behind its ReLU bit mask when there is one (e = element index of the quad's first float, a multiple of 4)
+__device__ __forceinline__ f4 residual_quad(const float* __restrict__ res, const unsigned* __restrict__ bits, size_t e) {
+    f4 r = *reinterpret_cast<const f4*>(res + e);
+    if (bits) {
+        const unsigned nb = bits[e >> 5] >> (unsigned)(e & 28);
+        r[0] = (nb & 1u) ? r[0] : 0.f;
+        r[1] = (nb & 2u) ? r[1] : 0.f;
+        r[2] = (nb & 4u) ? r[2] : 0.f;
+        r[3] = (nb & 8u) ? r[3] : 0.f;
+    }
+    return r;
+}
 
 template <int S, int TH> struct ConvGeom {
     static constexpr int IH = (TH - 1) * S + 3;
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
             }
             v = v * sc + sh;
             if (a.gate) v = v * gt;
-            if (a.res && valid && co < a.cout) v += *reinterpret_cast<const f4*>(a.res + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.cout + co);
+            if (a.res && valid && co < a.cout) v += residual_quad(a.res, a.res_bits, (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.cout + co);
             if (a.relu2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -514,7 +528,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
         const f4 sc = a.scale ? *reinterpret_cast<const f4*>(a.scale + co) : (f4){1.f, 1.f, 1.f, 1.f};
         const f4 sh = a.shift ? *reinterpret_cast<const f4*>(a.shift + co) : (f4){0.f, 0.f, 0.f, 0.f};
         const f4 gt = (a.gate && co < a.cout) ? *reinterpret_cast<const f4*>(a.gate + (size_t)b * a.cout + co) : (f4){1.f, 1.f, 1.f, 1.f};
-        const float* __restrict__ rb = a.res ? a.res + (size_t)b * hw * a.cout : nullptr;
+        const bool rb = a.res != nullptr;
+        const size_t rbase = (size_t)b * hw * a.cout;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             f4 v = acc[0][t][n] + bi;
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a, const 
             }
             v = v * sc + sh;
             if (a.gate) v = v * gt;
-            if (rb && pixo[t] >= 0 && co < a.cout) v += *reinterpret_cast<const f4*>(rb + pixo[t] * a.cout + co);
+            if (rb && pixo[t] >= 0 && co < a.cout) v += residual_quad(a.res, a.res_bits, rbase + (size_t)pixo[t] * a.cout + co);
             if (a.relu2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -725,15 +740,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_persistent_kernel(ConvArgs
     f4 rsn[MT][NT];
     auto load_res = [&](const Coord& c) {
         const int ty = c.ty, tx = c.tx;
-        const float* __restrict__ rb = a.res ? a.res + (size_t)c.b * hw * 32 : nullptr;
+        const size_t rbase = (size_t)c.b * hw * 32;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int id = wave * MT + t;
             const int oy = ty * TH + (id >> 1), ox = tx * 32 + (id & 1) * 16 + li;
-            const bool ok = rb && oy < a.Ho && ox < a.Wo;
+            const bool ok = a.res && oy < a.Ho && ox < a.Wo;
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                rsn[t][n] = ok ? *reinterpret_cast<const f4*>(rb + (oy * a.Wo + ox) * 32 + n * 16 + kq * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+                rsn[t][n] = ok ? residual_quad(a.res, a.res_bits, rbase + (size_t)(oy * a.Wo + ox) * 32 + n * 16 + kq * 4) : (f4){0.f, 0.f, 0.f, 0.f};
         }
     };
     Coord cur;
@@ -1249,12 +1264,22 @@ extern "C" int eg_conv3x3(const float* x, const float* w, const float* bias, con
 namespace {
 int conv3x3_dispatch(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate, const float* residual,
                      float* y, float* gap_partial, float* gap_sq, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
-                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream, const float* in_scale = nullptr, const float* in_shift = nullptr);
+                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream, const float* in_scale = nullptr, const float* in_shift = nullptr,
+                     const uint32_t* res_bits = nullptr);
 }
 extern "C" int eg_conv3x3_se(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate,
                              const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin,
                              int32_t cout, int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream) {
     return conv3x3_dispatch(x, w, bias, scale, shift, gate, residual, y, gap_partial, nullptr, batch, h, wdt, cin, cout, stride, relu, nchw_out, precision, stream);
+}
+// y = conv(x) + (bit ? residual : 0): the input gradient of an SE block's first convolution with the identity shortcut's gradient
+// dout * (out > 0) (ResNetBlocks.py:33-36) added in the epilogue straight from dout and the tail's ReLU bits (csrc/train.hip: se_tail_fwd_kernel writes one bit
+// per element, bit e & 31 of word e >> 5) -- the masked map is never stored.  Stride 1, NHWC, cout % 4 == 0; x is the upstream gradient, w the flipped image.
+extern "C" int eg_conv3x3_res_masked(const float* x, const float* w, const float* residual, const uint32_t* res_bits, float* y, int32_t batch, int32_t h,
+                                     int32_t wdt, int32_t cin, int32_t cout, int32_t precision, void* stream) {
+    EG_REQUIRE(residual && res_bits, EG_ERR_BAD_ARG, "eg_conv3x3_res_masked: the residual and its bit mask are required");
+    return conv3x3_dispatch(x, w, nullptr, nullptr, nullptr, nullptr, residual, y, nullptr, nullptr, batch, h, wdt, cin, cout, 1, 0, 0, precision, stream, nullptr,
+                            nullptr, res_bits);
 }
 // Training forward: y = [relu](conv(x) + bias), plus the per-(clip, tile) channel sums of y AND of y*y (both [batch][tiles][cout]): train-mode
 // BatchNorm takes its mean and variance from them (csrc/train.hip: eg_bn_train_forward_sq) without reading y again.  Split-bf16 modes only.
@@ -1280,8 +1305,10 @@ extern "C" int eg_conv3x3_sq_in_affine(const float* x, const float* in_scale, co
 namespace {
 int conv3x3_dispatch(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* gate, const float* residual,
                      float* y, float* gap_partial, float* gap_sq, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout, int32_t stride,
-                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream, const float* in_scale, const float* in_shift) {
+                     int32_t relu, int32_t nchw_out, int32_t precision, void* stream, const float* in_scale, const float* in_shift, const uint32_t* res_bits) {
     EG_REQUIRE(x && w && y && batch > 0 && h > 0 && wdt > 0, EG_ERR_BAD_ARG, "eg_conv3x3: null pointer or empty shape");
+    EG_REQUIRE(!res_bits || (residual && !gate && ((size_t)batch * h * wdt * cout) % 32 == 0), EG_ERR_BAD_ARG,
+               "eg_conv3x3_res_masked: the bit mask needs a residual, no gate and a map of a multiple of 32 elements");
     EG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!in_scale || (precision != EG_PREC_F32 && cin % 32 == 0 && eg_aligned16(in_scale) &&
                eg_aligned16(in_shift))), EG_ERR_BAD_ARG, "eg_conv3x3: the input affine needs both vectors, a split-bf16 mode and cin %% 32 == 0");
     // gate + residual: relu(v * gate + residual) (the fused SE tail); residual alone: v + residual, no ReLU (the training path's fused fan-in add:
@@ -1296,6 +1323,7 @@ int conv3x3_dispatch(const float* x, const float* w, const float* bias, const fl
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.gap = gap_partial; a.gap2 = gap_sq;
     a.gate = gate; a.res = residual; a.relu2 = gate ? 1 : 0;
+    a.res_bits = res_bits;
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.H = h; a.W = wdt; a.Ho = (h + 2 - 3) / stride + 1; a.Wo = (wdt + 2 - 3) / stride + 1;
     a.cout = cout; a.relu = relu; a.nchw = nchw_out;

@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(const f4* __rest
             const float xh = (x[k] - mu[k]) * rs[k];
             dx[k] = ga[k] * rs[k] * (dp[k] * gt[k] + dg[k] - a1[k] - xh * a2[k]);
         }
-        dres[i] = dp;
+        if (dres) dres[i] = dp;        // null: the consumer masks dout itself (eg_conv3x3_res_masked reads dout and the same bits)
         dc2[i] = dx;
     }
 }
@@ -1803,10 +1803,11 @@ extern "C" int eg_se_tail_backward_finish(const float* u1, const float* u2, cons
 extern "C" int eg_se_tail_backward_apply(const float* dout, const float* out, const uint32_t* relu_bits, const float* c2, const float* mean,
                                          const float* rstd, const float* gamma, const float* gate, const float* dgap_hw, const float* m1, const float* m2,
                                          float* dc2, float* dres, int32_t batch, int32_t hw, int32_t c, void* stream) {
-    EG_REQUIRE(dout && (out || relu_bits) && c2 && mean && rstd && gamma && gate && dgap_hw && m1 && m2 && dc2 && dres, EG_ERR_BAD_ARG,
+    EG_REQUIRE(dout && (out || relu_bits) && c2 && mean && rstd && gamma && gate && dgap_hw && m1 && m2 && dc2, EG_ERR_BAD_ARG,
                "eg_se_tail_backward_apply: null pointer");
+    EG_REQUIRE(dres || relu_bits, EG_ERR_BAD_ARG, "eg_se_tail_backward_apply: the residual's gradient may be left out only with the ReLU bit mask");
     SE_TAIL_SHAPE("eg_se_tail_backward_apply");
-    EG_REQUIRE(eg_aligned16(dout) && (!out || eg_aligned16(out)) && eg_aligned16(c2) && eg_aligned16(dc2) && eg_aligned16(dres), EG_ERR_ALIGN,
+    EG_REQUIRE(eg_aligned16(dout) && (!out || eg_aligned16(out)) && eg_aligned16(c2) && eg_aligned16(dc2) && (!dres || eg_aligned16(dres)), EG_ERR_ALIGN,
                "eg_se_tail_backward_apply: 16-byte aligned maps");
     const size_t n4 = (size_t)batch * hw * c / 4;
     hipLaunchKernelGGL(se_tail_bwd_apply_kernel, grid1(n4), dim3(256), 0, ST, reinterpret_cast<const f4*>(dout), reinterpret_cast<const f4*>(out),

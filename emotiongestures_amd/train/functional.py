@@ -556,7 +556,7 @@ class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(k=3, pad=1, stride s) on NHWC activations; weight OIHW as in the reference's state_dict."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False, passthrough=False, in_scale=None, in_shift=None):
+    def forward(ctx, x, w, b, stride, relu, want_gap=False, defer_mask=False, passthrough=False, in_scale=None, in_shift=None, res_link=None):
         lib = _lib()
         ctx.set_materialize_grads(False)            # no zero-filled "gradients" for the non-differentiable pooling partials / an unused alias
         xd, wd = _chk(x, "x"), _chk(w, "weight")
@@ -625,6 +625,11 @@ class _Conv3x3(torch.autograd.Function):
         ctx.params = (w, b)
         ctx.passthrough = bool(passthrough)
         ctx.pass_sub = passthrough == "sub"
+        # res_link (a dict shared with the block's se_block_tail): the tail's backward leaves (dout, ReLU bits) there instead of writing the identity
+        # shortcut's gradient dout * [out > 0] as a map; this backward masks dout in the input-gradient epilogue (eg_conv3x3_res_masked)
+        ctx.res_link = res_link if (passthrough is True and stride == 1 and Ci == Co and Ci % 32 == 0) else None
+        if res_link is not None and ctx.res_link is None:
+            raise L.EgError("conv3x3(res_link=...): only with passthrough=True on a square stride-1 convolution with channels % 32 == 0")
         outs = (y,)
         if want_gap:
             ctx.mark_non_differentiable(gap)
@@ -647,12 +652,15 @@ class _Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         B, H, W, Ci = x.shape
         Co = w.shape[0]
+        lazy = ctx.res_link.pop("masked", None) if ctx.res_link is not None else None        # (dout, bits) left by the block's tail
+        if lazy is not None and (dres is not None or dy is None):
+            raise L.EgError("conv3x3: the masked shortcut gradient cannot be combined with another gradient of the alias / a missing dy")
         if dy is None:              # only the alias was used downstream
             if dres is not None and ctx.pass_sub:
                 full = torch.empty_like(x)
                 L.check(lib.eg_subsample(_ptr(_chk(dres)), _ptr(full), B, H, W, Ci, ctx.stride, 1, _stream(x.device)), "eg_subsample")
                 dres = full
-            return (_chk(dres) if dres is not None else None), None, None, None, None, None, None, None, None, None
+            return (_chk(dres) if dres is not None else None), None, None, None, None, None, None, None, None, None, None
         dyd = _chk(dy)
         if y is not None:
             dyd = raw_ew(EW_RELU_BWD, dyd, y)
@@ -711,8 +719,13 @@ class _Conv3x3(torch.autograd.Function):
             wp = _pack_conv(w, flip=True)                                       # w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
             dx = torch.empty_like(x)
             res = _chk(dres) if dres is not None else None                      # the other consumer's gradient: added in the epilogue
-            L.check(lib.eg_conv3x3_se(_ptr(dyd), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"],
-                                      _stream(dev)), "eg_conv3x3 (dgrad)")
+            if lazy is not None:                                                # ... masked there from (dout, ReLU bits): never a map of its own
+                L.check(lib.eg_conv3x3_res_masked(_ptr(dyd), _ptr(wp), _ptr(lazy[0]), _ptr(lazy[1]), _ptr(dx), B, H, W, Co, Ci, _PREC["conv"], _stream(dev)),
+                        "eg_conv3x3_res_masked (dgrad)")
+                lazy = None
+            else:
+                L.check(lib.eg_conv3x3_se(_ptr(dyd), _ptr(wp), None, None, None, None, _ptr(res), _ptr(dx), None, B, H, W, Co, Ci, 1, 0, 0, _PREC["conv"],
+                                          _stream(dev)), "eg_conv3x3 (dgrad)")
             dres = None
         elif ctx.need_dx and _PREC["conv"] != F32 and ctx.stride == 1 and Ci == 128 and Co <= 64 and PAD_WGRAD:
             # final_conv1 (128 -> frames): the same rotated-filter convolution on dy and the filter zero-padded to 64 output channels, instead of
@@ -740,24 +753,26 @@ class _Conv3x3(torch.autograd.Function):
             dcol = raw_linear(dy2, wmat_t)                                    # [P, 9 Ci]
             dx = torch.empty_like(x)
             L.check(lib.eg_im2col3x3(_ptr(dcol), _ptr(dx), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_col2im3x3")
+        if lazy is not None and ctx.need_dx:
+            raise L.EgError("conv3x3: the masked shortcut gradient was left for an input-gradient path without the fused epilogue")
         if dres is not None and ctx.pass_sub:       # the shortcut's quarter-grid gradient on a path without the fused epilogue: scatter, then add
             full = torch.empty_like(x)
             L.check(lib.eg_subsample(_ptr(_chk(dres)), _ptr(full), B, H, W, Ci, ctx.stride, 1, _stream(dev)), "eg_subsample")
             dres = full
         if dres is not None:        # passthrough on a path without the fused epilogue (or no dx wanted): the plain add
             dx = raw_ew(EW_ADD, dx, _chk(dres)) if dx is not None else _chk(dres)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False, passthrough=False):
+def conv3x3(x_nhwc, w_oihw, b=None, stride=1, relu=False, want_gap=False, defer_mask=False, passthrough=False, res_link=None):
     """want_gap: also return the per-(clip, tile) channel sums of the output; defer_mask: the ReLU's backward is applied by the consumer;
     passthrough: also return an alias of the input for its second consumer (the residual branch) -- the two gradients are then summed in the
     input-gradient launch's epilogue instead of by a `fork`; passthrough="sub" (stride > 1): that consumer is the strided 1x1 shortcut, the extra
     output is x[:, ::stride, ::stride] and its gradient comes back on that grid."""
     aff = getattr(x_nhwc, "_eg_in_affine", None)        # a deferred BatchNorm produced x: (scale, shift) to apply while staging
     if aff is not None:
-        return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough, aff[0], aff[1])
-    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough)
+        return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough, aff[0], aff[1], res_link)
+    return _Conv3x3.apply(x_nhwc, w_oihw, b, stride, relu, want_gap, defer_mask, passthrough, None, None, res_link)
 
 
 class _Subsample(torch.autograd.Function):
@@ -891,6 +906,7 @@ def batch_norm(x_channels_last, bn, momentum=0.1, eps=1e-5, gap=None, relu_input
 
 
 SE_TAIL_RELU_BITS = __import__("os").environ.get("EG_SE_TAIL_BITS", "1") != "0"       # False: the tail's backward reads the block output for its ReLU mask (A/B)
+LAZY_SHORTCUT_GRAD = __import__("os").environ.get("EG_LAZY_SHORTCUT", "1") != "0"     # False: the tail writes the identity shortcut's gradient as a map (A/B)
 
 
 class _SEBlockTail(torch.autograd.Function):
@@ -898,7 +914,7 @@ class _SEBlockTail(torch.autograd.Function):
     partials + one centred pass, the SE gate per clip, one fused output pass; bn2's output is never stored (the backward recomputes it)."""
 
     @staticmethod
-    def forward(ctx, c2, gap, res, gamma, beta, run_mean, run_var, w1, b1, w2, b2, momentum, eps):
+    def forward(ctx, c2, gap, res, gamma, beta, run_mean, run_var, w1, b1, w2, b2, momentum, eps, res_link=None):
         lib = _lib()
         x, r = _chk(c2), _chk(res)
         B, H, W, Cc = x.shape
@@ -922,6 +938,9 @@ class _SEBlockTail(torch.autograd.Function):
         L.check(lib.eg_se_tail_forward(_ptr(x), _ptr(r), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(bt), _ptr(gate), _ptr(out), _ptr(bits), B, hw, Cc, st), "eg_se_tail_forward")
         ctx.save_for_backward(x, out if bits is None else bits, mean, rstd, clip, pooled, h, gate, g, bt, w1d, w2d)
         ctx.has_bits = bits is not None
+        # res_link: `res` is the block input's alias out of conv1 (an identity shortcut); with the bit mask its gradient is not written as a map --
+        # (dout, bits) go into the link and conv1's input-gradient epilogue masks dout itself (1.4 GB less written per 128-clip step)
+        ctx.res_link = res_link if bits is not None else None
         ctx.params = (gamma, beta, w1, b1, w2, b2)
         return out
 
@@ -948,14 +967,19 @@ class _SEBlockTail(torch.autograd.Function):
         dg, db, dw1, db1, dw2, db2 = (grad_out(p) for p in ctx.params)
         L.check(lib.eg_se_tail_backward_finish(_ptr(u1), _ptr(u2), _ptr(dz2), _ptr(dz1), _ptr(h), _ptr(pooled), _ptr(dg), _ptr(db), _ptr(m1), _ptr(m2),
                                                _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), B, hw, Cc, st), "eg_se_tail_backward_finish")
-        dc2, dres = torch.empty_like(x), torch.empty_like(x)
+        dc2 = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.res_link is None else None
+        if ctx.res_link is not None:
+            ctx.res_link["masked"] = (d, bits)
         L.check(lib.eg_se_tail_backward_apply(_ptr(d), _ptr(out), _ptr(bits), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(gate), _ptr(dgap), _ptr(m1), _ptr(m2),
                                               _ptr(dc2), _ptr(dres), B, hw, Cc, st), "eg_se_tail_backward_apply")
-        return dc2, None, dres, dg, db, None, None, dw1, db1, dw2, db2, None, None
+        return dc2, None, dres, dg, db, None, None, dw1, db1, dw2, db2, None, None, None
 
 
-def se_block_tail(c2, gap, res, bn, fc0, fc2, momentum=0.1, eps=1e-5):
-    out = _SEBlockTail.apply(c2, gap, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, fc0.weight, fc0.bias, fc2.weight, fc2.bias, momentum, eps)
+def se_block_tail(c2, gap, res, bn, fc0, fc2, momentum=0.1, eps=1e-5, res_link=None):
+    """res_link: the dict also given to the conv3x3(passthrough=True, res_link=...) whose alias output `res` is (see _Conv3x3.forward)."""
+    out = _SEBlockTail.apply(c2, gap, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, fc0.weight, fc0.bias, fc2.weight, fc2.bias, momentum, eps,
+                             res_link)
     _running_stats_written(bn)
     return out
 

@@ -92,7 +92,12 @@ def se_basic_block(blk, x):
     # conv1 -> ReLU -> bn1 (:24-26); the block input's second consumer (the residual branch) goes through the convolution's passthrough
     # output: the two input gradients are summed in conv1's input-gradient launch
     sub = blk.downsample is not None and blk.stride != 1       # the shortcut is the strided 1x1 convolution: it reads x[:, ::s, ::s] only
-    r1, gap1, xb = F.conv3x3(x, blk.conv1.weight, None, blk.stride, relu=True, want_gap=True, defer_mask=True, passthrough="sub" if sub else True)
+    # identity shortcut: its gradient dout * [out > 0] is never written -- the tail leaves (dout, its ReLU bits) in `link` and conv1's input-gradient
+    # epilogue masks dout itself
+    link = {} if (blk.downsample is None and F.LAZY_SHORTCUT_GRAD and x.requires_grad and x.shape[-1] % 32 == 0 and
+                  blk.conv1.weight.shape[0] == x.shape[-1] and blk.stride == 1) else None
+    r1, gap1, xb = F.conv3x3(x, blk.conv1.weight, None, blk.stride, relu=True, want_gap=True, defer_mask=True, passthrough="sub" if sub else True,
+                             res_link=link)
     # bn1 is not applied here: conv2 (and its weight-gradient kernel) apply it as a per-channel affine while staging r1 (split-bf16 modes)
     b1 = F.batch_norm(r1, blk.bn1, gap=gap1, relu_input=True, defer_apply=True)
     c2, gap2 = F.conv3x3(b1, blk.conv2.weight, want_gap=True)
@@ -100,7 +105,7 @@ def se_basic_block(blk, x):
         res = F.batch_norm(F.conv1x1(xb, blk.downsample[0].weight, 1 if sub else blk.stride), blk.downsample[1])      # sub: xb is already the strided map
     else:
         res = xb
-    out = F.se_block_tail(c2, gap2, res, blk.bn2, blk.se.fc[0], blk.se.fc[2])
+    out = F.se_block_tail(c2, gap2, res, blk.bn2, blk.se.fc[0], blk.se.fc[2], res_link=link)
     if TAP_FUSED is not None:
         if r1.requires_grad:
             r1.retain_grad()            # the (masked) gradient at conv1's ReLU output: lets a test weigh a mask element it decides differently

@@ -250,6 +250,12 @@ int32_t eg_conv3x3_gap_tiles(int32_t h, int32_t wdt, int32_t cin, int32_t cout, 
 int eg_conv3x3_se(const float* x, const float* w_packed, const float* bias, const float* scale, const float* shift, const float* gate,
                   const float* residual, float* y, float* gap_partial, int32_t batch, int32_t h, int32_t wdt, int32_t cin, int32_t cout,
                   int32_t stride, int32_t relu, int32_t nchw_out, int32_t precision, void* stream);
+/* y = conv(x) + (bit ? residual : 0), stride 1, NHWC: the input gradient of an SEBasicBlock's first convolution with the identity shortcut's
+ * gradient dout * [out > 0] (ResNetBlocks.py:33-36 under autograd) added in the epilogue from `dout` and the tail's ReLU bit mask (eg_se_tail_forward's
+ * relu_bits: bit e & 31 of word e >> 5 for element e) -- the masked map is never stored (eg_se_tail_backward_apply with dres == NULL).
+ * x = the upstream gradient, w_packed = the flipped filter image (eg_pack_conv3x3_device with flip_transpose). */
+int eg_conv3x3_res_masked(const float* x, const float* w_packed, const float* residual, const uint32_t* res_bits, float* y, int32_t batch, int32_t h,
+                          int32_t wdt, int32_t cin, int32_t cout, int32_t precision, void* stream);
 /* Training forward of a tower convolution (nn.Conv2d -> optional ReLU, ResNetBlocks.py:24-27 under autograd) in the split-bf16 modes: y as
  * eg_conv3x3 plus BOTH per-(clip, tile) channel partials, sums of y and of y*y ([batch][eg_conv3x3_gap_tiles][cout] each), so that the train-mode
  * BatchNorm that follows takes mean and variance from them (eg_bn_train_forward_sq) without reading y again. */
@@ -494,7 +500,8 @@ int eg_se_gate_train_forward(const float* clip_sum, const float* mean, const flo
                              int32_t c, void* stream);
 /* relu_bits (optional, batch * hw * c / 32 words; needs batch * hw * c % 32 == 0): the tail's ReLU mask [out > 0] as one nibble per float4 of the
  * map, eight float4 indices per word.  The two backward passes take it INSTEAD of `out` (then `out` may be NULL): they read 1/32 of a map where
- * they read a whole one (3.4 GB of the 128-clip step's 78). */
+ * they read a whole one (3.4 GB of the 128-clip step's 78).  eg_se_tail_backward_apply: dres may be NULL when relu_bits is given -- the consumer of
+ * the shortcut's gradient then masks `dout` itself (eg_conv3x3_res_masked). */
 int eg_se_tail_forward(const float* c2, const float* res, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        const float* gate, float* out, uint32_t* relu_bits, int32_t batch, int32_t hw, int32_t c, void* stream);
 int eg_se_tail_backward_reduce(const float* dout, const float* out, const uint32_t* relu_bits, const float* c2, const float* mean, float* s1,

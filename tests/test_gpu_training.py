@@ -113,6 +113,69 @@ def test_stride2_input_gradient_kernel_matches_float64(B, H, W, Ci, Co):
         L.check(lib.eg_conv3x3_dgrad_s2(_ptr(dyd), _ptr(wp), None, _ptr(dx), B, H, W, Ci, Co, L.EG_PREC_F32, _stream(dx.device)), "eg_conv3x3_dgrad_s2")
 
 
+@pytest.mark.parametrize("B,H,W,C,prec", [(2, 128, 124, 32, "bf16x3"), (3, 64, 62, 64, "bf16x3"), (2, 32, 31, 128, "bf16x3"), (16, 128, 124, 32, "bf16x3"),
+                                          (1, 7, 9, 64, "bf16x3"), (2, 20, 12, 32, "f32"), (2, 16, 16, 128, "bf16"), (1, 4, 8, 256, "bf16x3")])
+def test_masked_shortcut_gradient_in_the_input_gradient_epilogue(B, H, W, C, prec):
+    """eg_conv3x3_res_masked: conv(x) + (bit ? residual : 0) -- an identity SE block's conv1 input gradient with the shortcut's gradient dout * [out > 0]
+    (ResNetBlocks.py:33-36 under autograd) masked in the epilogue from the tail's ReLU bits -- against eg_conv3x3_se fed the masked map itself, bitwise,
+    on every convolution kernel that carries a residual (persistent 32-channel, the 64 / 128 / 256-channel bodies with and without channel split, the
+    fp32 kernel); the bits are the ones eg_se_tail_forward writes."""
+    from emotiongestures_amd import _lib as L
+    from emotiongestures_amd.engine import _ptr, _stream
+    from emotiongestures_amd.train import functional as F
+    lib = L.load()
+    P = {"f32": L.EG_PREC_F32, "bf16": L.EG_PREC_BF16, "bf16x3": L.EG_PREC_BF16X3}[prec]
+    w = T("w", (C, C, 3, 3), -0.1, 0.1).to(DEV)
+    dy, dout, out = T("dy", (B, H, W, C)).to(DEV), T("dout", (B, H, W, C)).to(DEV), T("out", (B, H, W, C), -1.0, 1.0, seed=3).to(DEV)
+    st = _stream(DEV)
+    # the bits as the forward writes them: relu(c2 * 1 + res) with res = 0, identity BatchNorm and gate -> out = relu(c2)
+    one, zero, gate = torch.ones(C, device=DEV), torch.zeros(C, device=DEV), torch.ones(B, C, device=DEV)
+    o2, bits = torch.empty_like(out), torch.empty(out.numel() // 32, dtype=torch.int32, device=DEV)
+    L.check(lib.eg_se_tail_forward(_ptr(out), _ptr(torch.zeros_like(out)), _ptr(zero), _ptr(one), _ptr(one), _ptr(zero), _ptr(gate), _ptr(o2), _ptr(bits),
+                                   B, H * W, C, st), "eg_se_tail_forward")
+    assert torch.equal(o2 > 0, out > 0)
+    masked = torch.where(out > 0, dout, torch.zeros_like(dout))
+    wp = F._pack_conv(w, flip=True)
+    a, b = torch.full_like(dy, float("nan")), torch.full_like(dy, float("nan"))
+    L.check(lib.eg_conv3x3_se(_ptr(dy), _ptr(wp), None, None, None, None, _ptr(masked), _ptr(a), None, B, H, W, C, C, 1, 0, 0, P, st), "eg_conv3x3_se")
+    L.check(lib.eg_conv3x3_res_masked(_ptr(dy), _ptr(wp), _ptr(dout), _ptr(bits), _ptr(b), B, H, W, C, C, P, st), "eg_conv3x3_res_masked")
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    plain = torch.empty_like(dy)
+    L.check(lib.eg_conv3x3(_ptr(dy), _ptr(wp), None, None, None, _ptr(plain), None, B, H, W, C, C, 1, 0, 0, P, st), "eg_conv3x3")
+    assert not torch.equal(plain, b)
+    with pytest.raises(L.EgError):          # no bits: not this entry point
+        L.check(lib.eg_conv3x3_res_masked(_ptr(dy), _ptr(wp), _ptr(dout), None, _ptr(b), B, H, W, C, C, P, st), "eg_conv3x3_res_masked")
+
+
+def test_identity_block_backward_without_the_shortcut_gradient_map():
+    """nets.se_basic_block with functional.LAZY_SHORTCUT_GRAD: the tail's backward writes no dres map and conv1's input-gradient epilogue masks dout from
+    the ReLU bits -- every gradient of the block (input, convolutions, BatchNorms, SE) bitwise the materialised composition's."""
+    from emotiongestures_amd.modules import SEBasicBlock
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train import nets
+    old = F.LAZY_SHORTCUT_GRAD
+    res = []
+    try:
+        for lazy in (True, False):
+            F.LAZY_SHORTCUT_GRAD = lazy
+            with F.precision("bf16x3"):
+                blk = load_synth_weights(SEBasicBlock(64, 64), 4).to(DEV).train()
+                x = T("x", (3, 32, 30, 64)).to(DEV).requires_grad_(True)
+                xin = F.relu(x)                  # a producer in front: the block input needs a gradient through an operator
+                out = nets.se_basic_block(blk, xin)
+                out.backward(T("g", tuple(out.shape)).to(DEV))
+                torch.cuda.synchronize()
+                res.append([x.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+            F.reset_state()
+    finally:
+        F.LAZY_SHORTCUT_GRAD = old
+        F.reset_state()
+    assert len(res[0]) == len(res[1]) >= 11
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride", [(2, 128, 124, 32, 64, 2), (3, 64, 62, 64, 128, 2), (2, 17, 13, 32, 64, 2), (1, 31, 33, 64, 128, 2), (2, 16, 16, 128, 256, 2),
                                                 (40, 20, 18, 32, 64, 2), (2, 12, 20, 32, 32, 1)])
 def test_gathered_weight_gradient_matches_float64(B, H, W, Ci, Co, stride):
