@@ -1036,10 +1036,16 @@ __global__ __launch_bounds__(GP_T) void se_gate_pre_kernel(const float* __restri
         m[t] = z / (float)(H * W) * scale2[t] + shift2[t];
     }
     __syncthreads();
-    if (t < R) {
-        float s = b1[t];
-        for (int cc = 0; cc < C; ++cc) s += w1[t * C + cc] * m[cc];
-        hbuf[t] = fmaxf(s, 0.f);
+    {   // hidden layer: one wave per unit, lanes stride the C inputs, fixed-order wave reduction (R threads each walking a row of W1 was a
+        // 2.5 us serial chain at C = 128: stamps in profiles/r06_gate_pre_stamps.txt)
+        const int wv = t >> 6, lane = t & 63;
+        for (int j = wv; j < R; j += GP_T / 64) {
+            float s = 0.f;
+            for (int cc = lane; cc < C; cc += 64) s += w1[j * C + cc] * m[cc];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) hbuf[j] = fmaxf(s + b1[j], 0.f);
+        }
     }
     __syncthreads();
     if (t < C) {
