@@ -416,6 +416,79 @@ def test_adam_float4_path_equals_the_scalar_kernel_on_every_slice_phase(dev_coun
         assert not torch.equal(a[0][lo:lo + n], base[0][lo:lo + n])
 
 
+def test_generator_and_discriminator_trained_side_by_side_share_the_process_state():
+    """The reference's adversarial setup trains several models in one process (generator + emotion CVAE, a Motion_Discriminator on the generated
+    motion: Models_memory.py Motion_Discriminator, test_emotion_gesture_diversity_iterative.py:41-44 calc_motion).  The training layer keeps its
+    state per process (precision, scratch buffers, registered weight images, dropout stream): two flattened models with their own optimisers and
+    their own RESIDENT weight images, stepped alternately (discriminator on real / detached fake motion -- its parameters used twice per step --, then
+    the generator through the discriminator), must give bit for bit the parameters of the same schedule with every weight image packed per use:
+    neither model may read the other's images, a stale image, or scratch the other still needs."""
+    from emotiongestures_amd import harness as H
+    from emotiongestures_amd.CAVE.BEAT_CVAE import MLP_Reconstruct_v3
+    from emotiongestures_amd.Full_model.Models_memory import Motion_Discriminator
+    from emotiongestures_amd.train import functional as F
+    from emotiongestures_amd.train import nets
+    from emotiongestures_amd.train.optim import FlatAdam, flatten_parameters
+    B = 3
+    inp = synth_inputs(B, 34, 126, 4, seed=41)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    target = T("tgt", (B, 34, 126), -0.5, 0.5).to(DEV)
+    label, eps = g["label"].argmax(1), g["z"]
+    motion = lambda p: TF.pad(H.calc_motion(p), (0, 2))         # 126 joints' offsets, zero-padded to the discriminator's width (pose_dim == d_model == 128)
+    runs = []
+    try:
+        for resident in (True, False):
+            F.set_precision("bf16x3")
+            gen = build_mirror("spatial", 34, 126, 4, 4, seed=2, precision="f32").to(DEV).train()
+            vae = load_synth_weights(MLP_Reconstruct_v3(frames=34), 2).to(DEV).train()
+            disc = load_synth_weights(Motion_Discriminator(frames=33, pose_dim=128, d_word_vec=128, d_model=128, d_inner=1024, n_layers=2, n_head=8, d_k=64,
+                                                           d_v=64, n_position=33, precision="f32"), 21).to(DEV).train()
+            both = torch.nn.ModuleList([gen, vae])
+            fp_g, fp_d = flatten_parameters(both), flatten_parameters(disc)
+            if resident:
+                fp_g.enable_weight_images(*nets.weight_image_plan(both))
+                fp_d.enable_weight_images(*nets.weight_image_plan(disc))
+                assert len(F._IMAGES["reg"]) == 2
+            opt_g = FlatAdam(fp_g, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+            opt_d = FlatAdam(fp_d, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+            losses = []
+            for _step in range(3):
+                # discriminator step: real motion -> 1, generated (detached) motion -> 0
+                with torch.no_grad():
+                    gen.eval(), vae.eval()            # the inference engine on the CURRENT weights (its packed images follow the parameters' versions)
+                    fake = gen(g["spec"], g["text"], g["pre_pose"], vae.sample(g["label"], eps))[0]
+                    gen.train(), vae.train()
+                opt_d.zero_grad()
+                lr_, lf_ = disc(motion(target)), disc(motion(fake.detach()))
+                loss_d = F.add(F.smooth_l1_loss(lr_, torch.ones_like(lr_), 1.0, 1.0), F.smooth_l1_loss(lf_, torch.zeros_like(lf_), 1.0, 1.0))
+                loss_d.backward()
+                opt_d.step()
+                # generator step: its own losses + the discriminator's verdict on the motion it generates
+                opt_g.zero_grad()
+                opt_d.zero_grad()
+                pose, emo, _s, pred, _t = gen(g["spec"], g["text"], g["pre_pose"], None)
+                rec, mu, logvar = vae(emo.detach(), g["label"], eps)
+                adv = disc(motion(pose))
+                loss_g = F.add(F.add(F.smooth_l1_loss(pose, target, 1.0, 100.0), F.cross_entropy(pred, label)),
+                               F.add(F.add(F.smooth_l1_loss(rec, emo.detach(), 1.0, 1.0), F.kld_loss(mu, logvar, 1.0)),
+                                     F.smooth_l1_loss(adv, torch.ones_like(adv), 1.0, 1.0)))
+                loss_g.backward()
+                opt_g.step()
+                losses.append((float(loss_d.detach()), float(loss_g.detach())))
+            torch.cuda.synchronize()
+            runs.append((losses, fp_g.flat.clone(), fp_d.flat.clone()))
+            for fp in (fp_g, fp_d):
+                if fp.images is not None:
+                    F.unregister_weight_images(fp.images)
+            F.reset_state()
+    finally:
+        F.reset_state()
+    (la, ga, da), (lb, gb_, db_) = runs
+    assert la == lb, (la, lb)
+    assert torch.equal(ga, gb_) and torch.equal(da, db_)
+    assert la[0] != la[2] and all(np.isfinite(x) for pair in la for x in pair)          # the schedule did train both
+
+
 # ---- block level: one SEBasicBlock at the activations / upstream gradient of a real training step ------------------------------------
 @pytest.mark.parametrize("li,bi", [(1, 1), (2, 0), (3, 5)])
 def test_se_block_backward_on_real_activations(li, bi):
