@@ -660,6 +660,7 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
     worst, worst_tower, n, tight = 0.0, 0.0, 0, 0
     tower_errs = []
     outliers = {}
+    bad = []                    # every parameter outside the tower over its bound (reported together: a moved flip shows its whole upstream set)
     for k, p in model.named_parameters():
         gr = sd_ref[k].grad
         if gr is None or float(gr.abs().max()) == 0.0:
@@ -688,7 +689,9 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
             lo = loose_tol is not None and k.startswith(tuple(loose))
             if os.environ.get("EG_GRAD_REPORT"):
                 print(f"   {k:60s} {e:.2e}{'  (upstream of a flipped ReLU element)' if lo else ''}")
-            assert e < (loose_tol if lo else tol), f"{k}: gradient rel-L2 {e:.2e}"
+            if not e < (loose_tol if lo else tol):
+                bad.append(f"{k}: gradient rel-L2 {e:.2e}")
+    assert not bad, bad
     # tower: the bulk within tower_tol; an isolated parameter may sit right behind a flipped unit (an SE hidden layer has C/8 units
     # x B samples: one flipped unit is a large share of its gradient)
     te = np.sort(np.asarray(tower_errs))
