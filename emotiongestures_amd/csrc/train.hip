@@ -317,21 +317,36 @@ __global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__
 //   mode 4 (fast path only): mode 2 with a replaced by a * [mask > 0]  (gradient behind a ReLU whose output is `mask`)
 // The centred forms (2, 3) keep BatchNorm exact for channels whose mean is large against their spread (post-ReLU maps):
 // E[x^2] - mean^2 from fp32 partial sums loses ~eps*mean^2/var there (measured: 3e-3 in the input gradient of one block).
+// (generic channel counts -- 34 / 60 / 120 frame channels behind final_conv1, the TCN's widths: the mode is a template parameter and eight rows'
+// loads are in flight per thread; with the mode a runtime branch inside a one-load-per-iteration loop a [15 872, 34] map took 21 us, round 6)
+template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mean,
-                                                          float* __restrict__ part, long rows, int C, long rows_per, int mode) {
+                                                          float* __restrict__ part, long rows, int C, long rows_per) {
     __shared__ float s0[4][64], s1[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const long r0 = (long)blockIdx.y * rows_per, r1 = (r0 + rows_per < rows) ? r0 + rows_per : rows;
     float u = 0.f, v = 0.f;
     if (c < C) {
-        const float mu = (mode >= 2) ? mean[c] : 0.f;
-        for (long r = r0 + w; r < r1; r += 4) {
-            const float x = a[(size_t)r * C + c];
-            if (mode == 0) { u += x; v += x * x; }
-            else if (mode == 1) { u += x; v += x * b[(size_t)r * C + c]; }
-            else if (mode == 2) { u += x; v += x * (b[(size_t)r * C + c] - mu); }
+        const float mu = (MODE >= 2) ? mean[c] : 0.f;
+        auto fold = [&](float x, float y) {
+            if (MODE == 0) { u += x; v += x * x; }
+            else if (MODE == 1) { u += x; v += x * y; }
+            else if (MODE == 2) { u += x; v += x * (y - mu); }
             else { const float d = x - mu; u += d * d; }
+        };
+        constexpr bool HAS_B = (MODE == 1 || MODE == 2);
+        long r = r0 + w;
+        for (; r + 28 < r1; r += 32) {              // eight rows of this thread's column in flight, folded in row order
+            float x[8], y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                x[k] = a[(size_t)(r + 4 * k) * C + c];
+                y[k] = HAS_B ? b[(size_t)(r + 4 * k) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fold(x[k], y[k]);
         }
+        for (; r < r1; r += 4) fold(a[(size_t)r * C + c], HAS_B ? b[(size_t)r * C + c] : 0.f);
     }
     s0[w][threadIdx.x & 63] = u;
     s1[w][threadIdx.x & 63] = v;
@@ -1574,7 +1589,7 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
     const bool fast = (c >= 4) && (1024 % c == 0) && eg_aligned16(a) && (!b || eg_aligned16(b));
     long cap = COL_MAX_PART / nseg;
     if (cap < 1) cap = 1;
-    long nblk = fast ? (rows * c + 16383) / 16384 : (rows + 255) / 256;         // fast path: >= 64 KB of input per block
+    long nblk = fast ? (rows * c + 16383) / 16384 : (rows + 127) / 128;         // fast path: >= 64 KB of input per block; generic: 128 rows x 64 columns
     if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     const long rows_per = (rows + nblk - 1) / nblk;
@@ -1595,10 +1610,15 @@ int col_reduce(const float* a, const float* b, const float* mean, int64_t rows, 
         return eg_check_launch("col_partial_fast");
     }
     EG_REQUIRE(mode != 4, EG_ERR_UNSUPPORTED, "column reduction behind a ReLU mask: C=%d must divide 1024 and the operands be 16-byte aligned", c);
+    EG_REQUIRE((mode == 0 && !b) || (mode == 1 && b) || (mode == 2 && b) || (mode == 3 && !b), EG_ERR_BAD_ARG, "column reduction: mode %d with%s a second operand", mode,
+               b ? "" : "out");
     for (int sgi = 0; sgi < nseg; ++sgi) {       // generic channel counts: one launch per segment
         const size_t off = (size_t)sgi * rows * c;
-        hipLaunchKernelGGL(col_partial_kernel, dim3(eg_cdiv(c, 64), (unsigned)nblk), dim3(256), 0, st, a + off, b ? b + off : nullptr, mean,
-                           part + (size_t)sgi * nblk * 2 * c, (long)rows, c, rows_per, mode);
+        const dim3 grid(eg_cdiv(c, 64), (unsigned)nblk), block(256);
+        float* po = part + (size_t)sgi * nblk * 2 * c;
+#define CPG(M) hipLaunchKernelGGL((col_partial_kernel<M>), grid, block, 0, st, a + off, b ? b + off : nullptr, mean, po, (long)rows, c, rows_per)
+        if (mode == 0) CPG(0); else if (mode == 1) CPG(1); else if (mode == 2) CPG(2); else CPG(3);
+#undef CPG
         if (int rc = eg_check_launch("col_partial")) return rc;
     }
     return EG_OK;

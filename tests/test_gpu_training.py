@@ -647,7 +647,76 @@ def test_tower_site_backward_matches_reference_golden(site, precision, tol):
 
 
 # ---- network level -----------------------------------------------------------------------------------------------------------
-def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_flip=None, loose=(), loose_tol=None):
+class _OracleReluSites:
+    """Record the INPUT of every F.relu / F.leaky_relu call of the CPU oracle (tensors inside its autograd graph), in call order."""
+
+    def __enter__(self):
+        from oracle import emogest_oracle as O
+        self.O, self.keep, self.sites = O, O.F, []
+        rec = self
+
+        class Proxy:
+            def __getattr__(self, name):
+                return getattr(rec.keep, name)
+
+            @staticmethod
+            def relu(x, *a, **k):
+                rec.sites.append(x)
+                return rec.keep.relu(x, *a, **k)
+
+            @staticmethod
+            def leaky_relu(x, *a, **k):
+                rec.sites.append(x)
+                return rec.keep.leaky_relu(x, *a, **k)
+        O.F = Proxy()
+        return self
+
+    def __exit__(self, *exc):
+        self.O.F = self.keep
+
+
+def _flipped_units_and_their_upstream(oracle_sites, gpu_sites, sd_ref, min_matched, bound=1e-4):
+    """ReLU units the oracle's forward and the GPU's decide differently, and the parameters UPSTREAM of them.
+
+    oracle_sites: _OracleReluSites.sites (pre-activations, in the oracle's autograd graph); gpu_sites: _ReluSites.sites (post-ReLU outputs of the
+    Linear epilogues, inputs of the elementwise ReLUs).  Sites are matched BY CONTENT (same element count, relu(x) equal to 1e-2 relative, a
+    [B, C, L] oracle tensor also tried channels-last) -- the two implementations visit their branches in different orders.  The audio tower's ReLUs
+    live inside the convolution kernels and stay unmatched: the tower has its own bounds.  Every flipped pre-activation must be rounding-sized
+    (|x| < bound on the oracle's side).  -> (flips [(oracle site index, element count)], names of the parameters the flipped units depend on:
+    what autograd reaches from those elements -- a flipped unit changes the gradient of exactly these, and of nothing else outside the tower)."""
+    params = {k: v for k, v in sd_ref.items() if v.is_floating_point() and v.requires_grad}
+    names = list(params)
+    used, matched, flips, upstream = set(), 0, [], set()
+    for i, xo in enumerate(oracle_sites):
+        cands = [xo] + ([xo.transpose(1, 2)] if xo.dim() == 3 else []) + ([xo.permute(0, 2, 3, 1)] if xo.dim() == 4 else [])
+        hit = None
+        for j, (_name, yg) in enumerate(gpu_sites):
+            if j in used or yg.numel() != xo.numel():
+                continue
+            g = torch.relu(yg.detach().cpu().float()).reshape(-1)
+            for c in cands:
+                r = torch.relu(c.detach()).reshape(-1)
+                if float((r - g).norm()) <= 1e-2 * float(r.norm()) + 1e-12:
+                    hit = (j, c, yg.detach().cpu().float().reshape(-1))
+                    break
+            if hit is not None:
+                break
+        if hit is None:
+            continue
+        used.add(hit[0])
+        matched += 1
+        xc = hit[1].reshape(-1)
+        d = ((xc.detach() > 0) != (hit[2] > 0)).nonzero().reshape(-1)
+        if d.numel():
+            assert float(xc.detach()[d].abs().max()) < bound, (i, xc.detach()[d][:8], hit[2][d][:8])        # rounding-sized pre-activations only
+            flips.append((i, int(d.numel())))
+            gr = torch.autograd.grad(xc[d].sum(), [params[k] for k in names], retain_graph=True, allow_unused=True)
+            upstream |= {k for k, t in zip(names, gr) if t is not None and float(t.abs().max()) > 0}
+    assert matched >= min_matched, f"only {matched} ReLU sites of the oracle found on the GPU side"
+    return flips, upstream
+
+
+def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_flip=None, loose=(), loose_tol=None, upstream=None):
     """Per-parameter relative L2 of the gradient.  Parameters under `tower_prefix` (the ReLU/BatchNorm convolution tower) get
     `tower_tol`: a ReLU's gradient is discontinuous at 0, the two fp32 forwards differ by ~6e-6, and ONE flipped mask element
     changes everything upstream of it (measured with tools/debug_block_grad.py: 2 of 253,952 mask elements of layer3.5.conv1
@@ -656,7 +725,9 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
     behind_flip: the tower parameters that sit directly behind a flipped mask element at these weights / inputs, BY NAME -- only they may exceed
     2.5 x tower_tol (and must stay under 0.5: a flipped unit of an SE hidden layer with C/8 units x B samples is a large share of that layer's
     gradient); every other tower parameter is held to 2.5 x tower_tol.  (None: the round-5 form, max < 0.5 for any tower parameter.)
-    loose / loose_tol: name prefixes OUTSIDE the tower that sit upstream of a ReLU element known to be decided differently: held to `loose_tol`."""
+    loose / loose_tol: name prefixes OUTSIDE the tower that sit upstream of a ReLU element known to be decided differently: held to `loose_tol`.
+    upstream (a set of names, from _flipped_units_and_their_upstream): replaces the `loose` prefixes by the COMPUTED set of parameters the flipped
+    units of this very run depend on -- empty set: every parameter outside the tower is held to `tol`."""
     worst, worst_tower, n, tight = 0.0, 0.0, 0, 0
     tower_errs = []
     outliers = {}
@@ -686,7 +757,7 @@ def _compare_param_grads(model, sd_ref, tol, tower_prefix, tower_tol, behind_fli
                 print(f"   {k:60s} {e:.2e}")
         else:
             worst = max(worst, e)
-            lo = loose_tol is not None and k.startswith(tuple(loose))
+            lo = loose_tol is not None and ((k in upstream) if upstream is not None else k.startswith(tuple(loose)))
             if os.environ.get("EG_GRAD_REPORT"):
                 print(f"   {k:60s} {e:.2e}{'  (upstream of a flipped ReLU element)' if lo else ''}")
             if not e < (loose_tol if lo else tol):
@@ -711,14 +782,6 @@ BEAT_LONG_STEP_BEHIND_FLIP = {"f32": (), "bf16x3": ()}               # none abov
 EMOTION_NET_BEHIND_FLIP = ("emotion_encoder.layer1.1.se.fc.0.weight", "emotion_encoder.layer1.1.se.fc.0.bias")       # 7.8e-2: one hidden SE unit (4 units x 2 samples)
 TED_STEP_BEHIND_FLIP = ()            # p = 0 step: no tower parameter above 5e-2 (worst 3.3e-3: layer1.1.se.fc.0)
 DROPOUT_STEP_BEHIND_FLIP = ()        # Dropout-ON step: the whole tower sits 2e-4 .. 3.3e-3 off (a ReLU mask element downstream of it), none above 5e-2
-# Outside the tower: with these masks ONE hidden unit of encoder.layer_stack.0.pos_ffn (relu(w_1 x), SubLayers.py:78; 68 x 2048 x 6 = 835 k such ReLU
-# elements in the step) has a pre-activation within fp32 round-off of zero and is decided differently by the GPU's and the CPU's fp32 forwards.  That
-# element carries 4e-4 of w_1's gradient and everything UPSTREAM of it inherits its share (measured 1.1e-4 .. 4.1e-4: the list below, and the whole
-# tower at 2e-4 .. 3.3e-3); every other parameter -- encoder layers 1-2, the decoder, post_projector, the prior encoder, layer 0's w_2 / LayerNorms --
-# agrees to 1.8e-6 .. 4e-6.  A Dropout site applied with a wrong mask, scale or placement moves the gradients behind it by O(1).
-DROPOUT_STEP_UPSTREAM_OF_THE_FLIP = ("audio_encoder.final_conv1", "audio_encoder.bn1", "audio_encoder.fc1", "audio_encoder.fc2", "emotion_proj.", "semantic_proj.",
-                                     "fusion_proj.", "encoder.layer_stack.0.slf_attn.", "encoder.layer_stack.0.pos_ffn.w_1.")
-
 
 def test_generator_train_step_gradients_match_oracle():
     """One training step of BASELINE configs[2] at B = 2 (TED shapes): loss = 100 smooth_l1(pose) + CE(emotion), train-mode
@@ -735,24 +798,30 @@ def test_generator_train_step_gradients_match_oracle():
     inp = synth_inputs(batch, 34, 126, 4, seed=seed)
     target = torch.from_numpy((hash_unit("train.target_pose", batch * 34 * 126, seed) - 0.5).astype(np.float32).reshape(batch, 34, 126))
     label = torch.from_numpy(inp["label"]).argmax(1)
-    loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
-                                                          torch.from_numpy(inp["pre_pose"]), target, label)
-    loss_ref.backward()
+    with _OracleReluSites() as osites:
+        loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
+                                                              torch.from_numpy(inp["pre_pose"]), target, label)
     model.to(DEV).train()
-    pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
-                                      torch.from_numpy(inp["pre_pose"]).to(DEV), None)
-    loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
-    loss.backward()
+    with _ReluSites(F) as gsites:
+        pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
+                                          torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+        loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
+        loss.backward()
+    # the ReLU units outside the tower that the two fp32 forwards decide differently at these weights / inputs, and what they are upstream of
+    flips, upstream = _flipped_units_and_their_upstream(osites.sites, gsites.sites, sd, min_matched=12)
+    loss_ref.backward()
     assert abs(float(loss) - float(z["gen/loss"])) / float(z["gen/loss"]) < 1e-5            # vs the REFERENCE's loss
     assert np.abs(pose.detach().cpu().numpy() - z["gen/pose"]).max() < 1e-4
     assert np.abs(pred.detach().cpu().numpy() - z["gen/emotion_prediction"]).max() < 1e-4
     bn = model.audio_encoder.feat_extractor.layer2[0].bn1                                   # running statistics after one train forward
     assert np.abs(bn.running_mean.cpu().numpy() - z["gen/bn_running_mean"]).max() < 1e-5
     assert np.abs(bn.running_var.cpu().numpy() - z["gen/bn_running_var"]).max() < 1e-5 * max(1.0, float(z["gen/bn_running_var"].max()))
-    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2, behind_flip=TED_STEP_BEHIND_FLIP)
-    assert n == 260 and tight >= 120          # every parameter outside the tower + the tower blocks downstream of the first mask flip
+    # outside the tower: 1e-4 for every parameter, except (1e-2) those autograd reaches from a flipped unit of THIS run -- computed, not listed
+    worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2, behind_flip=TED_STEP_BEHIND_FLIP,
+                                                        loose_tol=1e-2, upstream=upstream)
+    assert n == 260 and tight >= (120 if not flips else 30)          # every parameter outside the tower + the tower blocks downstream of the first mask flip
     print(f"generator: {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; "
-          f"{tight} within 1e-4")
+          f"{tight} within 1e-4; flipped ReLU units outside the tower (oracle site, count): {flips}, {len(upstream)} parameters upstream of them")
     assert txt is not None and tuple(txt.shape) == (batch, 60, 512)
 
 
@@ -779,19 +848,19 @@ def test_generator_train_step_with_dropout_on_matches_oracle_and_reference():
     label = torch.from_numpy(inp["label"]).argmax(1)
     plan = O.dropout_site_plan(O.GenCfg(), batch)
     masks, where = O.dropout_plan_masks(plan, mseed)
-    with O.dropout_masks(lambda site, x: masks.get(site)):
+    with O.dropout_masks(lambda site, x: masks.get(site)), _OracleReluSites() as osites:
         loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(), torch.from_numpy(inp["spec"]), torch.from_numpy(inp["text"]),
                                                               torch.from_numpy(inp["pre_pose"]), target, label)
-    loss_ref.backward()
     model.to(DEV).train()
     model.train_dropout = True
     try:
         F.manual_seed(mseed)
         sites = F.record_dropout_sites()
-        pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
-                                          torch.from_numpy(inp["pre_pose"]).to(DEV), None)
-        loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
-        loss.backward()
+        with _ReluSites(F) as gsites:
+            pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
+                                              torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+            loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
+            loss.backward()
         assert sites == where, (len(sites), len(where), sites[:6], where[:6])
         for i in (0, 5, len(plan) - 1):                     # a [B, F, D] site, an attention-probability site, the last one
             site, shape, p = plan[i]
@@ -806,12 +875,19 @@ def test_generator_train_step_with_dropout_on_matches_oracle_and_reference():
     assert np.abs(emo.detach().cpu().numpy()[:, ::4, ::16] - z["gen/emotion_feature"]).max() < 1e-4
     p0 = np.load(os.path.join(GOLDEN, "grads.npz"))
     assert abs(float(loss.detach()) - float(p0["gen/loss"])) > 1e-2 * float(p0["gen/loss"])           # and really not the p = 0 step
-    # 1e-4 everywhere outside the tower except the named parameters upstream of the one flipped FFN unit (2e-3); the tower's own bounds inside it
+    # With these masks a hidden unit of an FFN (relu(w_1 x), SubLayers.py:78; 68 x 2048 x 6 = 835 k such elements in the step) can have a pre-activation
+    # within fp32 round-off of zero and be decided differently by the GPU's and the CPU's fp32 forwards; it then carries ~4e-4 of w_1's gradient and
+    # everything UPSTREAM of it inherits its share.  Which unit that is moves with every ulp of the arithmetic (round 6 saw encoder layer 0, then decoder
+    # layer 0), so the set is COMPUTED for this run: the masks of both forwards are recorded, matched by content, and autograd says which parameters the
+    # flipped units depend on.  1e-4 everywhere outside the tower except those (1e-2: the prior branch's small gradients sit at 1-4e-3 behind a flipped decoder unit); the tower's own bounds inside it.  A Dropout site applied with
+    # a wrong mask, scale or placement moves the gradients behind it by O(1).
+    flips, upstream = _flipped_units_and_their_upstream(osites.sites, gsites.sites, sd, min_matched=12)
+    loss_ref.backward()
     worst, worst_tower, n, tight = _compare_param_grads(model, sd, 1e-4, "audio_encoder.feat_extractor.", 2e-2, behind_flip=DROPOUT_STEP_BEHIND_FLIP,
-                                                        loose=DROPOUT_STEP_UPSTREAM_OF_THE_FLIP, loose_tol=2e-3)
+                                                        loose_tol=1e-2, upstream=upstream)
     assert n == 260
     print(f"generator, Dropout ON: {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower (ReLU mask flips) {worst_tower:.2e}; "
-          f"{tight} within 1e-4")
+          f"{tight} within 1e-4; flipped ReLU units outside the tower (oracle site, count): {flips}, {len(upstream)} parameters upstream of them")
 
 
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16x3", 3e-3)])
@@ -834,24 +910,30 @@ def test_beat_long_generator_train_step_matches_oracle(precision, tol):
     inp = synth_inputs(B, Fr, D, P, spec_len=T, seed=seed)
     target = torch.from_numpy((hash_unit("train.target_pose", B * Fr * D, seed) - 0.5).astype(np.float32).reshape(B, Fr, D))
     label = torch.from_numpy(inp["label"]).argmax(1)
-    loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(frames=Fr, pose_dim=D, prior_frames=P, chunk=10), torch.from_numpy(inp["spec"]),
-                                                          torch.from_numpy(inp["text"]), torch.from_numpy(inp["pre_pose"]), target, label)
-    loss_ref.backward()
+    with _OracleReluSites() as osites:
+        loss_ref, pose_ref, pred_ref = O.generator_train_loss(sd, O.GenCfg(frames=Fr, pose_dim=D, prior_frames=P, chunk=10), torch.from_numpy(inp["spec"]),
+                                                              torch.from_numpy(inp["text"]), torch.from_numpy(inp["pre_pose"]), target, label)
     model.to(DEV).train()
     try:
         F.set_precision(precision)
-        pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
-                                          torch.from_numpy(inp["pre_pose"]).to(DEV), None)
-        loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
-        loss.backward()
+        with _ReluSites(F) as gsites:
+            pose, emo, sem, pred, txt = model(torch.from_numpy(inp["spec"]).to(DEV), torch.from_numpy(inp["text"]).to(DEV),
+                                              torch.from_numpy(inp["pre_pose"]).to(DEV), None)
+            loss = F.add(F.smooth_l1_loss(pose, target.to(DEV), 1.0, 100.0), F.cross_entropy(pred, label.to(DEV)))
+            loss.backward()
     finally:
         F.set_precision("f32")
+    # the ReLU units outside the tower decided differently by this run and the oracle (rounding-sized pre-activations: 1e-4 in fp32, the split-bf16
+    # product's 5e-5 relative error on O(10) pre-activations allows 2e-3), and the parameters autograd reaches from them
+    flips, upstream = _flipped_units_and_their_upstream(osites.sites, gsites.sites, sd, min_matched=12, bound=1e-4 if precision == "f32" else 2e-3)
+    loss_ref.backward()
     assert tuple(pose.shape) == (B, Fr, D)
     assert abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach()) < tol
     assert rel(pose.detach(), pose_ref.detach()) < tol
     worst, worst_tower, n, tight = _compare_param_grads(model, sd, 5 * tol, "audio_encoder.feat_extractor.", 2e-2 if precision == "f32" else 5e-2,
-                                                        behind_flip=BEAT_LONG_STEP_BEHIND_FLIP[precision])
-    print(f"BEAT-long generator ({precision}): {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower {worst_tower:.2e}")
+                                                        behind_flip=BEAT_LONG_STEP_BEHIND_FLIP[precision], loose_tol=max(5 * tol, 1e-2), upstream=upstream)
+    print(f"BEAT-long generator ({precision}): {n} parameter gradients; outside the conv tower worst rel-L2 vs oracle {worst:.2e}; tower {worst_tower:.2e}; "
+          f"flipped ReLU units outside the tower (oracle site, count): {flips}, {len(upstream)} parameters upstream of them")
 
 
 @pytest.mark.parametrize("variant", ["spatial", "memory"])
